@@ -1,0 +1,107 @@
+/* orbline_types.h -- POD records and parameter blocks shared by the HIP library
+ * (liborbline_hip.so), the C++ adaptor and the CPU oracle.
+ *
+ * Every record mirrors, field for field, a type that crosses the reference's
+ * ORBextractor / Lineextractor / ORBmatcher / LineMatcher / Frame surfaces
+ * (paths relative to /root/reference):
+ *   olf_keypoint  == cv::KeyPoint (28 B) as filled by src/ORBextractor.cc:839-849,1097-1103
+ *   olf_keyline   == cv::line_descriptor::KeyLine (68 B),
+ *                    Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp:105-144
+ *   descriptors   == rows of a continuous cv::Mat N x 32 CV_8U (src/ORBextractor.cc:1069,
+ *                    Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:634)
+ */
+#ifndef ORBLINE_TYPES_H
+#define ORBLINE_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLF_DESC_BYTES 32      /* 256-bit ORB and LBD descriptors                     */
+#define OLF_MAX_LEVELS 16
+#define OLF_GRID_COLS 64       /* include/Frame.h:51 FRAME_GRID_COLS                  */
+#define OLF_GRID_ROWS 48       /* include/Frame.h:52 FRAME_GRID_ROWS                  */
+
+typedef struct olf_keypoint {
+    float x, y;        /* pt, level-0 pixel coordinates                                 */
+    float size;        /* (int)(31*scale[octave])                                       */
+    float angle;       /* degrees [0,360)                                               */
+    float response;    /* FAST score                                                    */
+    int32_t octave;
+    int32_t class_id;  /* -1, as cv::KeyPoint's default                                 */
+} olf_keypoint;
+
+typedef struct olf_keyline {
+    float angle;
+    int32_t class_id;
+    int32_t octave;
+    float pt_x, pt_y;
+    float response;
+    float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength;
+    int32_t numOfPixels;
+} olf_keyline;
+
+/* ORBextractor ctor arguments, src/ORBextractor.cc:412-416; values from
+ * Examples/PL/PL_KITTI00-02.yaml:42-55 are the defaults of olf_default_params(). */
+typedef struct olf_orb_params {
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} olf_orb_params;
+
+/* Lineextractor 11-argument ctor (include/LineExtractor.h:44-45) -- the LSD options
+ * forwarded at src/LineExtractor.cc:44-53. */
+typedef struct olf_line_params {
+    int32_t lsd_nfeatures;      /* 0 = keep all                                        */
+    double  min_line_length;    /* relative to min(w,h); src/LineExtractor.cc:53       */
+    int32_t lsd_refine;         /* only 0 (LSD_REFINE_NONE) is on the path             */
+    double  lsd_scale;
+    double  lsd_sigma_scale;
+    double  lsd_quant;
+    double  lsd_ang_th;
+    double  lsd_log_eps;
+    double  lsd_density_th;
+    int32_t lsd_n_bins;
+} olf_line_params;
+
+/* Camera / matching scalars read on the path:
+ * src/Tracking.cc:54-79,156 ; src/Config.cpp:26-160 */
+typedef struct olf_stereo_params {
+    float  fx;                  /* Camera.fx                                           */
+    float  bf;                  /* Camera.bf                                           */
+    int32_t matching_s_ws;      /* Config::matchingSWs()                               */
+    double line_sim_th;         /* Config::lineSimTh()                                 */
+    double min_ratio_12_l;      /* Config::minRatio12L()                               */
+    double min_disp;            /* Config::minDisp()                                   */
+    double line_horiz_th;       /* Config::lineHorizTh()                               */
+    double stereo_overlap_th;   /* Config::stereoOverlapTh()                           */
+    double ls_min_disp_ratio;   /* Config::lsMinDispRatio()                            */
+    int32_t best_lr_matches;    /* Config::bestLRMatches()                             */
+} olf_stereo_params;
+
+typedef struct olf_params {
+    olf_orb_params    orb;
+    olf_line_params   line;
+    olf_stereo_params stereo;
+} olf_params;
+
+/* status codes returned by every entry point */
+enum {
+    OLF_OK = 0,
+    OLF_ERR_INVALID = -1,     /* bad argument (null, size mismatch, non-8UC1 ...)      */
+    OLF_ERR_CAPACITY = -2,    /* caller-supplied capacity too small                    */
+    OLF_ERR_HIP = -3,         /* HIP runtime error, see olf_last_error()               */
+    OLF_ERR_NODEVICE = -4     /* no gfx950 device visible                              */
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,128 @@
+// oracle_common.cpp -- CPU ORACLE (test infrastructure): restated OpenCV 3.4 primitives.
+// See oracle_common.hpp for scope; every function cites what it restates.
+#include "oracle_common.hpp"
+#include <cfloat>
+
+namespace orc {
+
+// cv::getGaussianKernel(n, sigma>0, CV_32F): taps exp(-x^2/(2 sigma^2)) stored as float,
+// normalised by the double sum of the float taps; createSeparableLinearFilter then converts
+// them with convertTo(CV_32S, 256) (cvRound).  SURVEY App. A.3.
+std::vector<int> gaussian_taps_q8(int n, double sigma)
+{
+    std::vector<float> cf(n);
+    double scale2X = -0.5 / (sigma * sigma), sum = 0;
+    for (int i = 0; i < n; ++i) {
+        double x = i - (n - 1) * 0.5;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    std::vector<int> q(n);
+    for (int i = 0; i < n; ++i) {
+        cf[i] = (float)(cf[i] * sum);
+        q[i] = cvRound((double)cf[i] * 256.0);
+    }
+    return q;
+}
+
+// Separable fixed-point filter: row pass exact int32, column pass (sum + 2^15) >> 16, saturated.
+Image gaussian_blur_u8(const Image& src, const std::vector<int>& taps)
+{
+    const int n = (int)taps.size(), r = n / 2, w = src.w, h = src.h;
+    std::vector<int> tmp((size_t)w * h);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* s = src.row(y);
+        for (int x = 0; x < w; ++x) {
+            int acc = 0;
+            for (int k = 0; k < n; ++k) acc += taps[k] * s[reflect101(x + k - r, w)];
+            tmp[(size_t)y * w + x] = acc;
+        }
+    }
+    Image dst(w, h);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            int acc = 0;
+            for (int k = 0; k < n; ++k) acc += taps[k] * tmp[(size_t)reflect101(y + k - r, h) * w + x];
+            dst.at(x, y) = sat_u8((acc + 32768) >> 16);
+        }
+    return dst;
+}
+
+// cv::resize INTER_LINEAR, 8UC1: 11-bit coefficients (INTER_RESIZE_COEF_SCALE = 2048),
+// HResizeLinear<uchar,int,short> then VResizeLinear's 8-bit specialisation.  SURVEY App. A.2.
+Image resize_linear_u8(const Image& src, int dw, int dh, double scale_x, double scale_y)
+{
+    const int sw = src.w, sh = src.h;
+    std::vector<int> xofs(dw), a0(dw), a1(dw);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        a0[dx] = (int16_t)std::min(std::max(cvRoundf((1.f - fx) * 2048.f), -32768), 32767);
+        a1[dx] = (int16_t)std::min(std::max(cvRoundf(fx * 2048.f), -32768), 32767);
+    }
+    Image dst(dw, dh);
+    std::vector<int> h0(dw), h1(dw);
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloor(fy);
+        fy -= sy;
+        int b0 = (int16_t)cvRoundf((1.f - fy) * 2048.f), b1 = (int16_t)cvRoundf(fy * 2048.f);
+        int y0 = std::min(std::max(sy, 0), sh - 1), y1 = std::min(std::max(sy + 1, 0), sh - 1);
+        const uint8_t *S0 = src.row(y0), *S1 = src.row(y1);
+        for (int dx = 0; dx < dw; ++dx) {
+            int sx = xofs[dx], sx1 = std::min(sx + 1, sw - 1);
+            h0[dx] = S0[sx] * a0[dx] + S0[sx1] * a1[dx];
+            h1[dx] = S1[sx] * a0[dx] + S1[sx1] * a1[dx];
+        }
+        uint8_t* D = dst.row(dy);
+        for (int dx = 0; dx < dw; ++dx)
+            D[dx] = (uint8_t)((((b0 * (h0[dx] >> 4)) >> 16) + ((b1 * (h1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    return dst;
+}
+
+// cv::fastAtan2 -> atanImpl<float>; SURVEY App. A.5.  fp32, no FMA.
+float fastAtan2(float y, float x)
+{
+    static const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    static const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    static const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    static const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// The reference's SWAR bit count over 8 x 32-bit words.
+int hamming256(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t pa, pb;
+        std::memcpy(&pa, a + 4 * i, 4);
+        std::memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+}  // namespace orc

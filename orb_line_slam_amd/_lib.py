@@ -1,0 +1,136 @@
+"""ctypes binding of liborbline_hip.so (include/orbline.h, include/orbline_types.h).
+
+The library is built in-tree by `make -C orb_line_slam_amd/csrc` (or __graft_entry__.build()).
+Importing this module never touches the GPU; creating a context does.  A missing library is a hard
+error -- there is no pure-Python or CPU path behind these classes.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liborbline_hip.so")
+SYNTH_PATH = os.path.join(_HERE, "csrc", "libolf_synth.so")
+
+OLF_OK, OLF_ERR_INVALID, OLF_ERR_CAPACITY, OLF_ERR_HIP, OLF_ERR_NODEVICE = 0, -1, -2, -3, -4
+DESC_BYTES = 32
+
+# cv::KeyPoint (28 B) and cv::line_descriptor::KeyLine (68 B) record layouts
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+KEYLINE_DTYPE = np.dtype([("angle", "<f4"), ("class_id", "<i4"), ("octave", "<i4"), ("pt_x", "<f4"), ("pt_y", "<f4"),
+                          ("response", "<f4"), ("size", "<f4"), ("startPointX", "<f4"), ("startPointY", "<f4"),
+                          ("endPointX", "<f4"), ("endPointY", "<f4"), ("sPointInOctaveX", "<f4"),
+                          ("sPointInOctaveY", "<f4"), ("ePointInOctaveX", "<f4"), ("ePointInOctaveY", "<f4"),
+                          ("lineLength", "<f4"), ("numOfPixels", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28 and KEYLINE_DTYPE.itemsize == 68
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class LineParams(C.Structure):
+    _fields_ = [("lsd_nfeatures", C.c_int32), ("min_line_length", C.c_double), ("lsd_refine", C.c_int32),
+                ("lsd_scale", C.c_double), ("lsd_sigma_scale", C.c_double), ("lsd_quant", C.c_double),
+                ("lsd_ang_th", C.c_double), ("lsd_log_eps", C.c_double), ("lsd_density_th", C.c_double),
+                ("lsd_n_bins", C.c_int32)]
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("fx", C.c_float), ("bf", C.c_float), ("matching_s_ws", C.c_int32), ("line_sim_th", C.c_double),
+                ("min_ratio_12_l", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
+                ("stereo_overlap_th", C.c_double), ("ls_min_disp_ratio", C.c_double), ("best_lr_matches", C.c_int32)]
+
+
+class OlfParams(C.Structure):
+    _fields_ = [("orb", OrbParams), ("line", LineParams), ("stereo", StereoParams)]
+
+
+class OlfError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: status {code}: {last_error()}")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_line_slam_amd/csrc` "
+                              "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.olf_last_error.restype = C.c_char_p
+        L.olf_ctx_create.argtypes = [C.POINTER(OlfParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.olf_ctx_destroy.argtypes = [C.c_void_p]
+        L.olf_ctx_destroy.restype = None
+        L.olf_ctx_synchronize.argtypes = [C.c_void_p]
+        L.olf_orb_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.olf_orb_level_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_orb_capacity.argtypes = [C.c_void_p]
+        L.olf_orb_extract_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_orb_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.olf_orb_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().olf_last_error().decode()
+
+
+def device_count():
+    return int(lib().olf_device_count())
+
+
+def default_params():
+    p = OlfParams()
+    rc = lib().olf_default_params(C.byref(p))
+    if rc != OLF_OK:
+        raise OlfError(rc, "olf_default_params")
+    return p
+
+
+def check(rc, where):
+    if rc != OLF_OK:
+        raise OlfError(rc, where)
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One olf_ctx: fixed image size, parameters and per-call image capacity."""
+
+    def __init__(self, params, width, height, max_images):
+        self.params, self.width, self.height, self.max_images = params, int(width), int(height), int(max_images)
+        h = C.c_void_p()
+        check(lib().olf_ctx_create(C.byref(params), self.width, self.height, self.max_images, C.byref(h)), "olf_ctx_create")
+        self.handle = h
+        self.nlevels = params.orb.nlevels
+        self.orb_capacity = int(lib().olf_orb_capacity(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().olf_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().olf_ctx_synchronize(self.handle), "olf_ctx_synchronize")

@@ -1,0 +1,158 @@
+// host_tables.cpp -- host-side tables of the ORB extractor (product code, no oracle dependency).
+//
+// Mirrors ORBextractor::ORBextractor (reference src/ORBextractor.cc:412-472): float scale chain,
+// per-level quotas, umax; ComputePyramid's level sizes (:1113-1114); the FAST cell grid of
+// ComputeKeyPointsOctTree (:775-789); the root layout of DistributeOctTree (:545-547); and the
+// coefficient tables cv::resize(INTER_LINEAR) builds for an 8-bit image and
+// cv::getGaussianKernel + 8-bit fixed point conversion (App. A.3).  These are evaluated once per
+// context on the host, in the same float/double expressions as the reference, and uploaded.
+#include "olf_internal.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cfenv>
+
+namespace olf {
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }   // cvRound: half-to-even
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
+
+std::vector<int> gaussian_taps_q8(int n, double sigma)
+{
+    std::vector<float> cf(n);
+    double scale2X = -0.5 / (sigma * sigma), sum = 0;
+    for (int i = 0; i < n; ++i) {
+        double x = i - (n - 1) * 0.5;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    std::vector<int> q(n);
+    for (int i = 0; i < n; ++i) {
+        cf[i] = (float)(cf[i] * sum);
+        q[i] = cv_round_d((double)cf[i] * 256.0);
+    }
+    return q;
+}
+
+void resize_axis_coefs(int sn, int dn, double scale, bool clamp_like_x, ResizeCoef* coef)
+{
+    for (int d = 0; d < dn; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor(f);
+        f -= s;
+        if (clamp_like_x) {   // horizontal: cv::resize forces the weight when the tap leaves the row
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= sn - 1) { f = 0; s = sn - 1; }
+        }
+        int a0 = cv_round_f((1.f - f) * 2048.f), a1 = cv_round_f(f * 2048.f);
+        coef[d].ofs = (int16_t)s;   // vertical: rows s and s+1 are clipped to [0, sn) by the kernel
+        coef[d].a0 = (int16_t)std::min(std::max(a0, -32768), 32767);
+        coef[d].a1 = (int16_t)std::min(std::max(a1, -32768), 32767);
+        coef[d].pad = 0;
+    }
+}
+
+int OrbHostTables::build(const olf_orb_params& p, int W, int H)
+{
+    const int nlevels = p.nlevels;
+    if (nlevels < 1 || nlevels > OLF_MAX_LEVELS || p.nfeatures < 1 || !(p.scale_factor > 1.0f)) return OLF_ERR_INVALID;
+    const double scaleFactor = p.scale_factor;   // the member is a double (include/ORBextractor.h:103)
+    sf.assign(nlevels, 1.f); sigma2.assign(nlevels, 1.f); inv_sf.resize(nlevels); inv_sigma2.resize(nlevels);
+    for (int i = 1; i < nlevels; ++i) {
+        sf[i] = (float)(sf[i - 1] * scaleFactor);
+        sigma2[i] = sf[i] * sf[i];
+    }
+    for (int i = 0; i < nlevels; ++i) {
+        inv_sf[i] = 1.0f / sf[i];
+        inv_sigma2[i] = 1.0f / sigma2[i];
+    }
+    nPerLevel.resize(nlevels);
+    float factor = (float)(1.0f / scaleFactor);
+    float nDesired = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; ++l) {
+        nPerLevel[l] = cv_round_f(nDesired);
+        sum += nPerLevel[l];
+        nDesired *= factor;
+    }
+    nPerLevel[nlevels - 1] = std::max(p.nfeatures - sum, 0);
+
+    OrbGeom& g = geom;
+    g = OrbGeom();
+    g.nlevels = nlevels; g.W = W; g.H = H; g.in_pitch = W;
+    g.iniTh = std::min(std::max(p.ini_th_fast, 1), 255);
+    g.minTh = std::min(std::max(p.min_th_fast, 1), 255);
+    {
+        int v, v0, vmax = cv_floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+        int vmin = cv_ceil(kHalfPatch * std::sqrt(2.f) / 2);
+        const double hp2 = kHalfPatch * kHalfPatch;
+        for (v = 0; v <= vmax; ++v) g.umax[v] = cv_round_d(std::sqrt(hp2 - v * v));
+        for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+            while (g.umax[v0] == g.umax[v0 + 1]) ++v0;
+            g.umax[v] = v0;
+            ++v0;
+        }
+    }
+    std::vector<int> taps = gaussian_taps_q8(7, 2.0);
+    for (int i = 0; i < 7; ++i) g.blurTaps[i] = taps[i];
+
+    rx.clear(); ry.clear();
+    int off = 0, cells = 0, cand = 0, kps = 0, cellCap = 1, maxQuota = 1;
+    for (int l = 0; l < nlevels; ++l) {
+        LevelGeom& L = g.lv[l];
+        L.w = cv_round_f((float)W * inv_sf[l]);
+        L.h = cv_round_f((float)H * inv_sf[l]);
+        // every level must hold at least one 30 px FAST cell and a landscape octree root
+        if (L.w - 2 * kMinBorder < 30 || L.h - 2 * kMinBorder < 30) return OLF_ERR_INVALID;
+        L.pitch = (L.w + 63) & ~63;
+        L.offset = off;
+        off += L.pitch * L.h;
+        off = (off + 255) & ~255;
+        L.maxBorderX = L.w - kMinBorder; L.maxBorderY = L.h - kMinBorder;
+        const float width = (float)(L.maxBorderX - kMinBorder), height = (float)(L.maxBorderY - kMinBorder);
+        L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+        L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+        L.cellBase = cells;
+        cells += L.nCols * L.nRows;
+        cellCap = std::max(cellCap, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
+        L.quota = nPerLevel[l];
+        maxQuota = std::max(maxQuota, L.quota);
+        L.nIni = (int)std::round(width / height);
+        if (L.nIni < 1) return OLF_ERR_INVALID;   // portrait images divide by zero in the reference
+        L.hX = width / L.nIni;
+        L.scale = sf[l]; L.inv_scale = inv_sf[l];
+        L.patch_size = (int)(31 * sf[l]);
+        L.kpBase = kps; L.kpCap = L.quota + 8; kps += L.kpCap;
+        if (l > 0) {
+            const LevelGeom& P = g.lv[l - 1];
+            L.resizeTabX = (int)rx.size(); L.resizeTabY = (int)ry.size();
+            rx.resize(rx.size() + L.w); ry.resize(ry.size() + L.h);
+            // cv::resize with an explicit dsize: inv_scale = dsize/ssize, scale = 1/inv_scale
+            double inv_x = (double)L.w / P.w, inv_y = (double)L.h / P.h;
+            resize_axis_coefs(P.w, L.w, 1. / inv_x, true, &rx[L.resizeTabX]);
+            resize_axis_coefs(P.h, L.h, 1. / inv_y, false, &ry[L.resizeTabY]);
+        }
+    }
+    g.pyrBytes = off;
+    g.totalCells = cells;
+    g.cellCap = cellCap;
+    for (int l = 0; l < nlevels; ++l) {
+        LevelGeom& L = g.lv[l];
+        long cap = (long)L.nCols * L.nRows * cellCap;
+        L.candCap = (int)std::min<long>(cap, 65535);
+        L.candBase = cand;
+        cand += (L.candCap + 63) & ~63;
+    }
+    g.candTotal = cand;
+    g.kpTotal = kps;
+    g.outCap = kps;
+    int mn = 64;
+    while (mn < maxQuota + 8) mn <<= 1;
+    g.maxNodes = mn;
+    if (mn > 4096) return OLF_ERR_INVALID;
+    return OLF_OK;
+}
+
+}  // namespace olf

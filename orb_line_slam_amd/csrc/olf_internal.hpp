@@ -1,0 +1,119 @@
+// olf_internal.hpp -- internal layout of the device context behind the C ABI (include/orbline.h).
+//
+// One olf_ctx serves a fixed image size (w x h), a fixed parameter block and up to max_images
+// images per call (a stereo pair = 2 images: index 2*pair + side).  All buffers are allocated once
+// at creation and sized for the worst case, so the hot path never allocates; with 288 GB of HBM3E
+// a context for hundreds of KITTI pairs is a few GB.
+//
+// HBM layout (per image, all level images packed with a 64-byte aligned pitch):
+//   pyr   : u8  levels 0..L-1   (level 0 is an aligned copy of the input)      mvImagePyramid
+//   blur  : u8  levels 0..L-1   GaussianBlur(7x7, sigma 2) of pyr               workingMat
+//   score : u8  levels 0..L-1   FAST-9/16 score (0 where score < minThFAST)
+//   cells : u32 per FAST cell a slot of cell_cap packed candidates (x:12 | y:12 | score:8, cell-local
+//           coordinates are converted to level coordinates relative to minBorder) + one count
+//   cand  : u32 per level, candidates gathered in reference order (vToDistributeKeys)
+//   lvl_kp: u32 per level, octree survivors in lNodes order
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/orbline_types.h"
+
+#define OLF_HIP_CHECK(expr)                                                                 \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            olf::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            return OLF_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+namespace olf {
+
+void set_error(const std::string& s);
+
+constexpr int kEdge = 19;          // EDGE_THRESHOLD   src/ORBextractor.cc:76
+constexpr int kMinBorder = 16;     // EDGE_THRESHOLD-3 src/ORBextractor.cc:775
+constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE  src/ORBextractor.cc:75
+
+// Geometry of one pyramid level; identical for every image of the context.
+struct LevelGeom {
+    int w, h, pitch;        // level size; pitch is a multiple of 64
+    int offset;             // byte offset of the level inside a per-image pyramid block
+    int maxBorderX, maxBorderY;
+    int nCols, nRows, wCell, hCell;   // FAST cell grid, src/ORBextractor.cc:783-789
+    int cellBase;           // index of this level's first cell in the per-image cell arrays
+    int quota;              // mnFeaturesPerLevel[level]
+    int nIni;               // DistributeOctTree root count
+    float hX;               // DistributeOctTree root width
+    float scale;            // mvScaleFactor[level]
+    float inv_scale;        // mvInvScaleFactor[level]
+    int patch_size;         // (int)(31*scale)
+    int candBase;           // offset of this level in the per-image candidate array
+    int candCap;            // capacity of this level's candidate array
+    int kpBase, kpCap;      // per-level survivor array (kpCap = quota + 8)
+    int resizeTabX, resizeTabY;  // offsets into the resize coefficient tables (level >= 1)
+};
+
+struct ResizeCoef { int16_t ofs; int16_t a0; int16_t a1; int16_t pad; };
+
+struct OrbGeom {
+    int nlevels;
+    int W, H, in_pitch;
+    int pyrBytes;           // per image
+    int totalCells;         // per image
+    int cellCap;            // candidates per cell slot
+    int candTotal;          // per image
+    int kpTotal;            // per image (sum of kpCap)
+    int outCap;             // max key points per image returned (nfeatures + 4*nlevels)
+    int iniTh, minTh;
+    int maxNodes;           // octree LDS node capacity (power of two)
+    LevelGeom lv[OLF_MAX_LEVELS];
+    int umax[16];
+    int blurTaps[7];
+};
+
+// Host-side derivation of every table of ORBextractor::ORBextractor (src/ORBextractor.cc:412-472),
+// of the level sizes (:1113-1114), of the cell grid (:775-789) and of the cv::resize
+// coefficient tables.  Pure host code, shared by api.cpp.
+struct OrbHostTables {
+    std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
+    std::vector<int> nPerLevel;
+    OrbGeom geom;
+    std::vector<ResizeCoef> rx, ry;    // concatenated over levels
+    int build(const olf_orb_params& p, int W, int H);
+};
+
+std::vector<int> gaussian_taps_q8(int n, double sigma);
+// fills coef[0..dn) for a 1-D cv::resize(INTER_LINEAR) axis: sn source samples, step `scale`
+void resize_axis_coefs(int sn, int dn, double scale, bool clamp_like_x, ResizeCoef* coef);
+
+// ----------------------------------------------------------------------------------------------
+struct OrbDeviceBufs {
+    uint8_t* pyr = nullptr;       // [max_images][pyrBytes]
+    uint8_t* blur = nullptr;
+    uint8_t* score = nullptr;
+    uint32_t* cells = nullptr;    // [max_images][totalCells][cellCap]
+    int* cellCount = nullptr;     // [max_images][totalCells]
+    uint32_t* cand = nullptr;     // [max_images][candTotal]
+    uint16_t* candNode = nullptr; // [max_images][candTotal]
+    int* candCount = nullptr;     // [max_images][nlevels]
+    uint32_t* lvlKp = nullptr;    // [max_images][kpTotal]
+    int* lvlCount = nullptr;      // [max_images][nlevels]
+    float* lvlAngle = nullptr;    // [max_images][kpTotal]
+    ResizeCoef* rx = nullptr;
+    ResizeCoef* ry = nullptr;
+    OrbGeom* geom = nullptr;      // device copy
+    int* status = nullptr;        // device error flags (capacity overflow etc.)
+};
+
+// kernel launchers (orb_*.hip)
+int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* d_in, int n_images, hipStream_t s);
+int launch_orb_fast(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
+int launch_orb_octree(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
+int launch_orb_blur(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
+int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
+                        int* d_counts, int out_cap, hipStream_t s);
+
+}  // namespace olf

@@ -1,0 +1,104 @@
+// orb_describe.hip -- per-key-point stages of ORBextractor::operator() (reference
+// src/ORBextractor.cc): IC_Angle / computeOrientation (:79-106, :474-481, cv::fastAtan2 App. A.5),
+// computeOrbDescriptor (:110-149) on the blurred level, the scale-up of pt (:1097-1103) and the
+// level-ascending concatenation (:1078-1106).  One 64-lane wave per key point: the 749-pixel
+// intensity-centroid disc is summed 2 rows per pass, the 256 steered-BRIEF tests are 4 ballots.
+#include "olf_internal.hpp"
+#include "device_math.hpp"
+
+namespace olf {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+__global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp, const uint8_t* __restrict__ pyr,
+                                                  const uint8_t* __restrict__ blur, const uint32_t* __restrict__ lvlKp,
+                                                  const int* __restrict__ lvlCount, olf_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int* __restrict__ counts, int out_cap,
+                                                  int* __restrict__ status)
+{
+    const OrbGeom& g = *gp;
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* lc = lvlCount + img * g.nlevels;
+    if (slot == 0 && lane == 0) {
+        int tot = 0;
+        for (int l = 0; l < g.nlevels; ++l) tot += lc[l];
+        if (tot > out_cap) { atomicOr(status, 4); tot = out_cap; }
+        counts[img] = tot;
+    }
+    if (slot >= g.kpTotal) return;
+    int level = 0;
+    while (level + 1 < g.nlevels && slot >= g.lv[level + 1].kpBase) ++level;
+    const LevelGeom& L = g.lv[level];
+    const int i = slot - L.kpBase;
+    if (i >= lc[level]) return;
+    int outIdx = i;
+    for (int l = 0; l < level; ++l) outIdx += lc[l];
+    if (outIdx >= out_cap) return;
+    const uint32_t p = lvlKp[(size_t)img * g.kpTotal + slot];
+    const int cx = (int)(p >> 20) + kMinBorder, cy = (int)((p >> 8) & 0xfff) + kMinBorder, score = (int)(p & 0xff);
+
+    // ---- IC_Angle on the un-blurred level
+    const uint8_t* im = pyr + (size_t)img * g.pyrBytes + L.offset;
+    int m10 = 0, m01 = 0;
+    const int half = lane >> 5, ul = lane & 31;
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+        const int v = -kHalfPatch + 2 * pass + half;
+        if (v <= kHalfPatch) {
+            const int d = g.umax[v < 0 ? -v : v];
+            const int u = ul - 15;
+            if (u >= -d && u <= d) {
+                const int val = im[(size_t)(cy + v) * L.pitch + cx + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = dev_fastAtan2((float)m01, (float)m10);
+
+    // ---- steered BRIEF on the blurred level
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    const float a = glibc_cosf(rad), b = glibc_sinf(rad);
+    const uint8_t* bl = blur + (size_t)img * g.pyrBytes + L.offset + (size_t)cy * L.pitch + cx;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int8_t* pt = &c_pattern[(j * 64 + lane) * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bl[r0 * L.pitch + c0], t1 = bl[r1 * L.pitch + c1];
+        bits[j] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)img * out_cap + outIdx) * OLF_DESC_BYTES);
+        d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+        olf_keypoint k;
+        k.x = (float)cx; k.y = (float)cy;
+        if (level != 0) { k.x = __fmul_rn(k.x, L.scale); k.y = __fmul_rn(k.y, L.scale); }
+        k.size = (float)L.patch_size; k.angle = angle; k.response = (float)score; k.octave = level; k.class_id = -1;
+        kps[(size_t)img * out_cap + outIdx] = k;
+    }
+}
+
+int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
+                        int* d_counts, int out_cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.pyr, b.blur, b.lvlKp, b.lvlCount,
+                       d_kps, d_desc, d_counts, out_cap, b.status);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+}  // namespace olf

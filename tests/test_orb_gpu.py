@@ -1,0 +1,60 @@
+"""GPU parity: ORBextractor on the MI355X vs the CPU oracle, bit-exact (key point coords, octave,
+response, angle, 256-bit descriptors, order), through the C ABI."""
+import numpy as np
+import pytest
+import orb_line_slam_amd as ola
+from orb_line_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    (640, 480, 1000),     # BASELINE config C2
+    (1242, 375, 2000),    # C3 (KITTI)
+    (752, 480, 1200),     # C4 (EuRoC)
+]
+
+
+def _compare(gk, gd, ok, od):
+    assert len(gk) == len(ok), (len(gk), len(ok))
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        a, b = gk[f], ok[f]
+        assert np.array_equal(a.view(np.uint32) if a.dtype.kind == "f" else a, b.view(np.uint32) if b.dtype.kind == "f" else b), f
+    assert np.array_equal(gd, od)
+
+
+@pytest.mark.parametrize("w,h,nf", CONFIGS)
+def test_orb_matches_oracle(oracle, w, h, nf):
+    ex = ola.ORBextractor(nf, 1.2, 8, 20, 7)
+    p = oracle.orb_params(nf)
+    for seed in (1, 2):
+        left, right = synth.stereo_pair(seed, w, h)
+        for img in (left, right):
+            gk, gd = ex(img)
+            o = oracle.orb_extract(img, p, debug=True)
+            # stage-by-stage so a mismatch names the first broken stage
+            for l in range(8):
+                assert np.array_equal(ex.pyramid_level(l), o["pyramid"][l]), f"pyramid level {l}"
+            for l in range(8):
+                assert np.array_equal(ex.debug_candidates(l), o["candidates"][l]), f"candidates level {l}"
+            for l in range(8):
+                if o["blurred"][l].any():
+                    assert np.array_equal(ex.pyramid_level(l, blurred=True), o["blurred"][l]), f"blur level {l}"
+            _compare(gk, gd, o["kps"], o["desc"])
+
+
+def test_orb_batch_equals_single(oracle):
+    w, h = 640, 480
+    imgs = synth.stereo_batch(10, 3, w, h)
+    ex = ola.ORBextractor(1000, 1.2, 8, 20, 7, max_images=6)
+    kps, desc, counts = ex.extract_batch(imgs)
+    p = oracle.orb_params(1000)
+    for i in range(6):
+        o = oracle.orb_extract(imgs[i], p)
+        n = int(counts[i])
+        _compare(kps[i, :n], desc[i, :n], o["kps"], o["desc"])
+
+
+def test_orb_flat_image_has_no_keypoints():
+    ex = ola.ORBextractor(500, 1.2, 8, 20, 7)
+    k, d = ex(np.full((240, 320), 77, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
