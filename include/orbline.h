@@ -58,6 +58,31 @@ int olf_orb_pyramid_level(olf_ctx* ctx, int image, int level, int blurred, uint8
  * src/ORBextractor.cc:821-827) as int32 triples (x,y,score) relative to minBorder. */
 int olf_orb_debug_candidates(olf_ctx* ctx, int image, int level, int32_t* xys, int cap, int32_t* count);
 
+/* ---- Frame::ComputeStereoMatches (src/Frame.cc:702-876) ------------------------------------- */
+/* Stereo point matching for n_pairs pairs whose ORB features (images 2p = left, 2p+1 = right) came from
+ * the immediately preceding olf_orb_extract*_dev call on this context (its device-resident
+ * mvImagePyramid of both extractors is read for the 11x11 SAD refinement, src/Frame.cc:799-816).
+ * Outputs per pair, stride olf_orb_capacity(): mvuRight / mvDepth (-1 = no match), src/Frame.cc:704-705. */
+int olf_stereo_points_dev(olf_ctx* ctx, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_counts,
+                          float* d_uright, float* d_depth, void* stream);
+/* host convenience: ExtractORB x2 + ComputeStereoMatches for n_pairs pairs (images: 2*n_pairs) */
+int olf_stereo_points(olf_ctx* ctx, const uint8_t* images, int n_pairs, olf_keypoint* kps, uint8_t* desc, int32_t* counts,
+                      float* uright, float* depth);
+
+/* ---- LineMatcher / ORBmatcher brute force (src/LineMatcher.cpp:42-62,104-132; App. A.10) ------- */
+/* match(desc1, desc2, nnr, matches_12) for n_sets independent sets: set s has d_nA[s*a_step] rows at
+ * d_descA + s*strideA*32 and d_nB[s*b_step] rows at d_descB + s*strideB*32.  kNN(2) both ways, ratio
+ * test d0 < d1*nnr, mutual check when best_lr (Config::bestLRMatches()).  d_m12: n_sets*strideA ints,
+ * -1 = no match. */
+int olf_match_bf_dev(olf_ctx* ctx, const uint8_t* d_descA, const int32_t* d_nA, int strideA, int a_step, const uint8_t* d_descB,
+                     const int32_t* d_nB, int strideB, int b_step, int n_sets, float nnr, int best_lr, int32_t* d_m12, void* stream);
+int olf_match_bf(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, float nnr, int best_lr, int32_t* m12);
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (host buffers): per query best index, best and second distance
+ * (-1 / INT_MAX where the train set is too small) */
+int olf_knn2(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx0, int32_t* dist0, int32_t* dist1);
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1795-1811) over all pairs: out[nA][nB] uint16 (host buffers) */
+int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out);
+
 #ifdef __cplusplus
 }
 #endif

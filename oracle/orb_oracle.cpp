@@ -10,6 +10,7 @@
 // PARITY UNPINNED (see oracle_common.hpp).  Convention C.1 (octree tie-break): nodes with equal
 // key-point counts are expanded most-recently-created first.
 #include "oracle_common.hpp"
+#include "orb_oracle.hpp"
 #include <list>
 #include <utility>
 
@@ -21,10 +22,6 @@ static const int8_t kPattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
-struct KP {
-    float x, y, size, angle, response;
-    int octave;
-};
 
 struct OrbTables {
     int nfeatures, nlevels, iniTh, minTh;
@@ -266,14 +263,6 @@ static std::vector<KP> distribute_octree(const std::vector<KP>& toDistribute, in
 }
 
 // ---- pyramid / key points / descriptors ---------------------------------------------------
-struct OrbResult {
-    std::vector<Image> pyramid;                 // mvImagePyramid (ROI part; the 19 px border is never read, App. A.1)
-    std::vector<Image> blurred;                 // per-level GaussianBlur(7x7, 2) working images
-    std::vector<std::vector<KP>> candidates;    // vToDistributeKeys per level (coords relative to minBorder)
-    std::vector<std::vector<KP>> level_kps;     // after octree + border + orientation (level coords)
-    std::vector<olf_keypoint> kps;
-    std::vector<uint8_t> desc;
-};
 
 static void compute_pyramid(const Image& img, const OrbTables& T, std::vector<Image>& pyr)
 {
@@ -400,6 +389,12 @@ void orb_extract(const Image& img, const olf_orb_params& p, OrbResult& R)
             R.kps.push_back(o);
         }
     }
+}
+
+void orb_scale_tables(const olf_orb_params& p, std::vector<float>& sf, std::vector<float>& inv_sf)
+{
+    OrbTables T(p);
+    sf = T.sf; inv_sf = T.inv_sf;
 }
 
 }  // namespace orc

@@ -77,6 +77,13 @@ def lib():
         L.olf_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_orb_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.olf_orb_debug_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.olf_stereo_points_dev.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.olf_stereo_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.olf_match_bf_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_match_bf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.olf_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_hamming_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

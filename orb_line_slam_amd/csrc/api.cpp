@@ -26,8 +26,26 @@ struct olf_ctx {
     uint8_t* d_desc = nullptr;
     int* d_counts = nullptr;
     int last_n_images = 0;
+    float* d_uright = nullptr;     // [max_pairs][outCap]
+    float* d_depth = nullptr;
+    int* d_sad = nullptr;
+    // grow-on-demand scratch (matcher k-NN tables, host-pointer staging)
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
 };
+
+static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
+{
+    if (c->scratch_bytes[slot] < bytes) {
+        if (c->scratch[slot]) { OLF_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
+        size_t want = std::max<size_t>(bytes * 3 / 2, 4096);
+        OLF_HIP_CHECK(hipMalloc(&c->scratch[slot], want));
+        c->scratch_bytes[slot] = want;
+    }
+    *out = c->scratch[slot];
+    return OLF_OK;
+}
 
 template <typename T>
 static int dev_alloc(olf_ctx* c, T** p, size_t n)
@@ -74,6 +92,7 @@ void olf_ctx_destroy(olf_ctx* c)
 {
     if (!c) return;
     for (void* p : c->allocs) (void)hipFree(p);
+    for (void* p : c->scratch) if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -103,6 +122,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
     A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 4);
+    A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap);
     A(c->d_images, n * width * height); A(c->d_kps, n * g.outCap); A(c->d_desc, n * g.outCap * OLF_DESC_BYTES); A(c->d_counts, n);
 #undef A
     if (hipMemcpy(b.rx, c->orb.rx.data(), c->orb.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
@@ -212,6 +232,104 @@ int olf_orb_debug_candidates(olf_ctx* c, int image, int level, int32_t* xys, int
     for (int i = 0; i < std::min(n, cap); ++i) {
         xys[3 * i] = tmp[i] >> 20; xys[3 * i + 1] = (tmp[i] >> 8) & 0xfff; xys[3 * i + 2] = tmp[i] & 0xff;
     }
+    return OLF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int olf_stereo_points_dev(olf_ctx* c, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_counts,
+                          float* d_uright, float* d_depth, void* stream)
+{
+    if (!c || !d_kps || !d_desc || !d_counts || !d_uright || !d_depth) { set_error("olf_stereo_points_dev: null argument"); return OLF_ERR_INVALID; }
+    if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return launch_stereo_points(c->orb.geom, c->ob, n_pairs, d_kps, d_desc, d_counts, c->orb.geom.outCap, c->params.stereo.bf,
+                                c->params.stereo.fx, d_uright, d_depth, c->d_sad, s);
+}
+
+int olf_stereo_points(olf_ctx* c, const uint8_t* images, int n_pairs, olf_keypoint* kps, uint8_t* desc, int32_t* counts, float* uright,
+                      float* depth)
+{
+    if (!c || !images || !kps || !desc || !counts || !uright || !depth) { set_error("olf_stereo_points: null argument"); return OLF_ERR_INVALID; }
+    const int n_images = 2 * n_pairs;
+    if (n_pairs < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    const size_t npx = (size_t)c->W * c->H, cap = c->orb.geom.outCap;
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * n_images, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_orb_extract_dev(c, c->d_images, n_images, c->d_kps, c->d_desc, c->d_counts, c->stream));
+    OLF_TRY(olf_stereo_points_dev(c, n_pairs, c->d_kps, c->d_desc, c->d_counts, c->d_uright, c->d_depth, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(kps, c->d_kps, cap * n_images * sizeof(olf_keypoint), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(desc, c->d_desc, cap * n_images * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(counts, c->d_counts, n_images * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(uright, c->d_uright, cap * n_pairs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(depth, c->d_depth, cap * n_pairs * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int olf_match_bf_dev(olf_ctx* c, const uint8_t* dA, const int32_t* nA, int strideA, int a_step, const uint8_t* dB, const int32_t* nB,
+                     int strideB, int b_step, int n_sets, float nnr, int best_lr, int32_t* d_m12, void* stream)
+{
+    if (!c || !dA || !dB || !nA || !nB || !d_m12 || strideA < 0 || strideB < 0 || n_sets < 0) { set_error("olf_match_bf_dev: bad argument"); return OLF_ERR_INVALID; }
+    if (n_sets == 0 || strideA == 0) return OLF_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    void* ws = nullptr;
+    OLF_TRY(scratch_get(c, 0, (size_t)3 * (strideA + strideB) * n_sets * sizeof(int), &ws));
+    return launch_match_bf(dA, nA, strideA, a_step, dB, nB, strideB, b_step, n_sets, nnr, best_lr, (int*)ws, d_m12, s);
+}
+
+// host staging helper: [descA | descB | nA nB | out...]
+int olf_match_bf(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* descB, int nB, float nnr, int best_lr, int32_t* m12)
+{
+    if (!c || !m12 || nA < 0 || nB < 0 || (nA && !descA) || (nB && !descB)) { set_error("olf_match_bf: bad argument"); return OLF_ERR_INVALID; }
+    if (nA == 0) return OLF_OK;
+    void* st = nullptr;
+    const size_t bA = (size_t)nA * 32, bB = (size_t)std::max(nB, 1) * 32;
+    OLF_TRY(scratch_get(c, 1, bA + bB + 64 + (size_t)nA * 4, &st));
+    uint8_t* dA = (uint8_t*)st; uint8_t* dB = dA + bA; int* dn = (int*)(dB + bB); int* dm = dn + 16;
+    int n[2] = {nA, nB};
+    OLF_HIP_CHECK(hipMemcpyAsync(dA, descA, bA, hipMemcpyHostToDevice, c->stream));
+    if (nB) OLF_HIP_CHECK(hipMemcpyAsync(dB, descB, (size_t)nB * 32, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dn, n, sizeof(n), hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_match_bf_dev(c, dA, dn, nA, 1, dB, dn + 1, std::max(nB, 1), 1, 1, nnr, best_lr, dm, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(m12, dm, (size_t)nA * 4, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_knn2(olf_ctx* c, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx0, int32_t* dist0, int32_t* dist1)
+{
+    if (!c || !idx0 || !dist0 || !dist1 || nQ < 0 || nT < 0 || (nQ && !descQ) || (nT && !descT)) { set_error("olf_knn2: bad argument"); return OLF_ERR_INVALID; }
+    if (nQ == 0) return OLF_OK;
+    void* st = nullptr;
+    const size_t bQ = (size_t)nQ * 32, bT = (size_t)std::max(nT, 1) * 32;
+    OLF_TRY(scratch_get(c, 1, bQ + bT + 64 + (size_t)nQ * 12, &st));
+    uint8_t* dQ = (uint8_t*)st; uint8_t* dT = dQ + bQ; int* dn = (int*)(dT + bT); int* o = dn + 16;
+    int n[2] = {nQ, nT};
+    OLF_HIP_CHECK(hipMemcpyAsync(dQ, descQ, bQ, hipMemcpyHostToDevice, c->stream));
+    if (nT) OLF_HIP_CHECK(hipMemcpyAsync(dT, descT, (size_t)nT * 32, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dn, n, sizeof(n), hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_knn2(dQ, dn, nQ, dT, dn + 1, std::max(nT, 1), 1, o, o + nQ, o + 2 * nQ, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(idx0, o, (size_t)nQ * 4, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dist0, o + nQ, (size_t)nQ * 4, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dist1, o + 2 * nQ, (size_t)nQ * 4, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_hamming_matrix(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out)
+{
+    if (!c || !out || nA < 0 || nB < 0 || (nA && !descA) || (nB && !descB)) { set_error("olf_hamming_matrix: bad argument"); return OLF_ERR_INVALID; }
+    if (nA == 0 || nB == 0) return OLF_OK;
+    void* st = nullptr;
+    const size_t bA = (size_t)nA * 32, bB = (size_t)nB * 32, bO = (size_t)nA * nB * 2;
+    OLF_TRY(scratch_get(c, 1, bA + bB + bO, &st));
+    uint8_t* dA = (uint8_t*)st; uint8_t* dB = dA + bA; uint16_t* dO = (uint16_t*)(dB + bB);
+    OLF_HIP_CHECK(hipMemcpyAsync(dA, descA, bA, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dB, descB, bB, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_hamming_matrix(dA, nA, dB, nB, dO, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(out, dO, bO, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return OLF_OK;
 }
 

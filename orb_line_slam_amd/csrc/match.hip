@@ -1,0 +1,307 @@
+// match.hip -- 256-bit Hamming matchers of the path, gfx950.
+//   Frame::ComputeStereoMatches            reference src/Frame.cc:702-876
+//   matchNNR / match(desc1, desc2, nnr)    reference src/LineMatcher.cpp:42-62, :104-132
+//   ORBmatcher::DescriptorDistance         reference src/ORBmatcher.cc:1795-1811 (dense matrix form)
+// Bit counting, not contraction: XOR + v_bcnt (popcount) on 64-bit words, one wave per query,
+// candidates strided over the 64 lanes and reduced with DPP/shuffle min; no MFMA.
+#include "olf_internal.hpp"
+#include "device_math.hpp"
+
+namespace olf {
+
+__device__ __forceinline__ int ham256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
+{
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+           __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ComputeStereoMatches, one wave per left key point of one stereo pair (images 2p, 2p+1).
+constexpr int TH_HIGH = 100, TH_LOW = 50;
+
+__global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict__ gp, const uint8_t* __restrict__ pyr,
+                                                      const olf_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                      const int* __restrict__ counts, int cap, float mbf, float fx,
+                                                      float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad)
+{
+    const OrbGeom& g = *gp;
+    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nL = counts[2 * pair], nR = counts[2 * pair + 1];
+    if (iL >= nL) return;
+    const size_t oL = (size_t)(2 * pair) * cap, oR = (size_t)(2 * pair + 1) * cap;
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    const olf_keypoint kL = kps[oL + iL];
+    const int levelL = kL.octave;
+    const float vL = kL.y, uL = kL.x;
+    const float mb = f_div(mbf, fx);
+    const float maxD = f_div(mbf, mb);
+    const float minU = f_sub(uL, maxD), maxU = uL;
+    const int row = (int)vL;
+    const uint4* dLp = reinterpret_cast<const uint4*>(desc + (oL + iL) * OLF_DESC_BYTES);
+    const uint4 a0 = dLp[0], a1 = dLp[1];
+    // best = min (distance, iR): the reference scans candidates in increasing iR with a strict '<'
+    unsigned best = ((unsigned)TH_HIGH << 16) | 0xffffu;
+    for (int iR = lane; iR < nR; iR += 64) {
+        const olf_keypoint kR = kps[oR + iR];
+        const float r = f_mul(2.0f, g.lv[kR.octave].scale);
+        const int maxr = (int)ceilf(f_add(kR.y, r)), minr = (int)floorf(f_sub(kR.y, r));
+        if (row < minr || row > maxr) continue;
+        if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
+        if (!(kR.x >= minU && kR.x <= maxU)) continue;
+        const uint4* dRp = reinterpret_cast<const uint4*>(desc + (oR + iR) * OLF_DESC_BYTES);
+        const unsigned d = (unsigned)ham256(a0, a1, dRp[0], dRp[1]);
+        const unsigned key = (d << 16) | (unsigned)iR;
+        best = min(best, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    const int bestDist = (int)(best >> 16);
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    if (bestDist < thOrbDist && (best & 0xffffu) != 0xffffu && bestDist < TH_HIGH) {
+        const int bestIdxR = (int)(best & 0xffffu);
+        const float uR0 = kps[oR + bestIdxR].x;
+        const LevelGeom& L = g.lv[levelL];
+        const float scaleFactor = L.inv_scale;
+        const float scaleduL = roundf(f_mul(kL.x, scaleFactor));
+        const float scaledvL = roundf(f_mul(kL.y, scaleFactor));
+        const float scaleduR0 = roundf(f_mul(uR0, scaleFactor));
+        const int w = 5, Ls = 5;
+        const float iniu = scaleduR0 + Ls - w, endu = scaleduR0 + Ls + w + 1;
+        if (!(iniu < 0 || endu >= (float)L.w)) {
+            const uint8_t* IL = pyr + (size_t)(2 * pair) * g.pyrBytes + L.offset;
+            const uint8_t* IR = pyr + (size_t)(2 * pair + 1) * g.pyrBytes + L.offset;
+            const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR0 = (int)scaleduR0;
+            const int cL = IL[(size_t)cy * L.pitch + cxL];
+            // each lane owns up to two of the 121 patch pixels
+            int a[2], py[2], px[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = lane + 64 * k;
+                py[k] = idx / 11 - w; px[k] = idx % 11 - w;
+                a[k] = idx < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
+            }
+            int dists[11];
+#pragma unroll
+            for (int inc = -Ls; inc <= Ls; ++inc) {
+                const int cxR = cxR0 + inc;
+                const int cR = IR[(size_t)cy * L.pitch + cxR];
+                int s = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = lane + 64 * k;
+                    if (idx < 121) {
+                        const int b = (int)IR[(size_t)(cy + py[k]) * L.pitch + cxR + px[k]] - cR;
+                        const int df = a[k] - b;
+                        s += df < 0 ? -df : df;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                dists[inc + Ls] = s;
+            }
+            int bestS = 0x7fffffff, bestinc = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k)
+                if (dists[k] < bestS) { bestS = dists[k]; bestinc = k - Ls; }
+            if (bestinc != -Ls && bestinc != Ls) {
+                float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+                for (int k = 1; k < 10; ++k)
+                    if (k - Ls == bestinc) { dist1 = (float)dists[k - 1]; dist2 = (float)dists[k]; dist3 = (float)dists[k + 1]; }
+                const float num = f_sub(dist1, dist3);
+                const float den = f_mul(2.0f, f_sub(f_add(dist1, dist3), f_mul(2.0f, dist2)));
+                const float deltaR = f_div(num, den);
+                if (!(deltaR < -1 || deltaR > 1)) {
+                    float bestuR = f_mul(L.scale, f_add(f_add(scaleduR0, (float)bestinc), deltaR));
+                    float disparity = f_sub(uL, bestuR);
+                    if (disparity >= 0 && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = 0.01f;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        outD = f_div(mbf, disparity);
+                        outU = bestuR;
+                        outS = bestS;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        uRight[(size_t)pair * cap + iL] = outU;
+        depth[(size_t)pair * cap + iL] = outD;
+        sad[(size_t)pair * cap + iL] = outS;
+    }
+}
+
+// median filter of src/Frame.cc:862-875: drop matches whose SAD >= 1.5*1.4*median(SAD).
+__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ counts, int cap, int sortN, float* __restrict__ uRight,
+                                                       float* __restrict__ depth, const int* __restrict__ sad)
+{
+    extern __shared__ unsigned keys[];
+    __shared__ int nMatched;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nL = counts[2 * pair];
+    if (tid == 0) nMatched = 0;
+    __syncthreads();
+    const int* s = sad + (size_t)pair * cap;
+    int local = 0;
+    for (int i = tid; i < sortN; i += 256) {
+        unsigned k = 0xffffffffu;
+        if (i < nL && s[i] >= 0) { k = (unsigned)s[i]; ++local; }
+        keys[i] = k;
+    }
+    atomicAdd(&nMatched, local);
+    __syncthreads();
+    const int m = nMatched;
+    if (m == 0) return;   // convention C.5: nothing to filter
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = keys[i], b = keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if (asc ? (a > b) : (a < b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const float median = (float)keys[m / 2];
+    const float thDist = f_mul(f_mul(1.5f, 1.4f), median);
+    for (int i = tid; i < nL; i += 256)
+        if (s[i] >= 0 && !((float)s[i] < thDist)) {
+            uRight[(size_t)pair * cap + i] = -1.0f;
+            depth[(size_t)pair * cap + i] = -1.0f;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Brute-force 2-nearest-neighbour search (cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2), App. A.10):
+// per query the two smallest distances; ties keep the lower train index first.  One wave per query.
+// Sets are batched: set s has nQ[s] queries at q + s*strideQ*32 and nT[s] train rows at t + s*strideT*32.
+struct Knn2 { unsigned k0; unsigned d1; };   // k0 = (d0 << 16 | idx), d1 = second distance
+
+__device__ __forceinline__ Knn2 knn_merge(Knn2 a, Knn2 b)
+{
+    Knn2 r;
+    if (a.k0 <= b.k0) { r.k0 = a.k0; r.d1 = min(a.d1, b.k0 >> 16); }
+    else { r.k0 = b.k0; r.d1 = min(b.d1, a.k0 >> 16); }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nQ, int strideQ, int qSetStep,
+                                              const uint8_t* __restrict__ t, const int* __restrict__ nT, int strideT, int tSetStep,
+                                              int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ dist1)
+{
+    const int set = blockIdx.y, lane = threadIdx.x & 63;
+    const int iq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = nQ[set * qSetStep], nt = nT[set * tSetStep];
+    if (iq >= nq) return;
+    const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
+    const uint4 a0 = qp[0], a1 = qp[1];
+    Knn2 best;
+    best.k0 = 0xffffffffu; best.d1 = 0xffffu;
+    const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)set * strideT * OLF_DESC_BYTES);
+    for (int j = lane; j < nt; j += 64) {
+        const unsigned d = (unsigned)ham256(a0, a1, tp[2 * j], tp[2 * j + 1]);
+        Knn2 c;
+        c.k0 = (d << 16) | (unsigned)j; c.d1 = 0xffffu;
+        best = knn_merge(best, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Knn2 other;
+        other.k0 = (unsigned)__shfl_xor((int)best.k0, o);
+        other.d1 = (unsigned)__shfl_xor((int)best.d1, o);
+        best = knn_merge(best, other);
+    }
+    if (lane == 0) {
+        const size_t o = (size_t)set * strideQ + iq;
+        const bool has0 = best.k0 != 0xffffffffu, has1 = best.d1 != 0xffffu;
+        idx0[o] = has0 ? (int)(best.k0 & 0xffffu) : -1;
+        dist0[o] = has0 ? (int)(best.k0 >> 16) : 0x7fffffff;
+        dist1[o] = has1 ? (int)best.d1 : 0x7fffffff;
+    }
+}
+
+// ratio test of matchNNR (src/LineMatcher.cpp:54-59) + mutual check of match() (:121-127)
+__global__ __launch_bounds__(256) void k_ratio_mutual(const int* __restrict__ nA, int strideA, int aStep, const int* __restrict__ nB,
+                                                      int strideB, int bStep, const int* __restrict__ idxAB,
+                                                      const int* __restrict__ d0AB, const int* __restrict__ d1AB,
+                                                      const int* __restrict__ idxBA, const int* __restrict__ d0BA,
+                                                      const int* __restrict__ d1BA, float nnr, int best_lr, int* __restrict__ m12)
+{
+    const int set = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int na = nA[set * aStep], nb = nB[set * bStep];
+    if (i >= na) return;
+    const size_t oa = (size_t)set * strideA + i;
+    int m = -1;
+    if (nb >= 2 && (float)d0AB[oa] < f_mul((float)d1AB[oa], nnr)) m = idxAB[oa];
+    if (m >= 0 && best_lr) {
+        const size_t ob = (size_t)set * strideB + m;
+        int back = -1;
+        if (na >= 2 && (float)d0BA[ob] < f_mul((float)d1BA[ob], nnr)) back = idxBA[ob];
+        if (back != i) m = -1;
+    }
+    m12[oa] = m;
+}
+
+// dense distance matrix (DescriptorDistance over all pairs), int16 out[nA][nB]
+__global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restrict__ a, int nA, const uint8_t* __restrict__ b, int nB,
+                                                        uint16_t* __restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= nB || i >= nA) return;
+    const uint4* ap = reinterpret_cast<const uint4*>(a + (size_t)i * OLF_DESC_BYTES);
+    const uint4* bp = reinterpret_cast<const uint4*>(b + (size_t)j * OLF_DESC_BYTES);
+    out[(size_t)i * nB + j] = (uint16_t)ham256(ap[0], ap[1], bp[0], bp[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
+                         const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, b.geom, b.pyr, d_kps, d_desc, d_counts, cap, mbf,
+                       fx, d_uRight, d_depth, d_sad);
+    int sortN = 64;
+    while (sortN < cap) sortN <<= 1;
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(256), sortN * sizeof(unsigned), s, d_counts, cap, sortN, d_uRight, d_depth,
+                       d_sad);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, const uint8_t* dB, const int* nB, int strideB, int bStep,
+                    int n_sets, float nnr, int best_lr, int* ws /* 3*(strideA+strideB)*n_sets ints */, int* m12, hipStream_t s)
+{
+    int* idxAB = ws; int* d0AB = idxAB + (size_t)n_sets * strideA; int* d1AB = d0AB + (size_t)n_sets * strideA;
+    int* idxBA = d1AB + (size_t)n_sets * strideA; int* d0BA = idxBA + (size_t)n_sets * strideB; int* d1BA = d0BA + (size_t)n_sets * strideB;
+    hipLaunchKernelGGL(k_knn2, dim3((strideA + 3) / 4, n_sets), dim3(256), 0, s, dA, nA, strideA, aStep, dB, nB, strideB, bStep, idxAB, d0AB, d1AB);
+    if (best_lr)
+        hipLaunchKernelGGL(k_knn2, dim3((strideB + 3) / 4, n_sets), dim3(256), 0, s, dB, nB, strideB, bStep, dA, nA, strideA, aStep, idxBA, d0BA, d1BA);
+    hipLaunchKernelGGL(k_ratio_mutual, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, nA, strideA, aStep, nB, strideB, bStep, idxAB, d0AB,
+                       d1AB, idxBA, d0BA, d1BA, nnr, best_lr, m12);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
+                int* dist0, int* dist1, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_knn2, dim3((strideA + 3) / 4, n_sets), dim3(256), 0, s, dA, nA, strideA, 1, dB, nB, strideB, 1, idx0, dist0, dist1);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+int launch_hamming_matrix(const uint8_t* a, int nA, const uint8_t* b, int nB, uint16_t* out, hipStream_t s)
+{
+    if (nA <= 0 || nB <= 0) return OLF_OK;
+    hipLaunchKernelGGL(k_hamming_matrix, dim3((nB + 255) / 256, nA), dim3(256), 0, s, a, nA, b, nB, out);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+}  // namespace olf

@@ -116,4 +116,13 @@ int launch_orb_blur(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipS
 int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
                         int* d_counts, int out_cap, hipStream_t s);
 
+// match.hip
+int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
+                         const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, hipStream_t s);
+int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, const uint8_t* dB, const int* nB, int strideB, int bStep,
+                    int n_sets, float nnr, int best_lr, int* ws, int* m12, hipStream_t s);
+int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
+                int* dist0, int* dist1, hipStream_t s);
+int launch_hamming_matrix(const uint8_t* a, int nA, const uint8_t* b, int nB, uint16_t* out, hipStream_t s);
+
 }  // namespace olf

@@ -98,3 +98,46 @@ def gaussian_blur(src, ksize, sigma):
 
 def fast_atan2(y, x):
     return float(_L.orc_fast_atan2(y, x))
+
+
+def match_bf(d1, d2, nnr, best_lr=True):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    m12 = np.full(len(d1), -1, np.int32)
+    _L.orc_match_bf(_p(d1), len(d1), _p(d2), len(d2), C.c_float(nnr), int(best_lr), _p(m12))
+    return m12
+
+
+def knn2(d1, d2):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    n = len(d1)
+    i0, a, b = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    _L.orc_knn2(_p(d1), n, _p(d2), len(d2), _p(i0), _p(a), _p(b))
+    return i0, a, b
+
+
+def full_params(nfeatures=2000, nlines=500, fx=718.856, bf=386.1448):
+    from orb_line_slam_amd._lib import default_params
+    try:
+        p = default_params()
+    except Exception:
+        raise
+    p.orb.nfeatures = nfeatures
+    p.line.lsd_nfeatures = nlines
+    p.stereo.fx, p.stereo.bf = fx, bf
+    return p
+
+
+def stereo_points(imgL, imgR, p, cap=None):
+    imgL = np.ascontiguousarray(imgL); imgR = np.ascontiguousarray(imgR)
+    h, w = imgL.shape
+    cap = cap or p.orb.nfeatures + 64
+    kl, kr = np.zeros(cap, KEYPOINT_DTYPE), np.zeros(cap, KEYPOINT_DTYPE)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    nl, nr = C.c_int(), C.c_int()
+    ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    sad = np.zeros(cap, np.int32)
+    rc = _L.orc_stereo_points(_p(imgL), _p(imgR), w, h, C.byref(p), _p(kl), _p(dl), C.byref(nl), _p(kr), _p(dr), C.byref(nr), cap,
+                              _p(ur), _p(dp), _p(sad))
+    assert rc == 0, rc
+    n, m = nl.value, nr.value
+    return dict(kpsL=kl[:n], descL=dl[:n], kpsR=kr[:m], descR=dr[:m], uRight=ur[:n], depth=dp[:n], sad=sad[:n])
