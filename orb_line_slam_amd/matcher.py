@@ -18,7 +18,7 @@ def _ctx(context=None):
     if context is not None:
         return context
     if _shared_ctx is None:
-        _shared_ctx = _lib.Context(_lib.default_params(), 128, 128, 1)
+        _shared_ctx = _lib.Context(_lib.default_params(), 640, 480, 1)
     return _shared_ctx
 
 
