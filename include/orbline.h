@@ -83,6 +83,50 @@ int olf_knn2(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8_t* descT, i
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1795-1811) over all pairs: out[nA][nB] uint16 (host buffers) */
 int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out);
 
+/* ---- Lineextractor (include/LineExtractor.h:40-72, src/LineExtractor.cc:31-67) ------------------ */
+/* per-image capacity of the key line / LBD descriptor records (lsd_nfeatures, or the detector's own
+ * limit when lsd_nfeatures == 0) */
+int olf_line_capacity(const olf_ctx* ctx);
+/* Lineextractor::operator()(image, mask [ignored], keylines, descriptors_line): LSDDetectorC::detect with
+ * the context's LSD options, top-N by response, BinaryDescriptor::compute (LBD). */
+int olf_line_extract_dev(olf_ctx* ctx, const uint8_t* d_images, int n_images, olf_keyline* d_kls, uint8_t* d_ldesc, int32_t* d_lcounts,
+                         void* stream);
+int olf_line_extract(olf_ctx* ctx, const uint8_t* images, int n_images, olf_keyline* kls, uint8_t* ldesc, int32_t* lcounts);
+/* BinaryDescriptor::compute(image, keylines, descriptors) on caller-supplied key lines (host buffers;
+ * Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:524-687): kls [n_images][capacity], counts[n_images] */
+int olf_lbd_compute(olf_ctx* ctx, const uint8_t* images, int n_images, const olf_keyline* kls, const int32_t* lcounts, uint8_t* ldesc);
+/* debug/test: the sigma-0.6 blurred, x1.2 upsampled LSD working image of `image` (dst >= ws*hs bytes) */
+int olf_lsd_debug_scaled(olf_ctx* ctx, int image, uint8_t* dst, int32_t* ws, int32_t* hs);
+
+/* ---- Frame::ComputeStereoMatches_Lines (src/Frame.cc:878-1000) + matchGrid (src/LineMatcher.cpp:220-299) */
+/* key lines / LBD descriptors of images 2p (left) and 2p+1 (right), stride olf_line_capacity().
+ * Outputs per pair, stride capacity: matches_12 (-1 = none), mvDisparity_l (2 floats, -1 = mono),
+ * mvle_l (3 doubles, 0 = mono). */
+int olf_stereo_lines_dev(olf_ctx* ctx, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_ldesc, const int32_t* d_lcounts,
+                         int32_t* d_matches12, float* d_disp, double* d_le, void* stream);
+int olf_stereo_lines(olf_ctx* ctx, int n_pairs, const olf_keyline* kls, const uint8_t* ldesc, const int32_t* lcounts, int32_t* matches12,
+                     float* disp, double* le);
+
+/* ---- fused entry: the feature part of Frame::Frame (stereo + lines), src/Frame.cc:136-221 -------- */
+typedef struct olf_frame_buffers {
+    olf_keypoint* kps;      /* [2*n_pairs][orb capacity]      mvKeys / mvKeysRight                   */
+    uint8_t*  desc;         /* [2*n_pairs][orb capacity][32]  mDescriptors / mDescriptorsRight       */
+    int32_t*  counts;       /* [2*n_pairs]                    N, Nr                                  */
+    float*    uright;       /* [n_pairs][orb capacity]        mvuRight                               */
+    float*    depth;        /* [n_pairs][orb capacity]        mvDepth                                */
+    olf_keyline* kls;       /* [2*n_pairs][line capacity]     mvKeys_Line / mvKeysRight_Line         */
+    uint8_t*  ldesc;        /* [2*n_pairs][line capacity][32] mDescriptors_Line / mDescriptorsRight_Line */
+    int32_t*  lcounts;      /* [2*n_pairs]                                                           */
+    int32_t*  lmatches12;   /* [n_pairs][line capacity]       stereo line matches (left -> right)    */
+    float*    ldisp;        /* [n_pairs][line capacity][2]    mvDisparity_l                          */
+    double*   lle;          /* [n_pairs][line capacity][3]    mvle_l                                 */
+} olf_frame_buffers;
+/* ExtractORB x2 + ExtractLine x2 (the reference's 4 threads, src/Frame.cc:164-171, here two HIP streams),
+ * ComputeStereoMatches, ComputeStereoMatches_Lines, for n_pairs stereo pairs.  All pointers in `out` are
+ * device pointers for the _dev form, host pointers otherwise. */
+int olf_stereo_frames_dev(olf_ctx* ctx, const uint8_t* d_images, int n_pairs, const olf_frame_buffers* out, void* stream);
+int olf_stereo_frames(olf_ctx* ctx, const uint8_t* images, int n_pairs, const olf_frame_buffers* out);
+
 #ifdef __cplusplus
 }
 #endif

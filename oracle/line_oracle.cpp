@@ -1,0 +1,463 @@
+// line_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code).
+//
+// Restates the line half of the path (paths relative to /root/reference):
+//   Lineextractor::operator()            src/LineExtractor.cc:31-67
+//   LSDDetectorC::detect/detectImpl      Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:56-102, :218-324
+//   cv::createLineSegmentDetector->detect  (un-vendored OpenCV 3.4 lsd.cpp)
+//   cv::LineIterator count               (App. A.8)
+//   BinaryDescriptor::compute (LBD)      Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:217-259 (weights),
+//                                        :350-412 (blur, Sobel, binaryConversion), :539-687 (computeImpl), :1026-1372 (computeLBD)
+// PARITY UNPINNED (see oracle_common.hpp).  Conventions:
+//   C.3  the top-N selection by response uses a stable order (response desc, detection index asc);
+//        orc_line_extract can also run the reference's std::sort so tests can check that they agree.
+//   C.6  unqualified libm calls on float arguments inside cv::line_descriptor / cv::LineSegmentDetector
+//        (cos, sin, atan2, sqrt) are evaluated in double and rounded to float.
+#include "oracle_common.hpp"
+#include <cfloat>
+
+namespace orc {
+
+static const double kPI = 3.1415926535897932384626433832795;
+static const double NOTDEF = -1024.0, M_3_2_PI = (3 * kPI) / 2, M_2__PI = 2 * kPI, DEG_TO_RADS = kPI / 180;
+
+struct RegionPoint { int x, y; double angle, modgrad; };
+struct Vec4f { float v[4]; };
+
+struct LsdState {
+    int w = 0, h = 0;
+    std::vector<double> angles, modgrad;
+    std::vector<uint8_t> used;
+    std::vector<int> order;   // pixel addresses, bins high->low, raster inside a bin
+};
+
+static inline bool is_aligned(const LsdState& S, int addr, double theta, double prec)
+{
+    const double a = S.angles[addr];
+    if (a == NOTDEF) return false;
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI) {
+        n_theta -= M_2__PI;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+static inline double angle_diff(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -kPI) diff += M_2__PI;
+    while (diff > kPI) diff -= M_2__PI;
+    return std::fabs(diff);
+}
+
+// cv::LineSegmentDetector::detect with refine = LSD_REFINE_NONE.  scaled_out (optional) receives the
+// blurred + upsampled image, for stage-wise comparison.
+void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>& lines, Image* scaled_out, std::vector<int>* region_sizes)
+{
+    lines.clear();
+    const double SCALE = P.lsd_scale, SIGMA_SCALE = P.lsd_sigma_scale, QUANT = P.lsd_quant, ANG_TH = P.lsd_ang_th;
+    const int N_BINS = P.lsd_n_bins;
+    const double prec = kPI * ANG_TH / 180, p = ANG_TH / 180;
+    const double rho = QUANT / std::sin(prec);
+    Image scaled;
+    if (SCALE != 1) {
+        const double sigma = (SCALE < 1) ? (SIGMA_SCALE / SCALE) : SIGMA_SCALE;
+        const double sprec = 3;
+        const unsigned int hk = (unsigned int)std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0)));
+        Image g = gaussian_blur_u8(image, gaussian_taps_q8(1 + 2 * hk, sigma));
+        // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE): dsize = round(size*SCALE), scale = 1/SCALE
+        const int dw = cvRound(image.w * SCALE), dh = cvRound(image.h * SCALE);
+        scaled = resize_linear_u8(g, dw, dh, 1. / SCALE, 1. / SCALE);
+    } else scaled = image;
+    if (scaled_out) *scaled_out = scaled;
+    LsdState S;
+    const int W = S.w = scaled.w, H = S.h = scaled.h;
+    S.angles.assign((size_t)W * H, NOTDEF);
+    S.modgrad.assign((size_t)W * H, 0.0);
+    // ---- ll_angle
+    double max_grad = -1;
+    for (int y = 0; y < H - 1; ++y) {
+        const uint8_t* r0 = scaled.row(y);
+        const uint8_t* r1 = scaled.row(y + 1);
+        for (int x = 0; x < W - 1; ++x) {
+            int DA = r1[x + 1] - r0[x];
+            int BC = r0[x + 1] - r1[x];
+            int gx = DA + BC, gy = DA - BC;
+            double norm = std::sqrt((gx * gx + gy * gy) / 4.0);
+            S.modgrad[(size_t)y * W + x] = norm;
+            if (norm <= rho) S.angles[(size_t)y * W + x] = NOTDEF;
+            else {
+                S.angles[(size_t)y * W + x] = fastAtan2(float(gx), float(-gy)) * DEG_TO_RADS;
+                if (norm > max_grad) max_grad = norm;
+            }
+        }
+    }
+    // ---- pseudo-ordering: bins of the gradient norm, high to low, raster order inside a bin
+    {
+        const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
+        std::vector<int> cnt(N_BINS + 1, 0);
+        std::vector<int> bin((size_t)W * H, -1);
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x) {
+                int i = int(S.modgrad[(size_t)y * W + x] * bin_coef);
+                bin[(size_t)y * W + x] = i;
+                ++cnt[i];
+            }
+        std::vector<int> start(N_BINS + 1, 0);
+        int acc = 0;
+        for (int b = N_BINS - 1; b >= 0; --b) { start[b] = acc; acc += cnt[b]; }
+        S.order.assign(acc, 0);
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x) {
+                int b = bin[(size_t)y * W + x];
+                S.order[start[b]++] = y * W + x;
+            }
+    }
+    const double LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
+    const int min_reg_size = int(-LOG_NT / std::log10(p));
+    S.used.assign((size_t)W * H, 0);
+    std::vector<RegionPoint> reg;
+    for (size_t oi = 0; oi < S.order.size(); ++oi) {
+        const int addr0 = S.order[oi];
+        if (S.used[addr0] || S.angles[addr0] == NOTDEF) continue;
+        // ---- region_grow
+        reg.clear();
+        double reg_angle = S.angles[addr0];
+        reg.push_back({addr0 % W, addr0 / W, reg_angle, S.modgrad[addr0]});
+        float sumdx = float(std::cos(reg_angle));
+        float sumdy = float(std::sin(reg_angle));
+        S.used[addr0] = 1;
+        for (size_t i = 0; i < reg.size(); ++i) {
+            const int rx = reg[i].x, ry = reg[i].y;
+            const int xx_min = std::max(rx - 1, 0), xx_max = std::min(rx + 1, W - 1);
+            const int yy_min = std::max(ry - 1, 0), yy_max = std::min(ry + 1, H - 1);
+            for (int yy = yy_min; yy <= yy_max; ++yy) {
+                int c_addr = xx_min + yy * W;
+                for (int xx = xx_min; xx <= xx_max; ++xx, ++c_addr) {
+                    if (!S.used[c_addr] && is_aligned(S, c_addr, reg_angle, prec)) {
+                        S.used[c_addr] = 1;
+                        const double angle = S.angles[c_addr];
+                        reg.push_back({xx, yy, angle, S.modgrad[c_addr]});
+                        sumdx += std::cos((double)float(angle));   // convention C.6: double libm, rounded by the float +=
+                        sumdy += std::sin((double)float(angle));
+                        reg_angle = fastAtan2(sumdy, sumdx) * DEG_TO_RADS;
+                    }
+                }
+            }
+        }
+        if (region_sizes) region_sizes->push_back((int)reg.size());
+        if ((int)reg.size() < min_reg_size) continue;
+        // ---- region2rect
+        double x = 0, y = 0, sum = 0;
+        for (const RegionPoint& q : reg) {
+            const double weight = q.modgrad;
+            x += double(q.x) * weight;
+            y += double(q.y) * weight;
+            sum += weight;
+        }
+        x /= sum; y /= sum;
+        double Ixx = 0, Iyy = 0, Ixy = 0;
+        for (const RegionPoint& q : reg) {
+            const double dx = double(q.x) - x, dy = double(q.y) - y, weight = q.modgrad;
+            Ixx += dy * dy * weight;
+            Iyy += dx * dx * weight;
+            Ixy -= dx * dy * weight;
+        }
+        const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fastAtan2(float(lambda - Ixx), float(Ixy)))
+                                                         : double(fastAtan2(float(Ixy), float(lambda - Iyy)));
+        theta *= DEG_TO_RADS;
+        if (angle_diff(theta, reg_angle) > prec) theta += kPI;
+        const double dx = std::cos(theta), dy = std::sin(theta);
+        double l_min = 0, l_max = 0;
+        for (const RegionPoint& q : reg) {
+            const double regdx = double(q.x) - x, regdy = double(q.y) - y;
+            const double l = regdx * dx + regdy * dy;
+            if (l > l_max) l_max = l;
+            else if (l < l_min) l_min = l;
+        }
+        double x1 = x + l_min * dx, y1 = y + l_min * dy, x2 = x + l_max * dx, y2 = y + l_max * dy;
+        x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+        if (SCALE != 1) { x1 /= SCALE; y1 /= SCALE; x2 /= SCALE; y2 /= SCALE; }
+        lines.push_back({{float(x1), float(y1), float(x2), float(y2)}});
+    }
+}
+
+// LSDDetectorC::detectImpl (opts overload), 1 octave: Vec4f -> KeyLine
+void make_keylines(const std::vector<Vec4f>& segs, int cols, int rows, double min_length, std::vector<olf_keyline>& out)
+{
+    out.clear();
+    int class_counter = -1;
+    for (const Vec4f& s : segs) {
+        float e[4] = {s.v[0], s.v[1], s.v[2], s.v[3]};
+        // checkLineExtremes
+        if (e[0] < 0) e[0] = 0;
+        if (e[0] >= cols) e[0] = (float)cols - 1.0f;
+        if (e[2] < 0) e[2] = 0;
+        if (e[2] >= cols) e[2] = (float)cols - 1.0f;
+        if (e[1] < 0) e[1] = 0;
+        if (e[1] >= rows) e[1] = (float)rows - 1.0f;
+        if (e[3] < 0) e[3] = 0;
+        if (e[3] >= rows) e[3] = (float)rows - 1.0f;
+        const double length = (float)std::sqrt(std::pow((double)(e[0] - e[2]), 2) + std::pow((double)(e[1] - e[3]), 2));
+        if (!(length > min_length)) continue;
+        olf_keyline kl;
+        const float octaveScale = 1.0f;   // pow((float)scale, 0)
+        kl.startPointX = e[0] * octaveScale; kl.startPointY = e[1] * octaveScale;
+        kl.endPointX = e[2] * octaveScale; kl.endPointY = e[3] * octaveScale;
+        kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1]; kl.ePointInOctaveX = e[2]; kl.ePointInOctaveY = e[3];
+        kl.lineLength = (float)length;
+        // cv::LineIterator(img, Point2f, Point2f).count : end points rounded (cvRound), 8-connected
+        const int x1 = cvRoundf(e[0]), y1 = cvRoundf(e[1]), x2 = cvRoundf(e[2]), y2 = cvRoundf(e[3]);
+        kl.numOfPixels = std::max(std::abs(x2 - x1), std::abs(y2 - y1)) + 1;
+        kl.angle = (float)std::atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
+        kl.class_id = ++class_counter;
+        kl.octave = 0;
+        kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
+        kl.response = kl.lineLength / std::max(cols, rows);
+        kl.pt_x = (kl.endPointX + kl.startPointX) / 2; kl.pt_y = (kl.endPointY + kl.startPointY) / 2;
+        out.push_back(kl);
+    }
+}
+
+// ---- LBD ----------------------------------------------------------------------------------------
+static const int8_t kBandPairs[64] = {
+#include "lbd_band_pairs.inc"
+};
+static const int NUM_OF_BANDS = 9, WIDTH_OF_BAND = 7;
+
+// cv::Sobel(src, dst, CV_16S, dx, dy, 3) with BORDER_REFLECT_101 (App. A.9)
+static void sobel3(const Image& src, std::vector<int16_t>& dxI, std::vector<int16_t>& dyI)
+{
+    const int w = src.w, h = src.h;
+    dxI.assign((size_t)w * h, 0); dyI.assign((size_t)w * h, 0);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* r0 = src.row(reflect101(y - 1, h));
+        const uint8_t* r1 = src.row(y);
+        const uint8_t* r2 = src.row(reflect101(y + 1, h));
+        for (int x = 0; x < w; ++x) {
+            const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+            dxI[(size_t)y * w + x] = (int16_t)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
+            dyI[(size_t)y * w + x] = (int16_t)((r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]));
+        }
+    }
+}
+
+void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, std::vector<uint8_t>& desc,
+                 std::vector<float>* float_desc)
+{
+    const int n = (int)keylines.size();
+    desc.assign((size_t)n * 32, 0);
+    if (float_desc) float_desc->assign((size_t)n * 72, 0.f);
+    if (n == 0) return;   // "Error: keypoint list is empty" + return (binary_descriptor_custom.cpp:556-560)
+    // weights, binary_descriptor_custom.cpp:217-259 (integer divisions are the reference's)
+    std::vector<double> gaussCoefL(WIDTH_OF_BAND * 3), gaussCoefG(NUM_OF_BANDS * WIDTH_OF_BAND);
+    {
+        double u = (WIDTH_OF_BAND * 3 - 1) / 2;
+        double sigma = (WIDTH_OF_BAND * 2 + 1) / 2;
+        double invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < WIDTH_OF_BAND * 3; ++i) { double dis = i - u; gaussCoefL[i] = std::exp(dis * dis * invsigma2); }
+        u = (NUM_OF_BANDS * WIDTH_OF_BAND - 1) / 2;
+        sigma = u;
+        invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < NUM_OF_BANDS * WIDTH_OF_BAND; ++i) { double dis = i - u; gaussCoefG[i] = std::exp(dis * dis * invsigma2); }
+    }
+    Image blurred = gaussian_blur_u8(image, gaussian_taps_q8(5, 1.0));
+    std::vector<int16_t> dxImg, dyImg;
+    sobel3(blurred, dxImg, dyImg);
+    const short heightOfLSP = (short)(WIDTH_OF_BAND * NUM_OF_BANDS);
+    const short realWidth = (short)image.w, imageWidth = (short)(realWidth - 1), imageHeight = (short)(image.h - 1);
+    for (int li = 0; li < n; ++li) {
+        const olf_keyline& kl = keylines[li];
+        float pgdLBandSum[9] = {0}, ngdLBandSum[9] = {0}, pgdL2BandSum[9] = {0}, ngdL2BandSum[9] = {0};
+        float pgdOBandSum[9] = {0}, ngdOBandSum[9] = {0}, pgdO2BandSum[9] = {0}, ngdO2BandSum[9] = {0};
+        const short lengthOfLSP = (short)kl.numOfPixels;
+        const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+        const short halfHeight = (short)((heightOfLSP - 1) / 2);
+        const float lineMiddlePointX = (float)(0.5 * (kl.sPointInOctaveX + kl.ePointInOctaveX));
+        const float lineMiddlePointY = (float)(0.5 * (kl.sPointInOctaveY + kl.ePointInOctaveY));
+        float dL[2], dO[2];
+        dL[0] = (float)std::cos((double)kl.angle);   // osl.direction = kl.angle; convention C.6
+        dL[1] = (float)std::sin((double)kl.angle);
+        dO[0] = -dL[1]; dO[1] = dL[0];
+        float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
+        float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
+        for (short hID = 0; hID < heightOfLSP; ++hID) {
+            float sCorX = sCorX0, sCorY = sCorY0;
+            float pgdLRowSum = 0, ngdLRowSum = 0, pgdORowSum = 0, ngdORowSum = 0;
+            for (short wID = 0; wID < lengthOfLSP; ++wID) {
+                short tempCor = (short)std::round(sCorX);
+                const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+                tempCor = (short)std::round(sCorY);
+                const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+                const short dx = dxImg[yCor * realWidth + xCor], dy = dyImg[yCor * realWidth + xCor];
+                const float gDL = dx * dL[0] + dy * dL[1];
+                const float gDO = dx * dO[0] + dy * dO[1];
+                if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
+                if (gDO > 0) pgdORowSum += gDO; else ngdORowSum -= gDO;
+                sCorX += dL[0];
+                sCorY += dL[1];
+            }
+            sCorX0 -= dL[1];
+            sCorY0 += dL[0];
+            float coefInGaussion = (float)gaussCoefG[hID];
+            pgdLRowSum = coefInGaussion * pgdLRowSum;
+            ngdLRowSum = coefInGaussion * ngdLRowSum;
+            const float pgdL2RowSum = pgdLRowSum * pgdLRowSum, ngdL2RowSum = ngdLRowSum * ngdLRowSum;
+            pgdORowSum = coefInGaussion * pgdORowSum;
+            ngdORowSum = coefInGaussion * ngdORowSum;
+            const float pgdO2RowSum = pgdORowSum * pgdORowSum, ngdO2RowSum = ngdORowSum * ngdORowSum;
+            auto add = [&](short bandID, float c) {
+                pgdLBandSum[bandID] += c * pgdLRowSum;
+                ngdLBandSum[bandID] += c * ngdLRowSum;
+                pgdL2BandSum[bandID] += c * c * pgdL2RowSum;
+                ngdL2BandSum[bandID] += c * c * ngdL2RowSum;
+                pgdOBandSum[bandID] += c * pgdORowSum;
+                ngdOBandSum[bandID] += c * ngdORowSum;
+                pgdO2BandSum[bandID] += c * c * pgdO2RowSum;
+                ngdO2BandSum[bandID] += c * c * ngdO2RowSum;
+            };
+            short bandID = (short)(hID / WIDTH_OF_BAND);
+            add(bandID, (float)gaussCoefL[hID % WIDTH_OF_BAND + WIDTH_OF_BAND]);
+            bandID--;
+            if (bandID >= 0) add(bandID, (float)gaussCoefL[hID % WIDTH_OF_BAND + 2 * WIDTH_OF_BAND]);
+            bandID = (short)(bandID + 2);
+            if (bandID < NUM_OF_BANDS) add(bandID, (float)gaussCoefL[hID % WIDTH_OF_BAND]);
+        }
+        float desVec[72];
+        const float invN2 = (float)(1.0 / (WIDTH_OF_BAND * 2.0)), invN3 = (float)(1.0 / (WIDTH_OF_BAND * 3.0));
+        for (short bandID = 0; bandID < NUM_OF_BANDS; ++bandID) {
+            const float invN = (bandID == 0 || bandID == NUM_OF_BANDS - 1) ? invN2 : invN3;
+            const short desID = (short)(bandID * 8);
+            float temp = pgdLBandSum[bandID] * invN;
+            desVec[desID] = temp;
+            desVec[desID + 4] = (float)std::sqrt((double)(pgdL2BandSum[bandID] * invN - temp * temp));
+            temp = ngdLBandSum[bandID] * invN;
+            desVec[desID + 1] = temp;
+            desVec[desID + 5] = (float)std::sqrt((double)(ngdL2BandSum[bandID] * invN - temp * temp));
+            temp = pgdOBandSum[bandID] * invN;
+            desVec[desID + 2] = temp;
+            desVec[desID + 6] = (float)std::sqrt((double)(pgdO2BandSum[bandID] * invN - temp * temp));
+            temp = ngdOBandSum[bandID] * invN;
+            desVec[desID + 3] = temp;
+            desVec[desID + 7] = (float)std::sqrt((double)(ngdO2BandSum[bandID] * invN - temp * temp));
+        }
+        float tempM = 0, tempS = 0;
+        for (int b = 0; b < NUM_OF_BANDS; ++b) {
+            const float* d = desVec + 8 * b;
+            tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
+            tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
+        }
+        tempM = (float)(1 / std::sqrt((double)tempM));   // convention C.6: double sqrt, double divide
+        tempS = (float)(1 / std::sqrt((double)tempS));
+        for (int b = 0; b < NUM_OF_BANDS; ++b) {
+            float* d = desVec + 8 * b;
+            d[0] = d[0] * tempM; d[1] = d[1] * tempM; d[2] = d[2] * tempM; d[3] = d[3] * tempM;
+            d[4] = d[4] * tempS; d[5] = d[5] * tempS; d[6] = d[6] * tempS; d[7] = d[7] * tempS;
+        }
+        for (int i = 0; i < 72; ++i)
+            if (desVec[i] > 0.4) desVec[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < 72; ++i) temp += desVec[i] * desVec[i];
+        temp = (float)(1 / std::sqrt((double)temp));
+        for (int i = 0; i < 72; ++i) desVec[i] = desVec[i] * temp;
+        if (float_desc) std::memcpy(&(*float_desc)[(size_t)li * 72], desVec, sizeof(desVec));
+        // binaryConversion over the 32 band pairs
+        for (int c = 0; c < 32; ++c) {
+            const float* f1 = &desVec[8 * kBandPairs[2 * c]];
+            const float* f2 = &desVec[8 * kBandPairs[2 * c + 1]];
+            uint8_t r = 0;
+            for (int i = 0; i < 8; ++i)
+                if (f1[i] > f2[i]) r = (uint8_t)(r + (1 << i));
+            desc[(size_t)li * 32 + c] = r;
+        }
+    }
+}
+
+struct sort_lines_by_response {
+    bool operator()(const olf_keyline& a, const olf_keyline& b) const { return a.response > b.response; }
+};
+
+// Lineextractor::operator(): detect, top-N by response, LBD.  use_std_sort: the reference's unstable
+// std::sort (C.3) instead of the stable convention.
+void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort, std::vector<olf_keyline>& kls, std::vector<uint8_t>& desc,
+                  std::vector<olf_keyline>* all_detected)
+{
+    std::vector<Vec4f> segs;
+    lsd_detect(img, P, segs, nullptr, nullptr);
+    const double min_length = P.min_line_length * std::min(img.w, img.h);
+    make_keylines(segs, img.w, img.h, min_length, kls);
+    if (all_detected) *all_detected = kls;
+    if ((int)kls.size() > P.lsd_nfeatures && P.lsd_nfeatures != 0) {
+        if (use_std_sort) std::sort(kls.begin(), kls.end(), sort_lines_by_response());
+        else std::stable_sort(kls.begin(), kls.end(), sort_lines_by_response());
+        kls.resize(P.lsd_nfeatures);
+        for (int i = 0; i < P.lsd_nfeatures; ++i) kls[i].class_id = i;
+    }
+    lbd_compute(img, kls, desc, nullptr);
+}
+
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+
+// raw LSD segments (x1,y1,x2,y2 floats) + optional scaled image (dims via sw/sh) + region sizes
+int orc_lsd_detect(const uint8_t* img, int w, int h, const olf_line_params* P, float* segs, int cap, int* n, uint8_t* scaled, int* sw, int* sh)
+{
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t)w * h);
+    std::vector<Vec4f> lines;
+    Image sc;
+    lsd_detect(im, *P, lines, &sc, nullptr);
+    *n = (int)lines.size();
+    for (int i = 0; i < std::min(*n, cap); ++i) std::memcpy(segs + 4 * i, lines[i].v, 16);
+    if (sw) *sw = sc.w;
+    if (sh) *sh = sc.h;
+    if (scaled) std::memcpy(scaled, sc.d.data(), sc.d.size());
+    return *n > cap ? OLF_ERR_CAPACITY : OLF_OK;
+}
+
+int orc_line_extract(const uint8_t* img, int w, int h, const olf_line_params* P, int use_std_sort, olf_keyline* kls, uint8_t* desc, int cap, int* n,
+                     olf_keyline* all_kls, int all_cap, int* n_all)
+{
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t)w * h);
+    std::vector<olf_keyline> k, all;
+    std::vector<uint8_t> d;
+    line_extract(im, *P, use_std_sort != 0, k, d, &all);
+    *n = (int)k.size();
+    if (n_all) *n_all = (int)all.size();
+    if (*n > cap) return OLF_ERR_CAPACITY;
+    if (*n) { std::memcpy(kls, k.data(), k.size() * sizeof(olf_keyline)); std::memcpy(desc, d.data(), d.size()); }
+    if (all_kls) std::memcpy(all_kls, all.data(), std::min<size_t>(all.size(), all_cap) * sizeof(olf_keyline));
+    return OLF_OK;
+}
+
+// LBD only, on caller-supplied key lines (float_desc optional: n*72 floats)
+int orc_lbd_compute(const uint8_t* img, int w, int h, const olf_keyline* kls, int n, uint8_t* desc, float* float_desc)
+{
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t)w * h);
+    std::vector<olf_keyline> k(kls, kls + n);
+    std::vector<uint8_t> d;
+    std::vector<float> fd;
+    lbd_compute(im, k, d, float_desc ? &fd : nullptr);
+    std::memcpy(desc, d.data(), d.size());
+    if (float_desc) std::memcpy(float_desc, fd.data(), fd.size() * sizeof(float));
+    return OLF_OK;
+}
+
+int orc_sobel3(const uint8_t* img, int w, int h, int16_t* dx, int16_t* dy)
+{
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t)w * h);
+    std::vector<int16_t> a, b;
+    sobel3(im, a, b);
+    std::memcpy(dx, a.data(), a.size() * 2);
+    std::memcpy(dy, b.data(), b.size() * 2);
+    return 0;
+}
+
+}  // extern "C"

@@ -48,6 +48,12 @@ class OlfParams(C.Structure):
     _fields_ = [("orb", OrbParams), ("line", LineParams), ("stereo", StereoParams)]
 
 
+class FrameBuffers(C.Structure):
+    """olf_frame_buffers (include/orbline.h): device or host pointers of the fused stereo-frame entry"""
+    _fields_ = [(n, C.c_void_p) for n in ("kps", "desc", "counts", "uright", "depth", "kls", "ldesc", "lcounts", "lmatches12",
+                                          "ldisp", "lle")]
+
+
 class OlfError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -84,6 +90,15 @@ def lib():
         L.olf_match_bf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.olf_knn2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_hamming_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.olf_line_capacity.argtypes = [C.c_void_p]
+        L.olf_line_extract_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.olf_line_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3
+        L.olf_lbd_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3
+        L.olf_lsd_debug_scaled.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
+        L.olf_stereo_lines_dev.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+        L.olf_stereo_lines.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.olf_stereo_frames_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers), C.c_void_p]
+        L.olf_stereo_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers)]
         _lib = L
     return _lib
 
@@ -127,6 +142,7 @@ class Context:
         self.handle = h
         self.nlevels = params.orb.nlevels
         self.orb_capacity = int(lib().olf_orb_capacity(self.handle))
+        self.line_capacity = int(lib().olf_line_capacity(self.handle))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -2,6 +2,7 @@
 // Owns the device context; every compute entry point launches HIP kernels -- there is no CPU
 // fallback: without a gfx950 device olf_ctx_create fails with OLF_ERR_NODEVICE.
 #include "olf_internal.hpp"
+#include "line_internal.hpp"
 #include "../../include/orbline.h"
 #include <cstring>
 #include <mutex>
@@ -29,6 +30,20 @@ struct olf_ctx {
     float* d_uright = nullptr;     // [max_pairs][outCap]
     float* d_depth = nullptr;
     int* d_sad = nullptr;
+    // line side
+    LineHostTables line;
+    LineDeviceBufs lb;
+    olf_keyline* d_kls = nullptr;      // [max_images][lineCap]   (host-pointer staging / fused path)
+    uint8_t* d_ldesc = nullptr;
+    int* d_lcounts = nullptr;
+    void* d_lprep = nullptr;
+    uint16_t* d_ldist = nullptr;
+    int* d_lm21 = nullptr;
+    int* d_lm12 = nullptr;
+    float* d_ldisp = nullptr;
+    double* d_lle = nullptr;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // grow-on-demand scratch (matcher k-NN tables, host-pointer staging)
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
@@ -93,6 +108,10 @@ void olf_ctx_destroy(olf_ctx* c)
     if (!c) return;
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
+    if (c->lb.sortTemp) (void)hipFree(c->lb.sortTemp);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -132,6 +151,36 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
         set_error("olf_ctx_create: table upload failed");
         return fail(OLF_ERR_HIP);
     }
+    // ---- line side ----
+    rc = c->line.build(p->line, width, height);
+    if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
+    const LineGeom& lg = c->line.geom;
+    if ((double)n * lg.Ps >= 4294967295.0) { set_error("olf_ctx_create: max_images * LSD working size exceeds 2^32 keys"); return fail(OLF_ERR_CAPACITY); }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }
+    LineDeviceBufs& l = c->lb;
+#define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
+    A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
+    A(l.keyCount, n); A(l.maxN, n); A(l.segBegin, n); A(l.segEnd, n); A(l.used, n * lg.Ps); A(l.region, n * lg.Ps);
+    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
+    A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
+    A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
+    {
+        const size_t np = (n + 1) / 2;
+        A(c->d_ldist, np * lg.outCap * lg.outCap); A(c->d_lm21, np * lg.outCap); A(c->d_lm12, np * lg.outCap);
+        A(c->d_ldisp, np * lg.outCap * 2); A(c->d_lle, np * lg.outCap * 3);
+        void* q = nullptr;
+        if (hipMalloc(&q, stereo_lines_prep_bytes((int)n, lg.outCap)) != hipSuccess) { set_error("hipMalloc failed"); return fail(OLF_ERR_HIP); }
+        c->allocs.push_back(q); c->d_lprep = q;
+    }
+#undef A
+    l.status = b.status;
+    l.sortTempBytes = lsd_sort_temp_bytes((int)std::min<size_t>(n * lg.Ps, 0xffffffffu), (int)n);
+    if (hipMalloc(&l.sortTemp, std::max<size_t>(l.sortTempBytes, 256)) != hipSuccess) { set_error("hipMalloc(sort temp) failed"); return fail(OLF_ERR_HIP); }
+    if (hipMemcpy(l.rx, c->line.rx.data(), c->line.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(l.ry, c->line.ry.data(), c->line.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(l.geom, &lg, sizeof(LineGeom), hipMemcpyHostToDevice) != hipSuccess) { set_error("line table upload failed"); return fail(OLF_ERR_HIP); }
     *out = c;
     return OLF_OK;
 }
@@ -331,6 +380,142 @@ int olf_hamming_matrix(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* 
     OLF_HIP_CHECK(hipMemcpyAsync(out, dO, bO, hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return OLF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int olf_line_capacity(const olf_ctx* c) { return c ? c->line.geom.outCap : OLF_ERR_INVALID; }
+
+int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_keyline* d_kls, uint8_t* d_ldesc, int32_t* d_lcounts, void* stream)
+{
+    if (!c || !d_images || !d_kls || !d_ldesc || !d_lcounts) { set_error("olf_line_extract_dev: null argument"); return OLF_ERR_INVALID; }
+    if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_images == 0) return OLF_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    OLF_TRY(launch_lsd(c->line.geom, c->lb, d_images, c->W, n_images, s));
+    OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s));
+    return OLF_OK;
+}
+
+int olf_line_extract(olf_ctx* c, const uint8_t* images, int n_images, olf_keyline* kls, uint8_t* ldesc, int32_t* lcounts)
+{
+    if (!c || !images || !kls || !ldesc || !lcounts) { set_error("olf_line_extract: null argument"); return OLF_ERR_INVALID; }
+    if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_images == 0) return OLF_OK;
+    const size_t npx = (size_t)c->W * c->H, cap = c->line.geom.outCap;
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * n_images, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_line_extract_dev(c, c->d_images, n_images, c->d_kls, c->d_ldesc, c->d_lcounts, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(kls, c->d_kls, cap * n_images * sizeof(olf_keyline), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(ldesc, c->d_ldesc, cap * n_images * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(lcounts, c->d_lcounts, n_images * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int olf_lbd_compute(olf_ctx* c, const uint8_t* images, int n_images, const olf_keyline* kls, const int32_t* lcounts, uint8_t* ldesc)
+{
+    if (!c || !images || !kls || !lcounts || !ldesc) { set_error("olf_lbd_compute: null argument"); return OLF_ERR_INVALID; }
+    if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_images == 0) return OLF_OK;
+    const size_t npx = (size_t)c->W * c->H, cap = c->line.geom.outCap;
+    for (int i = 0; i < n_images; ++i)
+        if (lcounts[i] < 0 || lcounts[i] > (int)cap) { set_error("olf_lbd_compute: count exceeds capacity"); return OLF_ERR_CAPACITY; }
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * n_images, hipMemcpyHostToDevice, c->stream));
+    // stage the caller's key lines as the "raw" list, with selection disabled by pretending they are final
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_kls, kls, cap * n_images * sizeof(olf_keyline), hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_lcounts, lcounts, n_images * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_lbd_only(c->line.geom, c->lb, c->d_images, c->W, n_images, c->d_kls, c->d_ldesc, c->d_lcounts, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(ldesc, c->d_ldesc, cap * n_images * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_lsd_debug_scaled(olf_ctx* c, int image, uint8_t* dst, int32_t* ws, int32_t* hs)
+{
+    if (!c || !dst || image < 0 || image >= c->max_images) return OLF_ERR_INVALID;
+    const LineGeom& g = c->line.geom;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    OLF_HIP_CHECK(hipMemcpy2D(dst, g.Ws, c->lb.scaled + (size_t)image * g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, hipMemcpyDeviceToHost));
+    if (ws) *ws = g.Ws;
+    if (hs) *hs = g.Hs;
+    return OLF_OK;
+}
+
+int olf_stereo_lines_dev(olf_ctx* c, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_ldesc, const int32_t* d_lcounts, int32_t* d_m12,
+                         float* d_disp, double* d_le, void* stream)
+{
+    if (!c || !d_kls || !d_ldesc || !d_lcounts || !d_m12 || !d_disp || !d_le) { set_error("olf_stereo_lines_dev: null argument"); return OLF_ERR_INVALID; }
+    if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return launch_stereo_lines(c->W, c->H, c->params.stereo, n_pairs, d_kls, d_ldesc, d_lcounts, c->line.geom.outCap, c->d_lprep, c->d_ldist,
+                               c->d_lm21, d_m12, d_disp, d_le, s);
+}
+
+int olf_stereo_lines(olf_ctx* c, int n_pairs, const olf_keyline* kls, const uint8_t* ldesc, const int32_t* lcounts, int32_t* m12, float* disp,
+                     double* le)
+{
+    if (!c || !kls || !ldesc || !lcounts || !m12 || !disp || !le) { set_error("olf_stereo_lines: null argument"); return OLF_ERR_INVALID; }
+    if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    const size_t cap = c->line.geom.outCap, ni = 2 * (size_t)n_pairs;
+    for (size_t i = 0; i < ni; ++i)
+        if (lcounts[i] < 0 || lcounts[i] > (int)cap) { set_error("olf_stereo_lines: count exceeds capacity"); return OLF_ERR_CAPACITY; }
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_kls, kls, cap * ni * sizeof(olf_keyline), hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_ldesc, ldesc, cap * ni * OLF_DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_lcounts, lcounts, ni * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_stereo_lines_dev(c, n_pairs, c->d_kls, c->d_ldesc, c->d_lcounts, c->d_lm12, c->d_ldisp, c->d_lle, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(m12, c->d_lm12, cap * n_pairs * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(disp, c->d_ldisp, cap * n_pairs * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(le, c->d_lle, cap * n_pairs * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, const olf_frame_buffers* o, void* stream)
+{
+    if (!c || !d_images || !o || !o->kps || !o->desc || !o->counts || !o->uright || !o->depth || !o->kls || !o->ldesc || !o->lcounts ||
+        !o->lmatches12 || !o->ldisp || !o->lle) { set_error("olf_stereo_frames_dev: null argument"); return OLF_ERR_INVALID; }
+    if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const int n_images = 2 * n_pairs;
+    // fork: the line path runs beside the ORB path (the reference's 4 extraction threads, src/Frame.cc:164-171)
+    OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+    OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2));
+    OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
+    OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    OLF_TRY(olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s));
+    OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
+    OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    return OLF_OK;
+}
+
+int olf_stereo_frames(olf_ctx* c, const uint8_t* images, int n_pairs, const olf_frame_buffers* o)
+{
+    if (!c || !images || !o) { set_error("olf_stereo_frames: null argument"); return OLF_ERR_INVALID; }
+    if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
+    if (n_pairs == 0) return OLF_OK;
+    const size_t npx = (size_t)c->W * c->H, cap = c->orb.geom.outCap, lcap = c->line.geom.outCap, ni = 2 * (size_t)n_pairs;
+    olf_frame_buffers d;
+    d.kps = c->d_kps; d.desc = c->d_desc; d.counts = c->d_counts; d.uright = c->d_uright; d.depth = c->d_depth;
+    d.kls = c->d_kls; d.ldesc = c->d_ldesc; d.lcounts = c->d_lcounts; d.lmatches12 = c->d_lm12; d.ldisp = c->d_ldisp; d.lle = c->d_lle;
+    OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * ni, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_stereo_frames_dev(c, c->d_images, n_pairs, &d, c->stream));
+    hipStream_t s = c->stream;
+    OLF_HIP_CHECK(hipMemcpyAsync(o->kps, d.kps, cap * ni * sizeof(olf_keypoint), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->desc, d.desc, cap * ni * OLF_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->counts, d.counts, ni * sizeof(int), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->uright, d.uright, cap * n_pairs * sizeof(float), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->depth, d.depth, cap * n_pairs * sizeof(float), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->kls, d.kls, lcap * ni * sizeof(olf_keyline), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->ldesc, d.ldesc, lcap * ni * OLF_DESC_BYTES, hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->lcounts, d.lcounts, ni * sizeof(int), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->lmatches12, d.lmatches12, lcap * n_pairs * sizeof(int), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->ldisp, d.ldisp, lcap * n_pairs * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipMemcpyAsync(o->lle, d.lle, lcap * n_pairs * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    OLF_HIP_CHECK(hipStreamSynchronize(s));
+    return check_status(c);
 }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 // cv::getGaussianKernel + 8-bit fixed point conversion (App. A.3).  These are evaluated once per
 // context on the host, in the same float/double expressions as the reference, and uploaded.
 #include "olf_internal.hpp"
+#include "line_internal.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cfenv>
@@ -152,6 +153,67 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
     while (mn < maxQuota + 8) mn <<= 1;
     g.maxNodes = mn;
     if (mn > 4096) return OLF_ERR_INVALID;
+    return OLF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Line side: constants of cv::LineSegmentDetector (OpenCV 3.4 lsd.cpp) as set up
+// by LSDDetectorC::detectImpl (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:246-253) and the
+// LBD weights of BinaryDescriptor (binary_descriptor_custom.cpp:217-259).
+int LineHostTables::build(const olf_line_params& p, int W, int H)
+{
+    LineGeom& g = geom;
+    g = LineGeom();
+    if (p.lsd_refine != 0) return OLF_ERR_INVALID;            // only LSD_REFINE_NONE is on the path
+    if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
+    const double kPI = 3.1415926535897932384626433832795;
+    g.W = W; g.H = H; g.pitchW = (W + 63) & ~63;
+    g.scale = p.lsd_scale;
+    g.Ws = cv_round_d(W * p.lsd_scale); g.Hs = cv_round_d(H * p.lsd_scale);
+    g.pitchS = (g.Ws + 63) & ~63;
+    g.Ps = g.Ws * g.Hs;
+    if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
+    g.prec = kPI * p.lsd_ang_th / 180;
+    const double pp = p.lsd_ang_th / 180;
+    const double rho = p.lsd_quant / std::sin(g.prec);
+    int n = 0;
+    while (!(std::sqrt(n / 4.0) > rho)) ++n;
+    g.nThr = n;
+    g.nBins = p.lsd_n_bins;
+    const double LOG_NT = 5 * (std::log10(double(g.Ws)) + std::log10(double(g.Hs))) / 2 + std::log10(11.0);
+    g.minRegSize = int(-LOG_NT / std::log10(pp));
+    g.minLength = p.min_line_length * std::min(W, H);
+    g.maxDetect = 4096;
+    g.nFeatures = p.lsd_nfeatures;
+    g.outCap = p.lsd_nfeatures > 0 ? p.lsd_nfeatures : g.maxDetect;
+    for (int i = 0; i < 7; ++i) { g.lsdTaps[i] = 0; g.lbdTaps[i] = 0; }
+    if (p.lsd_scale != 1) {
+        const double sigma = (p.lsd_scale < 1) ? (p.lsd_sigma_scale / p.lsd_scale) : p.lsd_sigma_scale;
+        const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+        if (hk > 3) return OLF_ERR_INVALID;   // kernels wider than 7 taps are not implemented
+        std::vector<int> t = gaussian_taps_q8(1 + 2 * hk, sigma);
+        for (unsigned i = 0; i < t.size(); ++i) g.lsdTaps[3 - hk + i] = t[i];
+    } else g.lsdTaps[3] = 256;               // identity: cv::LineSegmentDetector skips blur+resize at scale 1
+    {
+        std::vector<int> t = gaussian_taps_q8(5, 1.0);
+        for (int i = 0; i < 5; ++i) g.lbdTaps[1 + i] = t[i];
+    }
+    {   // integer divisions are the reference's (binary_descriptor_custom.cpp:224-257)
+        const int widthOfBand = 7, numBands = 9;
+        double u = (widthOfBand * 3 - 1) / 2;
+        double sigma = (widthOfBand * 2 + 1) / 2;
+        double invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < widthOfBand * 3; ++i) { double dis = i - u; g.gaussCoefL[i] = (float)std::exp(dis * dis * invsigma2); }
+        u = (numBands * widthOfBand - 1) / 2;
+        sigma = u;
+        invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < numBands * widthOfBand; ++i) { double dis = i - u; g.gaussCoefG[i] = (float)std::exp(dis * dis * invsigma2); }
+    }
+    rx.resize(g.Ws); ry.resize(g.Hs);
+    g.resizeTabX = 0; g.resizeTabY = 0;
+    // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE, INTER_LINEAR): scale_x = 1/SCALE
+    resize_axis_coefs(W, g.Ws, 1. / p.lsd_scale, true, rx.data());
+    resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
     return OLF_OK;
 }
 

@@ -1,0 +1,259 @@
+// lbd.hip -- the rest of Lineextractor::operator() (reference src/LineExtractor.cc:55-66), gfx950:
+//   top-N by response (std::sort + resize + class_id renumbering, :56-65; convention C.3: stable order)
+//   BinaryDescriptor::compute -> computeImpl / computeSobel / computeLBD / binaryConversion
+//   (Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp:350-412, :539-687, :1026-1372).
+// The LBD float chains are order-sensitive (sequential += over the support-region columns, then over
+// its 63 rows), so the mapping is: one thread per (line, support row) walks the row's columns in the
+// reference order; one thread per line folds the 63 rows into the 9 bands and finishes the descriptor.
+// No FMA contraction anywhere (f_mul/f_add are __fmul_rn/__fadd_rn).
+#include "line_internal.hpp"
+#include "device_math.hpp"
+
+namespace olf {
+
+#define OLF_TRY_RC(expr) do { int _rc = (expr); if (_rc != OLF_OK) return _rc; } while (0)
+
+__constant__ int8_t c_bandPairs[64] = {
+#include "lbd_band_pairs.inc"
+};
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_line_select(const LineGeom* __restrict__ gp, const olf_keyline* __restrict__ rawLines,
+                                                     const int* __restrict__ rawCount, olf_keyline* __restrict__ kls, int* __restrict__ counts)
+{
+    extern __shared__ unsigned long long skeys[];
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int R = min(rawCount[img], g.maxDetect);
+    const olf_keyline* raw = rawLines + (size_t)img * g.maxDetect;
+    olf_keyline* out = kls + (size_t)img * g.outCap;
+    if (!(R > g.nFeatures && g.nFeatures != 0)) {
+        const int n = min(R, g.outCap);
+        for (int i = tid; i < n; i += 256) out[i] = raw[i];
+        if (tid == 0) counts[img] = n;
+        return;
+    }
+    int sortN = 64;
+    while (sortN < R) sortN <<= 1;
+    for (int i = tid; i < sortN; i += 256) {
+        unsigned long long k = 0;
+        if (i < R) k = ((unsigned long long)__float_as_uint(raw[i].response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+        skeys[i] = k;   // responses are >= 0, so the float bit pattern orders like the value
+    }
+    __syncthreads();
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = skeys[i], b = skeys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { skeys[i] = b; skeys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < g.nFeatures; i += 256) {
+        const unsigned idx = 0xffffffffu - (unsigned)(skeys[i] & 0xffffffffull);
+        olf_keyline kl = raw[idx];
+        kl.class_id = i;
+        out[i] = kl;
+    }
+    if (tid == 0) counts[img] = g.nFeatures;
+}
+
+// cv::Sobel(CV_16S, ksize 3, BORDER_REFLECT_101) of the sigma-1 blurred image, dx and dy packed
+__global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ blur, uint32_t* __restrict__ dxdy, const LineGeom* __restrict__ gp)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= g.W * g.H) return;
+    const int y = idx / g.W, x = idx - y * g.W;
+    const uint8_t* b = blur + (size_t)img * g.pitchW * g.H;
+    const int ym = y == 0 ? 1 : y - 1, yp = y == g.H - 1 ? g.H - 2 : y + 1;
+    const int xm = x == 0 ? 1 : x - 1, xp = x == g.W - 1 ? g.W - 2 : x + 1;
+    const uint8_t *r0 = b + (size_t)ym * g.pitchW, *r1 = b + (size_t)y * g.pitchW, *r2 = b + (size_t)yp * g.pitchW;
+    const int dx = ((int)r0[xp] - (int)r0[xm]) + 2 * ((int)r1[xp] - (int)r1[xm]) + ((int)r2[xp] - (int)r2[xm]);
+    const int dy = ((int)r2[xm] + 2 * (int)r2[x] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r0[x] + (int)r0[xp]);
+    dxdy[(size_t)img * g.W * g.H + idx] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+}
+
+// one thread per (line, support-region row): the four weighted row sums of computeLBD (:1143-1196)
+__global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ dxdyAll,
+                                                  const olf_keyline* __restrict__ kls, const int* __restrict__ counts,
+                                                  float4* __restrict__ rowSums)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int li = t / 63, hID = t - li * 63;
+    if (li >= counts[img]) return;
+    const olf_keyline kl = kls[(size_t)img * g.outCap + li];
+    const uint32_t* dxdy = dxdyAll + (size_t)img * g.W * g.H;
+    const short heightOfLSP = 63;
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+    const short halfHeight = (short)((heightOfLSP - 1) / 2);
+    const short realWidth = (short)g.W, imageWidth = (short)(g.W - 1), imageHeight = (short)(g.H - 1);
+    const float midX = (float)(0.5 * (double)f_add(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)(0.5 * (double)f_add(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);   // convention C.6
+    const float dO0 = -dL1, dO1 = dL0;
+    float sCorX0 = f_add(f_add(f_mul(-dL0, (float)halfWidth), f_mul(dL1, (float)halfHeight)), midX);
+    float sCorY0 = f_add(f_sub(f_mul(-dL1, (float)halfWidth), f_mul(dL0, (float)halfHeight)), midY);
+    for (int h = 0; h < hID; ++h) { sCorX0 = f_sub(sCorX0, dL1); sCorY0 = f_add(sCorY0, dL0); }
+    float sCorX = sCorX0, sCorY = sCorY0;
+    float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+    for (short wID = 0; wID < lengthOfLSP; ++wID) {
+        int tc = (int)(short)roundf(sCorX);
+        const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+        tc = (int)(short)roundf(sCorY);
+        const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+        const uint32_t p = dxdy[yCor * realWidth + xCor];
+        const float dx = (float)(int)(int16_t)(p & 0xffffu), dy = (float)(int)(int16_t)(p >> 16);
+        const float gDL = f_add(f_mul(dx, dL0), f_mul(dy, dL1));
+        const float gDO = f_add(f_mul(dx, dO0), f_mul(dy, dO1));
+        if (gDL > 0) pgdL = f_add(pgdL, gDL); else ngdL = f_sub(ngdL, gDL);
+        if (gDO > 0) pgdO = f_add(pgdO, gDO); else ngdO = f_sub(ngdO, gDO);
+        sCorX = f_add(sCorX, dL0);
+        sCorY = f_add(sCorY, dL1);
+    }
+    const float cg = g.gaussCoefG[hID];
+    rowSums[((size_t)img * g.outCap + li) * 63 + hID] = make_float4(f_mul(cg, pgdL), f_mul(cg, ngdL), f_mul(cg, pgdO), f_mul(cg, ngdO));
+}
+
+// one thread per line: 63 rows -> 9 bands (:1201-1240), means/stds (:1256-1280), normalise / clip / renormalise
+// (:1283-1341), 32 x binaryConversion (:401-412, :645-667)
+__global__ __launch_bounds__(64) void k_lbd_desc(const LineGeom* __restrict__ gp, const float4* __restrict__ rowSums,
+                                                 const int* __restrict__ counts, uint8_t* __restrict__ desc)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y;
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= counts[img]) return;
+    const float4* rs = rowSums + ((size_t)img * g.outCap + li) * 63;
+    float bs[9][8];   // pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
+#pragma unroll
+    for (int b = 0; b < 9; ++b)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs[b][k] = 0.f;
+    for (int hID = 0; hID < 63; ++hID) {
+        const float4 r = rs[hID];
+        const float pL = r.x, nL = r.y, pO = r.z, nO = r.w;
+        const float pL2 = f_mul(pL, pL), nL2 = f_mul(nL, nL), pO2 = f_mul(pO, pO), nO2 = f_mul(nO, nO);
+        const int band = hID / 7, m = hID - band * 7;
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            // order of the reference: own band (coef L[m+7]), band above (L[m+14]), band below (L[m])
+            const int b = which == 0 ? band : (which == 1 ? band - 1 : band + 1);
+            if (b < 0 || b >= 9) continue;
+            const float c = g.gaussCoefL[which == 0 ? m + 7 : (which == 1 ? m + 14 : m)];
+            const float cc = f_mul(c, c);
+#pragma unroll
+            for (int bb = 0; bb < 9; ++bb)
+                if (bb == b) {
+                    bs[bb][0] = f_add(bs[bb][0], f_mul(c, pL));
+                    bs[bb][1] = f_add(bs[bb][1], f_mul(c, nL));
+                    bs[bb][2] = f_add(bs[bb][2], f_mul(cc, pL2));
+                    bs[bb][3] = f_add(bs[bb][3], f_mul(cc, nL2));
+                    bs[bb][4] = f_add(bs[bb][4], f_mul(c, pO));
+                    bs[bb][5] = f_add(bs[bb][5], f_mul(c, nO));
+                    bs[bb][6] = f_add(bs[bb][6], f_mul(cc, pO2));
+                    bs[bb][7] = f_add(bs[bb][7], f_mul(cc, nO2));
+                }
+        }
+    }
+    float d[72];
+    const float invN2 = (float)(1.0 / (7 * 2.0)), invN3 = (float)(1.0 / (7 * 3.0));
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+        const float invN = (b == 0 || b == 8) ? invN2 : invN3;
+        float temp = f_mul(bs[b][0], invN);
+        d[8 * b] = temp;
+        d[8 * b + 4] = (float)sqrt((double)f_sub(f_mul(bs[b][2], invN), f_mul(temp, temp)));
+        temp = f_mul(bs[b][1], invN);
+        d[8 * b + 1] = temp;
+        d[8 * b + 5] = (float)sqrt((double)f_sub(f_mul(bs[b][3], invN), f_mul(temp, temp)));
+        temp = f_mul(bs[b][4], invN);
+        d[8 * b + 2] = temp;
+        d[8 * b + 6] = (float)sqrt((double)f_sub(f_mul(bs[b][6], invN), f_mul(temp, temp)));
+        temp = f_mul(bs[b][5], invN);
+        d[8 * b + 3] = temp;
+        d[8 * b + 7] = (float)sqrt((double)f_sub(f_mul(bs[b][7], invN), f_mul(temp, temp)));
+    }
+    float tempM = 0, tempS = 0;
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tempM = f_add(tempM, f_mul(d[8 * b + k], d[8 * b + k]));
+#pragma unroll
+        for (int k = 4; k < 8; ++k) tempS = f_add(tempS, f_mul(d[8 * b + k], d[8 * b + k]));
+    }
+    tempM = (float)(1 / sqrt((double)tempM));
+    tempS = (float)(1 / sqrt((double)tempS));
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[8 * b + k] = f_mul(d[8 * b + k], tempM);
+#pragma unroll
+        for (int k = 4; k < 8; ++k) d[8 * b + k] = f_mul(d[8 * b + k], tempS);
+    }
+#pragma unroll
+    for (int i = 0; i < 72; ++i)
+        if ((double)d[i] > 0.4) d[i] = (float)0.4;
+    float temp = 0;
+#pragma unroll
+    for (int i = 0; i < 72; ++i) temp = f_add(temp, f_mul(d[i], d[i]));
+    temp = (float)(1 / sqrt((double)temp));
+#pragma unroll
+    for (int i = 0; i < 72; ++i) d[i] = f_mul(d[i], temp);
+    uint8_t* o = desc + ((size_t)img * g.outCap + li) * OLF_DESC_BYTES;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const int p = c_bandPairs[2 * c], q = c_bandPairs[2 * c + 1];
+        unsigned r = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float f1 = 0, f2 = 0;
+#pragma unroll
+            for (int bb = 0; bb < 9; ++bb) { if (bb == p) f1 = d[8 * bb + i]; if (bb == q) f2 = d[8 * bb + i]; }
+            if (f1 > f2) r += 1u << i;
+        }
+        o[c] = (uint8_t)r;
+    }
+}
+
+int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images,
+                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s)
+{
+    int sortN = 64;
+    while (sortN < g.maxDetect) sortN <<= 1;
+    hipLaunchKernelGGL(k_line_select, dim3(n_images), dim3(256), sortN * sizeof(unsigned long long), s, b.geom, b.rawLines, b.rawCount, d_kls,
+                       d_counts);
+    // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel)
+    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 1, n_images, s));
+    hipLaunchKernelGGL(k_sobel3, dim3((g.W * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                       reinterpret_cast<float4*>(b.rowSums));
+    hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
+                       d_counts, d_desc);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+// BinaryDescriptor::compute on key lines already in d_kls/d_counts (no LSD, no selection)
+int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
+                    uint8_t* d_desc, const int* d_counts, hipStream_t s)
+{
+    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 1, n_images, s));
+    hipLaunchKernelGGL(k_sobel3, dim3((g.W * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                       reinterpret_cast<float4*>(b.rowSums));
+    hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
+                       d_counts, d_desc);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+}  // namespace olf

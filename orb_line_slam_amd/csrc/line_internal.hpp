@@ -1,0 +1,84 @@
+// line_internal.hpp -- device layout of the line half of the path (Lineextractor: LSD + LBD) and
+// of the stereo line matcher.  See lsd.hip / lbd.hip / linematch.hip.
+//
+// HBM layout per image (W x H input, Ws x Hs = round(1.2 W) x round(1.2 H) LSD working size):
+//   lsdBlur  : u8  H  x pitchW     GaussianBlur(7x7, sigma 0.6) of the input            (LSD step 1)
+//   scaled   : u8  Hs x pitchS     x1.2 bilinear upsample                               (LSD step 1)
+//   grad     : u32 Hs x Ws         packed (gx, gy) int16 pair; gx = -32768 marks NOTDEF (LSD ll_angle)
+//   keys     : u32 Ps (x2)         ((n_bins-1-bin) << 22 | address) of every defined pixel, sorted ascending
+//   used     : u8  Ps              region-growing `used` map
+//   region   : u32 Ps              FIFO of the region being grown (x | y << 16)
+//   rawLines : olf_keyline maxDetect  key lines in detection order (after the length filter)
+//   lbdBlur  : u8  H x pitchW      GaussianBlur(5x5, sigma 1)                           (LBD)
+//   dxdy     : u32 H x W           packed Sobel (dx, dy) int16 pair                     (LBD)
+//   rowSums  : float4 nLines x 63  per support-region row: (pgdL, ngdL, pgdO, ngdO)     (LBD)
+#pragma once
+#include "olf_internal.hpp"
+
+namespace olf {
+
+struct LineGeom {
+    int W, H, pitchW;          // input size, 64-byte aligned pitch of the u8 work images
+    int Ws, Hs, pitchS, Ps;    // LSD working size, Ps = Ws*Hs
+    int nThr;                  // smallest gx^2+gy^2 whose norm sqrt(n/4.0) exceeds rho
+    int nBins;
+    int minRegSize;
+    double prec;               // pi * ang_th / 180
+    double scale;              // lsd_scale
+    double minLength;          // min_line_length * min(W, H)
+    int maxDetect;             // capacity of the raw key line list
+    int nFeatures;             // lsd_nfeatures (0 = keep all)
+    int outCap;                // key lines returned per image
+    int lsdTaps[7];            // sigma 0.6 (7x7)
+    int lbdTaps[7];            // sigma 1 (5x5, zero padded to 7)
+    float gaussCoefL[21];      // (float) of the reference's double weights
+    float gaussCoefG[63];
+    int resizeTabX, resizeTabY;
+};
+
+struct LineDeviceBufs {
+    uint8_t* lsdBlur = nullptr;
+    uint8_t* scaled = nullptr;
+    uint32_t* grad = nullptr;
+    uint32_t* keysA = nullptr;
+    uint32_t* keysB = nullptr;
+    int* keyCount = nullptr;       // [n] defined-pixel count
+    int* maxN = nullptr;           // [n] max gx^2+gy^2 over defined pixels
+    unsigned* segBegin = nullptr;  // [n] segment offsets for the sort
+    unsigned* segEnd = nullptr;
+    uint8_t* used = nullptr;
+    uint32_t* region = nullptr;
+    olf_keyline* rawLines = nullptr;
+    int* rawCount = nullptr;
+    uint8_t* lbdBlur = nullptr;
+    uint32_t* dxdy = nullptr;
+    float* rowSums = nullptr;      // [n][outCap][63][4]
+    ResizeCoef* rx = nullptr;
+    ResizeCoef* ry = nullptr;
+    LineGeom* geom = nullptr;
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    int* status = nullptr;
+};
+
+struct LineHostTables {
+    LineGeom geom;
+    std::vector<ResizeCoef> rx, ry;
+    int build(const olf_line_params& p, int W, int H);
+};
+
+int launch_lsd(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s);
+int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images,
+                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s);
+int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
+                    uint8_t* d_desc, const int* d_counts, hipStream_t s);
+int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
+                      const LineGeom* d_geom, int which, int n_images, hipStream_t s);
+size_t lsd_sort_temp_bytes(int total_keys, int n_segments);
+
+size_t stereo_lines_prep_bytes(int n_images, int cap);
+int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_desc,
+                        const int* d_counts, int cap, void* d_prep, uint16_t* d_dist /* [pairs][cap][cap] */, int* d_m21, int* d_m12,
+                        float* d_disp, double* d_le, hipStream_t s);
+
+}  // namespace olf

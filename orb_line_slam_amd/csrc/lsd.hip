@@ -1,0 +1,431 @@
+// lsd.hip -- cv::LineSegmentDetector (OpenCV 3.4 lsd.cpp, LSD_REFINE_NONE) as called by
+// LSDDetectorC::detectImpl (reference Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:227-324), gfx950.
+//
+// Data-parallel front half (HBM-bound stencils, one pass each): sigma-0.6 blur, x1.2 bilinear upsample,
+// 2x2 gradient.  The reference keeps fp64 modgrad + angle per pixel (16 B); both are pure functions of
+// the integer gradient pair, so we store (gx, gy) as 2 x int16 (4 B/px) and recompute norm / angle on
+// demand with the reference's own expressions (bit-identical, 4x less traffic).
+// Pseudo-ordering: every defined pixel becomes a key ((n_bins-1-bin) << 22 | address); an ascending
+// segmented radix sort (rocPRIM) yields "bins high to low, raster order inside a bin".
+// Region growing is order-dependent by construction (seed order, running region angle, shared `used`
+// map), so one wave per image replays it sequentially; inside the wave the 3x3 neighbourhoods of up to
+// 7 FIFO entries are fetched and their angles / cos / sin evaluated in parallel (63 lanes), and only
+// the accept/reject chain is serial.  Parallelism comes from the batch: thousands of images in flight.
+#include "line_internal.hpp"
+#include "device_math.hpp"
+#include <rocprim/rocprim.hpp>
+
+namespace olf {
+
+constexpr double kPI = 3.1415926535897932384626433832795;
+constexpr double kDegToRads = kPI / 180;
+constexpr double kM32PI = (3 * kPI) / 2, kM2PI = 2 * kPI;
+constexpr unsigned kNotDefGx = 0x8000u;
+
+__device__ __forceinline__ int refl101(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * (n - 1) - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 7-tap separable Gaussian in 8-bit fixed point (App. A.3) on plain images: src [n][H][srcPitch]
+// -> dst [n][H][dstPitch].  which = 0: LSD taps, 1: LBD taps.
+constexpr int GT_W = 64, GT_H = 16;
+__global__ __launch_bounds__(256) void k_gauss7_img(const uint8_t* __restrict__ src, int srcPitch, size_t srcImgStride,
+                                                    uint8_t* __restrict__ dst, int dstPitch, size_t dstImgStride, int W, int H,
+                                                    const LineGeom* __restrict__ gp, int which)
+{
+    __shared__ uint8_t in[(GT_H + 6) * 72];
+    __shared__ uint16_t hrow[(GT_H + 6) * 64];
+    const int img = blockIdx.z;
+    const int x0 = blockIdx.x * GT_W, y0 = blockIdx.y * GT_H;
+    const uint8_t* s = src + (size_t)img * srcImgStride;
+    for (int i = threadIdx.x; i < (GT_H + 6) * (GT_W + 6); i += 256) {
+        const int ty = i / (GT_W + 6), tx = i - ty * (GT_W + 6);
+        const int gx = refl101(min(x0 - 3 + tx, W + 2), W), gy = refl101(min(y0 - 3 + ty, H + 2), H);
+        in[ty * 72 + tx] = s[(size_t)gy * srcPitch + gx];
+    }
+    __syncthreads();
+    int taps[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) taps[k] = which ? gp->lbdTaps[k] : gp->lsdTaps[k];
+    for (int i = threadIdx.x; i < (GT_H + 6) * GT_W; i += 256) {
+        const int ty = i >> 6, tx = i & 63;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += taps[k] * in[ty * 72 + tx + k];
+        hrow[i] = (uint16_t)acc;
+    }
+    __syncthreads();
+    uint8_t* d = dst + (size_t)img * dstImgStride;
+    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ly = ly0 + 4 * r;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= W || gy >= H) continue;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += taps[k] * hrow[(ly + k) * 64 + lx];
+        acc = (acc + 32768) >> 16;
+        d[(size_t)gy * dstPitch + gx] = (uint8_t)min(acc, 255);
+    }
+}
+
+int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
+                      const LineGeom* d_geom, int which, int n_images, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gauss7_img, dim3((W + GT_W - 1) / GT_W, (H + GT_H - 1) / GT_H, n_images), dim3(256), 0, s, src, srcPitch, srcStride, dst,
+                       dstPitch, dstStride, W, H, d_geom, which);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+// x1.2 bilinear upsample (cv::resize INTER_LINEAR, App. A.2)
+__global__ __launch_bounds__(256) void k_lsd_upsample(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const LineGeom* __restrict__ gp, const ResizeCoef* __restrict__ rx,
+                                                      const ResizeCoef* __restrict__ ry)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y;
+    const int quads = (g.Ws + 3) >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= quads * g.Hs) return;
+    const int dy = idx / quads, dx0 = (idx - dy * quads) * 4;
+    const uint8_t* s = src + (size_t)img * g.pitchW * g.H;
+    const ResizeCoef cy = ry[dy];
+    const int y0 = min(max((int)cy.ofs, 0), g.H - 1), y1 = min(max((int)cy.ofs + 1, 0), g.H - 1);
+    const uint8_t* S0 = s + (size_t)y0 * g.pitchW;
+    const uint8_t* S1 = s + (size_t)y1 * g.pitchW;
+    const int b0 = cy.a0, b1 = cy.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < g.Ws) {
+            const ResizeCoef cx = rx[dx];
+            const int sx = cx.ofs, sx1 = min(sx + 1, g.W - 1);
+            const int h0 = S0[sx] * cx.a0 + S0[sx1] * cx.a1;
+            const int h1 = S1[sx] * cx.a0 + S1[sx1] * cx.a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)img * g.pitchS * g.Hs + (size_t)dy * g.pitchS + dx0) = out;
+}
+
+// ll_angle, first half: gradient pair per pixel + per-image max of gx^2+gy^2 over defined pixels
+__global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
+                                                  const LineGeom* __restrict__ gp, int* __restrict__ maxN, int* __restrict__ keyCount,
+                                                  int* __restrict__ rawCount)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int n = 0;
+    if (idx < g.Ps) {
+        const int y = idx / g.Ws, x = idx - y * g.Ws;
+        uint32_t packed = kNotDefGx;
+        if (x < g.Ws - 1 && y < g.Hs - 1) {
+            const uint8_t* r0 = scaled + (size_t)img * g.pitchS * g.Hs + (size_t)y * g.pitchS + x;
+            const uint8_t* r1 = r0 + g.pitchS;
+            const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+            const int gx = DA + BC, gy = DA - BC;
+            n = gx * gx + gy * gy;
+            if (n >= g.nThr) packed = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
+            else n = 0;
+        }
+        grad[(size_t)img * g.Ps + idx] = packed;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o));
+    if ((threadIdx.x & 63) == 0 && n > 0) atomicMax(&maxN[img], n);
+}
+
+// ll_angle, second half: bin of every defined pixel -> sort key
+__global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
+                                                  const int* __restrict__ maxN, uint32_t* __restrict__ keys, int* __restrict__ keyCount)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    bool def = false;
+    uint32_t key = 0;
+    if (idx < g.Ps) {
+        const uint32_t p = grad[(size_t)img * g.Ps + idx];
+        if ((p & 0xffffu) != kNotDefGx) {
+            const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
+            const double max_grad = sqrt((double)maxN[img] / 4.0);
+            const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
+            const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+            const int bin = (int)(norm * bin_coef);
+            key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+            def = true;
+        }
+    }
+    const unsigned long long m = __ballot(def);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&keyCount[img], __popcll(m));
+    base = __shfl(base, 0);
+    if (def) keys[(size_t)img * g.Ps + base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+}
+
+__global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, unsigned* __restrict__ b, unsigned* __restrict__ e)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { b[i] = (unsigned)i * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_d(double v, int l)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, l); hi = __shfl(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double grad_angle(int gx, int gy) { return d_mul((double)dev_fastAtan2((float)gx, (float)(-gy)), kDegToRads); }
+
+__device__ __forceinline__ bool is_aligned(double a, double theta, double prec)
+{
+    double n_theta = d_sub(theta, a);
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > kM32PI) {
+        n_theta = d_sub(n_theta, kM2PI);
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+__global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
+                                                 const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
+                                                 uint8_t* __restrict__ usedAll, uint32_t* __restrict__ regionAll,
+                                                 olf_keyline* __restrict__ rawLines, int* __restrict__ rawCount, int* __restrict__ status)
+{
+    __shared__ int s_x[64], s_y[64];
+    __shared__ double s_w[64];
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int Ws = g.Ws, Hs = g.Hs;
+    const uint32_t* grad = gradAll + (size_t)img * g.Ps;
+    const uint32_t* keys = keysAll + (size_t)img * g.Ps;
+    uint8_t* used = usedAll + (size_t)img * g.Ps;
+    uint32_t* reg = regionAll + (size_t)img * g.Ps;
+    olf_keyline* out = rawLines + (size_t)img * g.maxDetect;
+    const int nkeys = keyCount[img];
+    const double prec = g.prec;
+    int nl = 0;
+    for (int base = 0; base < nkeys; base += 64) {
+        const bool valid = base + lane < nkeys;
+        const int addr = valid ? (int)(keys[base + lane] & 0x3fffffu) : 0;
+        unsigned long long mask = __ballot(valid && used[addr] == 0);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            const int seed = __shfl(addr, l);
+            // ---- region_grow ------------------------------------------------------------------
+            int n = 1;
+            double reg_angle;
+            float sumdx, sumdy;
+            {
+                const uint32_t p = grad[seed];
+                reg_angle = grad_angle((int)(int16_t)(p & 0xffffu), (int)(int16_t)(p >> 16));
+                double s, c;
+                sincos(reg_angle, &s, &c);
+                sumdx = (float)c; sumdy = (float)s;
+                if (lane == 0) { used[seed] = 1; reg[0] = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); }
+            }
+            __threadfence_block();
+            int i = 0;
+            while (i < n) {
+                const int nb = min(7, n - i);
+                const int e = lane / 9, k = lane - 9 * e;
+                bool cand = false;
+                int a = -1, xx = 0, yy = 0;
+                double ang = 0, cs = 0, sn = 0;
+                if (lane < 63 && e < nb && k != 4) {
+                    const uint32_t rp = reg[i + e];
+                    xx = (int)(rp & 0xffffu) + (k % 3) - 1;
+                    yy = (int)(rp >> 16) + (k / 3) - 1;
+                    if (xx >= 0 && yy >= 0 && xx < Ws && yy < Hs) {
+                        a = yy * Ws + xx;
+                        const uint32_t p = grad[a];
+                        if (used[a] == 0 && (p & 0xffffu) != kNotDefGx) {
+                            cand = true;
+                            ang = grad_angle((int)(int16_t)(p & 0xffffu), (int)(int16_t)(p >> 16));
+                            sincos((double)(float)ang, &sn, &cs);
+                        }
+                    }
+                }
+                unsigned long long cm = __ballot(cand);
+                while (cm) {
+                    const int c = __ffsll((long long)cm) - 1;
+                    cm &= cm - 1;
+                    if (!__shfl((int)cand, c)) continue;       // taken earlier in this batch
+                    const double ang_c = shfl_d(ang, c);
+                    if (is_aligned(ang_c, reg_angle, prec)) {
+                        const int a_c = __shfl(a, c);
+                        const int x_c = __shfl(xx, c), y_c = __shfl(yy, c);
+                        const double cs_c = shfl_d(cs, c), sn_c = shfl_d(sn, c);
+                        if (lane == 0) { used[a_c] = 1; reg[n] = (uint32_t)x_c | ((uint32_t)y_c << 16); }
+                        ++n;
+                        sumdx = (float)d_add((double)sumdx, cs_c);
+                        sumdy = (float)d_add((double)sumdy, sn_c);
+                        reg_angle = d_mul((double)dev_fastAtan2(sumdy, sumdx), kDegToRads);
+                        if (a == a_c) cand = false;
+                    }
+                }
+                i += nb;
+                __threadfence_block();
+            }
+            if (n >= g.minRegSize) {
+                // ---- region2rect: sums follow the region (growth) order exactly --------------------
+                double x = 0, y = 0, sum = 0;
+                for (int cb = 0; cb < n; cb += 64) {
+                    const int cnt = min(64, n - cb);
+                    if (lane < cnt) {
+                        const uint32_t rp = reg[cb + lane];
+                        const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
+                        const uint32_t p = grad[py * Ws + px];
+                        const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
+                        s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                    }
+                    __syncthreads();
+                    for (int q = 0; q < cnt; ++q) {
+                        const double w = s_w[q];
+                        x = d_add(x, d_mul((double)s_x[q], w));
+                        y = d_add(y, d_mul((double)s_y[q], w));
+                        sum = d_add(sum, w);
+                    }
+                    __syncthreads();
+                }
+                x = x / sum; y = y / sum;
+                double Ixx = 0, Iyy = 0, Ixy = 0;
+                for (int cb = 0; cb < n; cb += 64) {
+                    const int cnt = min(64, n - cb);
+                    if (lane < cnt) {
+                        const uint32_t rp = reg[cb + lane];
+                        const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
+                        const uint32_t p = grad[py * Ws + px];
+                        const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
+                        s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                    }
+                    __syncthreads();
+                    for (int q = 0; q < cnt; ++q) {
+                        const double w = s_w[q];
+                        const double ddx = d_sub((double)s_x[q], x), ddy = d_sub((double)s_y[q], y);
+                        Ixx = d_add(Ixx, d_mul(d_mul(ddy, ddy), w));
+                        Iyy = d_add(Iyy, d_mul(d_mul(ddx, ddx), w));
+                        Ixy = d_sub(Ixy, d_mul(d_mul(ddx, ddy), w));
+                    }
+                    __syncthreads();
+                }
+                const double dI = d_sub(Ixx, Iyy);
+                const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
+                double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)dev_fastAtan2((float)d_sub(lambda, Ixx), (float)Ixy)
+                                                       : (double)dev_fastAtan2((float)Ixy, (float)d_sub(lambda, Iyy));
+                theta = d_mul(theta, kDegToRads);
+                {
+                    double diff = d_sub(theta, reg_angle);
+                    while (diff <= -kPI) diff = d_add(diff, kM2PI);
+                    while (diff > kPI) diff = d_sub(diff, kM2PI);
+                    if (fabs(diff) > prec) theta = d_add(theta, kPI);
+                }
+                double ddx, ddy;
+                sincos(theta, &ddy, &ddx);
+                double l_min = 0, l_max = 0;
+                for (int cb = 0; cb < n; cb += 64) {
+                    const int cnt = min(64, n - cb);
+                    if (lane < cnt) {
+                        const uint32_t rp = reg[cb + lane];
+                        s_x[lane] = (int)(rp & 0xffffu); s_y[lane] = (int)(rp >> 16);
+                    }
+                    __syncthreads();
+                    for (int q = 0; q < cnt; ++q) {
+                        const double rdx = d_sub((double)s_x[q], x), rdy = d_sub((double)s_y[q], y);
+                        const double lq = d_add(d_mul(rdx, ddx), d_mul(rdy, ddy));
+                        if (lq > l_max) l_max = lq;
+                        else if (lq < l_min) l_min = lq;
+                    }
+                    __syncthreads();
+                }
+                double x1 = d_add(x, d_mul(l_min, ddx)), y1 = d_add(y, d_mul(l_min, ddy));
+                double x2 = d_add(x, d_mul(l_max, ddx)), y2 = d_add(y, d_mul(l_max, ddy));
+                x1 = d_add(x1, 0.5); y1 = d_add(y1, 0.5); x2 = d_add(x2, 0.5); y2 = d_add(y2, 0.5);
+                if (g.scale != 1) { x1 = x1 / g.scale; y1 = y1 / g.scale; x2 = x2 / g.scale; y2 = y2 / g.scale; }
+                // ---- LSDDetectorC::detectImpl: Vec4f -> KeyLine (LSDDetector_custom.cpp:270-307)
+                float e0 = (float)x1, e1 = (float)y1, e2 = (float)x2, e3 = (float)y2;
+                const int cols = g.W, rows = g.H;
+                if (e0 < 0) e0 = 0;
+                if (e0 >= cols) e0 = (float)cols - 1.0f;
+                if (e2 < 0) e2 = 0;
+                if (e2 >= cols) e2 = (float)cols - 1.0f;
+                if (e1 < 0) e1 = 0;
+                if (e1 >= rows) e1 = (float)rows - 1.0f;
+                if (e3 < 0) e3 = 0;
+                if (e3 >= rows) e3 = (float)rows - 1.0f;
+                const double dxe = (double)f_sub(e0, e2), dye = (double)f_sub(e1, e3);
+                const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
+                if (length > g.minLength) {
+                    if (nl < g.maxDetect) {
+                        if (lane == 0) {
+                            olf_keyline kl;
+                            kl.startPointX = e0; kl.startPointY = e1; kl.endPointX = e2; kl.endPointY = e3;
+                            kl.sPointInOctaveX = e0; kl.sPointInOctaveY = e1; kl.ePointInOctaveX = e2; kl.ePointInOctaveY = e3;
+                            kl.lineLength = (float)length;
+                            const int rx1 = __float2int_rn(e0), ry1 = __float2int_rn(e1), rx2 = __float2int_rn(e2), ry2 = __float2int_rn(e3);
+                            kl.numOfPixels = max(abs(rx2 - rx1), abs(ry2 - ry1)) + 1;
+                            kl.angle = (float)atan2((double)f_sub(e3, e1), (double)f_sub(e2, e0));
+                            kl.class_id = nl; kl.octave = 0;
+                            kl.size = f_mul(f_sub(e2, e0), f_sub(e3, e1));
+                            kl.response = f_div(kl.lineLength, (float)max(cols, rows));
+                            kl.pt_x = f_div(f_add(e2, e0), 2.0f); kl.pt_y = f_div(f_add(e3, e1), 2.0f);
+                            out[nl] = kl;
+                        }
+                        ++nl;
+                    } else if (lane == 0) atomicOr(status, 8);
+                }
+            }
+            // seeds later in this 64-key window may have been consumed by the region just grown
+            if (n == 1) mask &= mask - 1;
+            else mask = __ballot(valid && lane > l && used[addr] == 0);
+        }
+    }
+    if (lane == 0) rawCount[img] = nl;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t lsd_sort_temp_bytes(int total_keys, int n_segments)
+{
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)total_keys,
+                                             (unsigned)n_segments, (unsigned*)nullptr, (unsigned*)nullptr, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+int launch_lsd(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
+{
+    OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, n_images * sizeof(int), s));
+    OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, n_images * sizeof(int), s));
+    OLF_HIP_CHECK(hipMemsetAsync(b.used, 0, (size_t)n_images * g.Ps, s));
+    hipLaunchKernelGGL(k_gauss7_img, dim3((g.W + GT_W - 1) / GT_W, (g.H + GT_H - 1) / GT_H, n_images), dim3(256), 0, s, d_in, in_pitch,
+                       (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 0);
+    {
+        const int quads = ((g.Ws + 3) >> 2) * g.Hs;
+        hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
+    }
+    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.keyCount, b.rawCount);
+    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount);
+    hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
+    OLF_HIP_CHECK(hipGetLastError());
+    size_t tb = b.sortTempBytes;
+    OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA, b.keysB, (unsigned)((size_t)n_images * g.Ps), (unsigned)n_images,
+                                                      b.segBegin, b.segEnd, 0, 32, s));
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.used, b.region, b.rawLines, b.rawCount,
+                       b.status);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+}  // namespace olf

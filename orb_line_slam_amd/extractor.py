@@ -8,7 +8,7 @@ liborbline_hip.so on the GPU.
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._lib import KEYPOINT_DTYPE, DESC_BYTES, check, lib, ptr
+from ._lib import KEYPOINT_DTYPE, KEYLINE_DTYPE, DESC_BYTES, check, lib, ptr
 
 
 class ORBextractor:
@@ -115,3 +115,74 @@ class ORBextractor:
         n = C.c_int32()
         check(lib().olf_orb_debug_candidates(self._ctx.handle, image, level, ptr(xys), cap, C.byref(n)), "olf_orb_debug_candidates")
         return xys[:min(n.value, cap)]
+
+
+class Lineextractor:
+    """Mirror of ORB_SLAM2::Lineextractor (reference include/LineExtractor.h:40-72): LSD detection, top-N by
+    response, LBD description.  Both reference constructors are supported: (nfeatures, length_th[, bFLD]) and the
+    11-argument LSD form.  bFLD=True returns nothing, exactly like the reference (src/LineExtractor.cc:68)."""
+
+    def __init__(self, lsd_nfeatures, llength_th, lsd_refine=0, lsd_scale=1.2, lsd_sigma_scale=0.6, lsd_quant=2.0, lsd_ang_th=22.5,
+                 lsd_log_eps=1.0, lsd_density_th=0.6, lsd_n_bins=1024, bFLD=False, max_images=2, context=None):
+        p = _lib.default_params()
+        lp = p.line
+        lp.lsd_nfeatures, lp.min_line_length, lp.lsd_refine = int(lsd_nfeatures), float(llength_th), int(lsd_refine)
+        lp.lsd_scale, lp.lsd_sigma_scale, lp.lsd_quant, lp.lsd_ang_th = float(lsd_scale), float(lsd_sigma_scale), float(lsd_quant), float(lsd_ang_th)
+        lp.lsd_log_eps, lp.lsd_density_th, lp.lsd_n_bins = float(lsd_log_eps), float(lsd_density_th), int(lsd_n_bins)
+        self._params, self._max_images, self._ctx, self.bFLD = p, int(max_images), context, bool(bFLD)
+
+    def _context(self, width, height, n_images):
+        c = self._ctx
+        if c is None or c.width != width or c.height != height or c.max_images < n_images:
+            if c is not None:
+                c.close()
+            c = _lib.Context(self._params, width, height, max(n_images, self._max_images))
+            self._ctx = c
+        return c
+
+    def __call__(self, image, mask=None):
+        """image (H, W) uint8 -> (keylines[KEYLINE_DTYPE], descriptors (N, 32) uint8); mask ignored."""
+        image = np.asarray(image)
+        if self.bFLD or image.size == 0:
+            return np.zeros(0, KEYLINE_DTYPE), np.zeros((0, DESC_BYTES), np.uint8)
+        kls, desc, counts = self.extract_batch(image[None])
+        n = int(counts[0])
+        return kls[0, :n].copy(), desc[0, :n].copy()
+
+    def extract_batch(self, images):
+        images = np.asarray(images)
+        if images.dtype != np.uint8 or images.ndim != 3:
+            raise RuntimeError("Error, depth image!= 0")   # LSDDetector_custom.cpp:236-237
+        images = np.ascontiguousarray(images)
+        n, h, w = images.shape
+        ctx = self._context(w, h, n)
+        cap = ctx.line_capacity
+        kls = np.zeros((n, cap), KEYLINE_DTYPE)
+        desc = np.zeros((n, cap, DESC_BYTES), np.uint8)
+        counts = np.zeros(n, np.int32)
+        check(lib().olf_line_extract(ctx.handle, ptr(images), n, ptr(kls), ptr(desc), ptr(counts)), "olf_line_extract")
+        return kls, desc, counts
+
+    def compute(self, image, keylines):
+        """BinaryDescriptor::compute(image, keylines, descriptors) on caller-supplied key lines."""
+        image = np.ascontiguousarray(image)
+        h, w = image.shape
+        ctx = self._context(w, h, 1)
+        cap = ctx.line_capacity
+        if len(keylines) > cap:
+            raise ValueError("more key lines than the extractor capacity")
+        if len(keylines) == 0:
+            return np.zeros((0, DESC_BYTES), np.uint8)   # "Error: keypoint list is empty" (binary_descriptor_custom.cpp:556-560)
+        k = np.zeros((1, cap), KEYLINE_DTYPE)
+        k[0, :len(keylines)] = keylines
+        desc = np.zeros((1, cap, DESC_BYTES), np.uint8)
+        counts = np.array([len(keylines)], np.int32)
+        check(lib().olf_lbd_compute(ctx.handle, ptr(image[None].copy()), 1, ptr(k), ptr(counts), ptr(desc)), "olf_lbd_compute")
+        return desc[0, :len(keylines)].copy()
+
+    def debug_scaled(self, image=0):
+        ctx = self._ctx
+        buf = np.zeros(int(ctx.width * 1.5) * int(ctx.height * 1.5), np.uint8)
+        ws, hs = C.c_int32(), C.c_int32()
+        check(lib().olf_lsd_debug_scaled(ctx.handle, image, ptr(buf), C.byref(ws), C.byref(hs)), "olf_lsd_debug_scaled")
+        return buf[:ws.value * hs.value].reshape(hs.value, ws.value).copy()

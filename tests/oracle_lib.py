@@ -141,3 +141,63 @@ def stereo_points(imgL, imgR, p, cap=None):
     assert rc == 0, rc
     n, m = nl.value, nr.value
     return dict(kpsL=kl[:n], descL=dl[:n], kpsR=kr[:m], descR=dr[:m], uRight=ur[:n], depth=dp[:n], sad=sad[:n])
+
+
+def lsd_detect(img, lp, cap=20000):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    segs = np.zeros((cap, 4), np.float32)
+    n, sw, sh = C.c_int(), C.c_int(), C.c_int()
+    scaled = np.zeros(int(w * 1.3 + 2) * int(h * 1.3 + 2), np.uint8)
+    rc = _L.orc_lsd_detect(_p(img), w, h, C.byref(lp), _p(segs), cap, C.byref(n), _p(scaled), C.byref(sw), C.byref(sh))
+    assert rc == 0, rc
+    return segs[:n.value].copy(), scaled[:sw.value * sh.value].reshape(sh.value, sw.value).copy()
+
+
+def line_extract(img, lp, use_std_sort=False, cap=None, all_cap=20000):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    cap = cap or max(lp.lsd_nfeatures, 1) + 16 if lp.lsd_nfeatures else all_cap
+    kls = np.zeros(cap, KEYLINE_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    allk = np.zeros(all_cap, KEYLINE_DTYPE)
+    n, na = C.c_int(), C.c_int()
+    rc = _L.orc_line_extract(_p(img), w, h, C.byref(lp), int(use_std_sort), _p(kls), _p(desc), cap, C.byref(n), _p(allk), all_cap, C.byref(na))
+    assert rc == 0, rc
+    return dict(kls=kls[:n.value].copy(), desc=desc[:n.value].copy(), all=allk[:min(na.value, all_cap)].copy(), n_all=na.value)
+
+
+def lbd_compute(img, kls, want_float=False):
+    img = np.ascontiguousarray(img)
+    kls = np.ascontiguousarray(kls)
+    h, w = img.shape
+    n = len(kls)
+    desc = np.zeros((n, 32), np.uint8)
+    fd = np.zeros((n, 72), np.float32) if want_float else None
+    _L.orc_lbd_compute(_p(img), w, h, _p(kls), n, _p(desc), _p(fd))
+    return (desc, fd) if want_float else desc
+
+
+def sobel3(img):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape
+    dx, dy = np.zeros((h, w), np.int16), np.zeros((h, w), np.int16)
+    _L.orc_sobel3(_p(img), w, h, _p(dx), _p(dy))
+    return dx, dy
+
+
+def line_coords(x1, y1, x2, y2, cap=4096):
+    xy = np.zeros((cap, 2), np.int32)
+    n = _L.orc_line_coords(C.c_double(x1), C.c_double(y1), C.c_double(x2), C.c_double(y2), _p(xy), cap)
+    return xy[:n].copy()
+
+
+def stereo_lines(klL, descL, klR, descR, w, h, sp):
+    klL, klR = np.ascontiguousarray(klL), np.ascontiguousarray(klR)
+    descL, descR = np.ascontiguousarray(descL), np.ascontiguousarray(descR)
+    nL, nR = len(klL), len(klR)
+    m = np.full(nL, -1, np.int32)
+    disp = np.zeros((nL, 2), np.float32)
+    le = np.zeros((nL, 3), np.float64)
+    _L.orc_stereo_lines(_p(klL), _p(descL), nL, _p(klR), _p(descR), nR, w, h, C.byref(sp), _p(m), _p(disp), _p(le))
+    return m, disp, le

@@ -1,0 +1,69 @@
+"""GPU parity: Lineextractor (LSD + LBD), stereo line matching and the fused stereo-frame entry vs the CPU oracle."""
+import numpy as np
+import pytest
+import orb_line_slam_amd as ola
+from orb_line_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+KL_FLOAT = ("angle", "pt_x", "pt_y", "response", "size", "startPointX", "startPointY", "endPointX", "endPointY", "sPointInOctaveX",
+            "sPointInOctaveY", "ePointInOctaveX", "ePointInOctaveY", "lineLength")
+KL_INT = ("class_id", "octave", "numOfPixels")
+
+
+def _cmp_keylines(g, o):
+    assert len(g) == len(o), (len(g), len(o))
+    for f in KL_INT:
+        assert np.array_equal(g[f], o[f]), f
+    for f in KL_FLOAT:
+        assert np.array_equal(g[f].view(np.uint32), o[f].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("w,h,nl", [(640, 480, 200), (1242, 375, 500), (752, 480, 0)])
+def test_line_extract(oracle, w, h, nl):
+    p = oracle.full_params(2000, nl)
+    ex = ola.Lineextractor(nl, 0.025)
+    for seed in (3, 4):
+        left, right = synth.stereo_pair(seed, w, h)
+        for img in (left, right):
+            gk, gd = ex(img)
+            _, scaled = oracle.lsd_detect(img, p.line)
+            assert np.array_equal(ex.debug_scaled(), scaled), "LSD working image"
+            o = oracle.line_extract(img, p.line)
+            _cmp_keylines(gk, o["kls"])
+            assert np.array_equal(gd, o["desc"])
+            o2 = oracle.line_extract(img, p.line, use_std_sort=True)   # the reference's std::sort gives the same top-N here
+            assert np.array_equal(o2["kls"], o["kls"])
+
+
+def test_lbd_on_given_keylines(oracle):
+    w, h = 640, 480
+    left, _ = synth.stereo_pair(9, w, h)
+    p = oracle.full_params(1000, 200)
+    o = oracle.line_extract(left, p.line)
+    ex = ola.Lineextractor(200, 0.025)
+    assert np.array_equal(ex.compute(left, o["kls"]), o["desc"])
+    assert ex.compute(left, o["kls"][:0]).shape == (0, 32)
+
+
+@pytest.mark.parametrize("w,h,nf,nl,fx,bf", [(640, 480, 1000, 200, 435.2047, 47.9064), (1242, 375, 2000, 500, 718.856, 386.1448)])
+def test_stereo_frames(oracle, w, h, nf, nl, fx, bf):
+    p = oracle.full_params(nf, nl, fx, bf)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=3)
+    imgs = synth.stereo_batch(31, 3, w, h)
+    f = fe.frames(imgs)
+    for i in range(3):
+        g = f.pair(i)
+        o = oracle.stereo_points(imgs[2 * i], imgs[2 * i + 1], p)
+        assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"])
+        assert np.array_equal(g["mvKeysRight"], o["kpsR"]) and np.array_equal(g["mDescriptorsRight"], o["descR"])
+        assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
+        assert np.array_equal(g["mvDepth"].view(np.uint32), o["depth"].view(np.uint32))
+        ol, orr = oracle.line_extract(imgs[2 * i], p.line), oracle.line_extract(imgs[2 * i + 1], p.line)
+        _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+        _cmp_keylines(g["mvKeysRight_Line"], orr["kls"])
+        assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        assert np.array_equal(g["line_matches_12"], m)
+        assert np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+        assert np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64))
+        assert (m >= 0).sum() > 20 and (disp[:, 0] >= 0).sum() > 10
