@@ -31,8 +31,12 @@ def test_line_extract(oracle, w, h, nl):
             o = oracle.line_extract(img, p.line)
             _cmp_keylines(gk, o["kls"])
             assert np.array_equal(gd, o["desc"])
-            o2 = oracle.line_extract(img, p.line, use_std_sort=True)   # the reference's std::sort gives the same top-N here
-            assert np.array_equal(o2["kls"], o["kls"])
+            # convention C.3: the reference's unstable std::sort may permute equal responses; it must at least keep
+            # the same multiset of responses (ties only), and agrees exactly when no response is repeated
+            o2 = oracle.line_extract(img, p.line, use_std_sort=True)
+            assert np.array_equal(np.sort(o2["kls"]["response"]), np.sort(o["kls"]["response"]))
+            if len(np.unique(o["all"]["response"])) == len(o["all"]):
+                assert np.array_equal(o2["kls"], o["kls"])
 
 
 def test_lbd_on_given_keylines(oracle):
