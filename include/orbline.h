@@ -36,6 +36,15 @@ int  olf_ctx_create(const olf_params* p, int width, int height, int max_images, 
 void olf_ctx_destroy(olf_ctx* ctx);
 int  olf_ctx_synchronize(olf_ctx* ctx);
 
+/* Stage timing with HIP events recorded on the stream each stage is launched on (the reference's only
+ * instrumentation is std::chrono around TrackStereo, Examples/PL/PL_stereo_kitti.cc:80-97).  Accumulates
+ * per-stage total milliseconds and call counts while enabled; read/reset synchronise the device. */
+int olf_profile_enable(olf_ctx* ctx, int on);
+int olf_profile_reset(olf_ctx* ctx);
+int olf_profile_stage_count(void);
+const char* olf_profile_stage_name(int stage);
+int olf_profile_read(olf_ctx* ctx, double* total_ms, int32_t* calls);   /* arrays of olf_profile_stage_count() */
+
 /* ---- ORBextractor (include/ORBextractor.h:52-118, src/ORBextractor.cc) -------------------- */
 /* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:68-91) + mnFeaturesPerLevel; arrays of nlevels */

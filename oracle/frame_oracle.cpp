@@ -11,6 +11,15 @@ void compute_stereo_matches(const std::vector<olf_keypoint>& keysL, const uint8_
                             const std::vector<float>& sf, const std::vector<float>& inv_sf, float mbf, float fx,
                             std::vector<float>& uRight, std::vector<float>& depth, std::vector<int>* sad_out);
 }
+namespace orc {
+struct Vec4f;
+void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort, std::vector<olf_keyline>& kls, std::vector<uint8_t>& desc,
+                  std::vector<olf_keyline>* all_detected);
+void stereo_lines(const std::vector<olf_keyline>& klL, const uint8_t* descL, const std::vector<olf_keyline>& klR, const uint8_t* descR,
+                  int img_w, int img_h, const olf_stereo_params& P, std::vector<int>& matches_12, std::vector<float>& disp,
+                  std::vector<double>& le);
+}
+#include <thread>
 using namespace orc;
 
 extern "C" {
@@ -38,6 +47,54 @@ int orc_stereo_points(const uint8_t* imgL, const uint8_t* imgR, int w, int h, co
     if (rl.kps.empty()) return OLF_OK;   // Frame ctor returns early (src/Frame.cc:176-177)
     compute_stereo_matches(rl.kps, rl.desc.data(), rr.kps, rr.desc.data(), rl.pyramid, rr.pyramid, sf, inv_sf, p->stereo.bf, p->stereo.fx, u, d, &s);
     for (int i = 0; i < *nL; ++i) { uRight[i] = u[i]; depth[i] = d[i]; if (sad) sad[i] = s[i]; }
+    return OLF_OK;
+}
+
+// The whole feature part of Frame::Frame (stereo + lines), src/Frame.cc:136-221.  threads = 4 runs the four
+// extractions on std::threads exactly like src/Frame.cc:164-171 (the cpu_baseline "reference-shaped" mode);
+// threads = 1 runs them back to back.  Any output pointer may be null.
+int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, const olf_params* p, int threads,
+                     olf_keypoint* kpsL, uint8_t* descL, int* nL, olf_keypoint* kpsR, uint8_t* descR, int* nR, int cap, float* uRight, float* depth,
+                     olf_keyline* klL, uint8_t* ldescL, int* nlL, olf_keyline* klR, uint8_t* ldescR, int* nlR, int lcap, int* lm12, float* ldisp,
+                     double* lle)
+{
+    Image L(w, h), R(w, h);
+    std::memcpy(L.d.data(), imgL, (size_t)w * h);
+    std::memcpy(R.d.data(), imgR, (size_t)w * h);
+    OrbResult rl, rr;
+    std::vector<olf_keyline> kl, kr;
+    std::vector<uint8_t> dl, dr;
+    auto f0 = [&] { orb_extract(L, p->orb, rl); };
+    auto f1 = [&] { orb_extract(R, p->orb, rr); };
+    auto f2 = [&] { line_extract(L, p->line, false, kl, dl, nullptr); };
+    auto f3 = [&] { line_extract(R, p->line, false, kr, dr, nullptr); };
+    if (threads >= 4) {
+        std::thread t0(f0), t1(f1), t2(f2), t3(f3);
+        t0.join(); t1.join(); t2.join(); t3.join();
+    } else { f0(); f1(); f2(); f3(); }
+    std::vector<float> sf, inv_sf, u, d;
+    orb_scale_tables(p->orb, sf, inv_sf);
+    if (!rl.kps.empty())
+        compute_stereo_matches(rl.kps, rl.desc.data(), rr.kps, rr.desc.data(), rl.pyramid, rr.pyramid, sf, inv_sf, p->stereo.bf, p->stereo.fx, u, d, nullptr);
+    std::vector<int> m;
+    std::vector<float> dsp;
+    std::vector<double> le;
+    stereo_lines(kl, dl.data(), kr, dr.data(), w, h, p->stereo, m, dsp, le);
+    if (nL) *nL = (int)rl.kps.size();
+    if (nR) *nR = (int)rr.kps.size();
+    if (nlL) *nlL = (int)kl.size();
+    if (nlR) *nlR = (int)kr.size();
+    if ((int)rl.kps.size() > cap || (int)rr.kps.size() > cap || (int)kl.size() > lcap || (int)kr.size() > lcap) return OLF_ERR_CAPACITY;
+    if (kpsL) std::memcpy(kpsL, rl.kps.data(), rl.kps.size() * sizeof(olf_keypoint));
+    if (descL) std::memcpy(descL, rl.desc.data(), rl.desc.size());
+    if (kpsR) std::memcpy(kpsR, rr.kps.data(), rr.kps.size() * sizeof(olf_keypoint));
+    if (descR) std::memcpy(descR, rr.desc.data(), rr.desc.size());
+    if (uRight) for (size_t i = 0; i < u.size(); ++i) { uRight[i] = u[i]; depth[i] = d[i]; }
+    if (klL) std::memcpy(klL, kl.data(), kl.size() * sizeof(olf_keyline));
+    if (ldescL) std::memcpy(ldescL, dl.data(), dl.size());
+    if (klR) std::memcpy(klR, kr.data(), kr.size() * sizeof(olf_keyline));
+    if (ldescR) std::memcpy(ldescR, dr.data(), dr.size());
+    if (lm12) for (size_t i = 0; i < m.size(); ++i) { lm12[i] = m[i]; ldisp[2 * i] = dsp[2 * i]; ldisp[2 * i + 1] = dsp[2 * i + 1]; lle[3 * i] = le[3 * i]; lle[3 * i + 1] = le[3 * i + 1]; lle[3 * i + 2] = le[3 * i + 2]; }
     return OLF_OK;
 }
 

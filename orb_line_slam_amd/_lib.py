@@ -99,6 +99,11 @@ def lib():
         L.olf_stereo_lines.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.olf_stereo_frames_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers), C.c_void_p]
         L.olf_stereo_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers)]
+        L.olf_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.olf_profile_reset.argtypes = [C.c_void_p]
+        L.olf_profile_stage_name.restype = C.c_char_p
+        L.olf_profile_stage_name.argtypes = [C.c_int]
+        L.olf_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -154,6 +159,18 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def profile(self, on=True):
+        check(lib().olf_profile_enable(self.handle, int(on)), "olf_profile_enable")
+        check(lib().olf_profile_reset(self.handle), "olf_profile_reset")
+
+    def profile_read(self):
+        """{stage: (total_ms, calls)} accumulated since profile(True)"""
+        n = lib().olf_profile_stage_count()
+        ms = np.zeros(n, np.float64)
+        calls = np.zeros(n, np.int32)
+        check(lib().olf_profile_read(self.handle, ptr(ms), ptr(calls)), "olf_profile_read")
+        return {lib().olf_profile_stage_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
 
     def synchronize(self):
         check(lib().olf_ctx_synchronize(self.handle), "olf_ctx_synchronize")

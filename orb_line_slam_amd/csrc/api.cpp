@@ -44,6 +44,13 @@ struct olf_ctx {
     double* d_lle = nullptr;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
+    bool prof_on = false;
+    struct ProfRec { int stage; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[16] = {0};
+    int prof_calls[16] = {0};
     // grow-on-demand scratch (matcher k-NN tables, host-pointer staging)
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
@@ -61,6 +68,24 @@ static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
     *out = c->scratch[slot];
     return OLF_OK;
 }
+
+enum { ST_ORB_PYRAMID, ST_ORB_FAST, ST_ORB_OCTREE, ST_ORB_BLUR, ST_ORB_DESCRIBE, ST_STEREO_POINTS, ST_LSD_FRONT, ST_LSD_GROW, ST_LINE_LBD,
+       ST_STEREO_LINES, ST_MATCH_BF, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"orb_pyramid", "orb_fast_cells", "orb_octree", "orb_blur", "orb_describe", "stereo_points",
+                                            "lsd_front", "lsd_grow", "line_select_lbd", "stereo_lines", "match_bf"};
+
+static hipEvent_t prof_event(olf_ctx* c)
+{
+    if (!c->prof_pool.empty()) { hipEvent_t e = c->prof_pool.back(); c->prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct StageScope {
+    olf_ctx* c; hipStream_t s; int stage; hipEvent_t a = nullptr;
+    StageScope(olf_ctx* c_, hipStream_t s_, int st) : c(c_), s(s_), stage(st) { if (c->prof_on) { a = prof_event(c); (void)hipEventRecord(a, s); } }
+    ~StageScope() { if (a) { hipEvent_t b = prof_event(c); (void)hipEventRecord(b, s); c->prof_recs.push_back({stage, a, b}); } }
+};
 
 template <typename T>
 static int dev_alloc(olf_ctx* c, T** p, size_t n)
@@ -108,6 +133,8 @@ void olf_ctx_destroy(olf_ctx* c)
     if (!c) return;
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
+    for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->lb.sortTemp) (void)hipFree(c->lb.sortTemp);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -189,6 +216,46 @@ int olf_ctx_synchronize(olf_ctx* c)
 {
     if (!c) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream2));
+    return OLF_OK;
+}
+
+// ---- stage profiling: HIP events on the launching streams -------------------------------------
+int olf_profile_enable(olf_ctx* c, int on)
+{
+    if (!c) return OLF_ERR_INVALID;
+    c->prof_on = on != 0;
+    return OLF_OK;
+}
+
+static int prof_collect(olf_ctx* c)
+{
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& r : c->prof_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { c->prof_ms[r.stage] += ms; c->prof_calls[r.stage] += 1; }
+        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+    }
+    c->prof_recs.clear();
+    return OLF_OK;
+}
+
+int olf_profile_reset(olf_ctx* c)
+{
+    if (!c) return OLF_ERR_INVALID;
+    OLF_TRY(prof_collect(c));
+    for (int i = 0; i < 16; ++i) { c->prof_ms[i] = 0; c->prof_calls[i] = 0; }
+    return OLF_OK;
+}
+
+int olf_profile_stage_count(void) { return ST_COUNT; }
+const char* olf_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+int olf_profile_read(olf_ctx* c, double* total_ms, int32_t* calls)
+{
+    if (!c || !total_ms || !calls) return OLF_ERR_INVALID;
+    OLF_TRY(prof_collect(c));
+    for (int i = 0; i < ST_COUNT; ++i) { total_ms[i] = c->prof_ms[i]; calls[i] = c->prof_calls[i]; }
     return OLF_OK;
 }
 
@@ -223,11 +290,11 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const OrbGeom& g = c->orb.geom;
     c->last_n_images = n_images;
-    OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s));
-    OLF_TRY(launch_orb_fast(g, c->ob, n_images, s));
-    OLF_TRY(launch_orb_octree(g, c->ob, n_images, s));
-    OLF_TRY(launch_orb_blur(g, c->ob, n_images, s));
-    OLF_TRY(launch_orb_describe(g, c->ob, n_images, d_kps, d_desc, d_counts, g.outCap, s));
+    { StageScope t(c, s, ST_ORB_PYRAMID); OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s)); }
+    { StageScope t(c, s, ST_ORB_FAST); OLF_TRY(launch_orb_fast(g, c->ob, n_images, s)); }
+    { StageScope t(c, s, ST_ORB_OCTREE); OLF_TRY(launch_orb_octree(g, c->ob, n_images, s)); }
+    { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
+    { StageScope t(c, s, ST_ORB_DESCRIBE); OLF_TRY(launch_orb_describe(g, c->ob, n_images, d_kps, d_desc, d_counts, g.outCap, s)); }
     return OLF_OK;
 }
 
@@ -292,6 +359,7 @@ int olf_stereo_points_dev(olf_ctx* c, int n_pairs, const olf_keypoint* d_kps, co
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    StageScope t(c, s, ST_STEREO_POINTS);
     return launch_stereo_points(c->orb.geom, c->ob, n_pairs, d_kps, d_desc, d_counts, c->orb.geom.outCap, c->params.stereo.bf,
                                 c->params.stereo.fx, d_uright, d_depth, c->d_sad, s);
 }
@@ -324,6 +392,7 @@ int olf_match_bf_dev(olf_ctx* c, const uint8_t* dA, const int32_t* nA, int strid
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     void* ws = nullptr;
     OLF_TRY(scratch_get(c, 0, (size_t)3 * (strideA + strideB) * n_sets * sizeof(int), &ws));
+    StageScope t(c, s, ST_MATCH_BF);
     return launch_match_bf(dA, nA, strideA, a_step, dB, nB, strideB, b_step, n_sets, nnr, best_lr, (int*)ws, d_m12, s);
 }
 
@@ -391,8 +460,9 @@ int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_
     if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
     if (n_images == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    OLF_TRY(launch_lsd(c->line.geom, c->lb, d_images, c->W, n_images, s));
-    OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s));
+    { StageScope t(c, s, ST_LSD_FRONT); OLF_TRY(launch_lsd_front(c->line.geom, c->lb, d_images, c->W, n_images, s)); }
+    { StageScope t(c, s, ST_LSD_GROW); OLF_TRY(launch_lsd_grow(c->line.geom, c->lb, n_images, s)); }
+    { StageScope t(c, s, ST_LINE_LBD); OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s)); }
     return OLF_OK;
 }
 
@@ -447,6 +517,7 @@ int olf_stereo_lines_dev(olf_ctx* c, int n_pairs, const olf_keyline* d_kls, cons
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    StageScope t(c, s, ST_STEREO_LINES);
     return launch_stereo_lines(c->W, c->H, c->params.stereo, n_pairs, d_kls, d_ldesc, d_lcounts, c->line.geom.outCap, c->d_lprep, c->d_ldist,
                                c->d_lm21, d_m12, d_disp, d_le, s);
 }

@@ -404,7 +404,7 @@ size_t lsd_sort_temp_bytes(int total_keys, int n_segments)
     return bytes;
 }
 
-int launch_lsd(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
+int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
     OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, n_images * sizeof(int), s));
     OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, n_images * sizeof(int), s));
@@ -422,6 +422,11 @@ int launch_lsd(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in
     size_t tb = b.sortTempBytes;
     OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA, b.keysB, (unsigned)((size_t)n_images * g.Ps), (unsigned)n_images,
                                                       b.segBegin, b.segEnd, 0, 32, s));
+    return OLF_OK;
+}
+
+int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
+{
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.used, b.region, b.rawLines, b.rawCount,
                        b.status);
     OLF_HIP_CHECK(hipGetLastError());
