@@ -461,3 +461,14 @@ int orc_sobel3(const uint8_t* img, int w, int h, int16_t* dx, int16_t* dy)
 }
 
 }  // extern "C"
+
+extern "C" int orc_lsd_region_stats(const uint8_t* img, int w, int h, const olf_line_params* P, int* sizes, int cap)
+{
+    orc::Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t)w * h);
+    std::vector<orc::Vec4f> lines;
+    std::vector<int> rs;
+    orc::lsd_detect(im, *P, lines, nullptr, &rs);
+    for (int i = 0; i < std::min((int)rs.size(), cap); ++i) sizes[i] = rs[i];
+    return (int)rs.size();
+}

@@ -20,7 +20,11 @@ namespace olf {
 constexpr double kPI = 3.1415926535897932384626433832795;
 constexpr double kDegToRads = kPI / 180;
 constexpr double kM32PI = (3 * kPI) / 2, kM2PI = 2 * kPI;
-constexpr unsigned kNotDefGx = 0x8000u;
+// grad word: bits 0-10 gx, 11-21 gy (11-bit two's complement, |g| <= 510), bit 30 NOTDEF, bit 31 USED
+constexpr unsigned kNotDef = 0x40000000u, kUsed = 0x80000000u;
+__device__ __forceinline__ int unpack_gx(uint32_t p) { return ((int)(p << 21)) >> 21; }
+__device__ __forceinline__ int unpack_gy(uint32_t p) { return ((int)(p << 10)) >> 21; }
+__device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0x7ffu) | (((uint32_t)gy & 0x7ffu) << 11); }
 
 __device__ __forceinline__ int refl101(int p, int n)
 {
@@ -116,66 +120,88 @@ __global__ __launch_bounds__(256) void k_lsd_upsample(const uint8_t* __restrict_
     *reinterpret_cast<uint32_t*>(dst + (size_t)img * g.pitchS * g.Hs + (size_t)dy * g.pitchS + dx0) = out;
 }
 
-// ll_angle, first half: gradient pair per pixel + per-image max of gx^2+gy^2 over defined pixels
+// ll_angle, first half: gradient pair per pixel + per-image max of gx^2+gy^2 over defined pixels.
+// One block covers LG_CHUNK consecutive pixels of one image (a single atomic per block).
+constexpr int LG_CHUNK = 4096;
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
-                                                  const LineGeom* __restrict__ gp, int* __restrict__ maxN, int* __restrict__ keyCount,
-                                                  int* __restrict__ rawCount)
+                                                  const LineGeom* __restrict__ gp, int* __restrict__ maxN)
 {
+    __shared__ int s_max[4];
     const LineGeom& g = *gp;
     const int img = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
     int n = 0;
-    if (idx < g.Ps) {
-        const int y = idx / g.Ws, x = idx - y * g.Ws;
-        uint32_t packed = kNotDefGx;
-        if (x < g.Ws - 1 && y < g.Hs - 1) {
-            const uint8_t* r0 = scaled + (size_t)img * g.pitchS * g.Hs + (size_t)y * g.pitchS + x;
-            const uint8_t* r1 = r0 + g.pitchS;
-            const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
-            const int gx = DA + BC, gy = DA - BC;
-            n = gx * gx + gy * gy;
-            if (n >= g.nThr) packed = ((uint32_t)gx & 0xffffu) | ((uint32_t)gy << 16);
-            else n = 0;
+    const uint8_t* sc = scaled + (size_t)img * g.pitchS * g.Hs;
+#pragma unroll 4
+    for (int k = 0; k < LG_CHUNK / 256; ++k) {
+        const int idx = blockIdx.x * LG_CHUNK + k * 256 + threadIdx.x;
+        if (idx < g.Ps) {
+            const int y = idx / g.Ws, x = idx - y * g.Ws;
+            uint32_t packed = kNotDef;
+            if (x < g.Ws - 1 && y < g.Hs - 1) {
+                const uint8_t* r0 = sc + (size_t)y * g.pitchS + x;
+                const uint8_t* r1 = r0 + g.pitchS;
+                const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+                const int gx = DA + BC, gy = DA - BC;
+                const int nn = gx * gx + gy * gy;
+                if (nn >= g.nThr) { packed = pack_g(gx, gy); n = max(n, nn); }
+            }
+            grad[(size_t)img * g.Ps + idx] = packed;
         }
-        grad[(size_t)img * g.Ps + idx] = packed;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o));
-    if ((threadIdx.x & 63) == 0 && n > 0) atomicMax(&maxN[img], n);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (n > 0) atomicMax(&maxN[img * 32], n);   // counters padded to one per 128-byte line
+    }
 }
 
-// ll_angle, second half: bin of every defined pixel -> sort key
+// ll_angle, second half: bin of every defined pixel -> sort key (one atomic per block)
 __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, uint32_t* __restrict__ keys, int* __restrict__ keyCount)
 {
+    __shared__ uint32_t s_keys[LG_CHUNK];
+    __shared__ int s_cnt, s_base;
     const LineGeom& g = *gp;
     const int img = blockIdx.y, lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    bool def = false;
-    uint32_t key = 0;
-    if (idx < g.Ps) {
-        const uint32_t p = grad[(size_t)img * g.Ps + idx];
-        if ((p & 0xffffu) != kNotDefGx) {
-            const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
-            const double max_grad = sqrt((double)maxN[img] / 4.0);
-            const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
-            const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
-            const int bin = (int)(norm * bin_coef);
-            key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
-            def = true;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
+    const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
+#pragma unroll 4
+    for (int k = 0; k < LG_CHUNK / 256; ++k) {
+        const int idx = blockIdx.x * LG_CHUNK + k * 256 + threadIdx.x;
+        bool def = false;
+        uint32_t key = 0;
+        if (idx < g.Ps) {
+            const uint32_t p = grad[(size_t)img * g.Ps + idx];
+            if (!(p & kNotDef)) {
+                const int gx = unpack_gx(p), gy = unpack_gy(p);
+                const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const int bin = (int)(norm * bin_coef);
+                key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+                def = true;
+            }
         }
+        const unsigned long long m = __ballot(def);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, __popcll(m));
+        base = __shfl(base, 0);
+        if (def) s_keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
     }
-    const unsigned long long m = __ballot(def);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(&keyCount[img], __popcll(m));
-    base = __shfl(base, 0);
-    if (def) keys[(size_t)img * g.Ps + base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&keyCount[img * 32], s_cnt) : 0;
+    __syncthreads();
+    const int cnt = s_cnt, base = s_base;
+    for (int i = threadIdx.x; i < cnt; i += 256) keys[(size_t)img * g.Ps + base + i] = s_keys[i];
 }
 
 __global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, unsigned* __restrict__ b, unsigned* __restrict__ e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { b[i] = (unsigned)i * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i]; }
+    if (i < n) { b[i] = (unsigned)i * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i * 32]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -199,87 +225,114 @@ __device__ __forceinline__ bool is_aligned(double a, double theta, double prec)
     return n_theta <= prec;
 }
 
-__global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
-                                                 const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
-                                                 uint8_t* __restrict__ usedAll, uint32_t* __restrict__ regionAll,
-                                                 olf_keyline* __restrict__ rawLines, int* __restrict__ rawCount, int* __restrict__ status)
+constexpr int RING = 1024;   // FIFO window of the growing region kept in LDS
+constexpr int PEND = 2048;   // hash table of pixels whose USED store may not be visible to a load yet
+
+__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double rlane_d(double v, int l)
 {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// One wave replays cv::LineSegmentDetector's seed loop for one image.  Visibility of the wave's own stores:
+// FIFO entries are read back from an LDS ring, and a pixel whose USED bit was just stored is also entered in
+// an LDS hash table that every `used` test consults, so no memory fence is needed per step; a fence is only
+// issued when a table slot is about to be reused by a different pixel (and before region2rect).
+__global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
+                                                 const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
+                                                 uint32_t* __restrict__ regionAll, olf_keyline* __restrict__ rawLines,
+                                                 int* __restrict__ rawCount, int* __restrict__ status)
+{
+    __shared__ uint32_t s_ring[RING];
+    __shared__ int s_pend[PEND];
     __shared__ int s_x[64], s_y[64];
     __shared__ double s_w[64];
     const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     const int Ws = g.Ws, Hs = g.Hs;
-    const uint32_t* grad = gradAll + (size_t)img * g.Ps;
+    uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
-    uint8_t* used = usedAll + (size_t)img * g.Ps;
     uint32_t* reg = regionAll + (size_t)img * g.Ps;
     olf_keyline* out = rawLines + (size_t)img * g.maxDetect;
-    const int nkeys = keyCount[img];
+    const int nkeys = keyCount[img * 32];
     const double prec = g.prec;
+    for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
+    __syncthreads();
     int nl = 0;
+
+#define PEND_FLUSH() do { __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __syncthreads(); } while (0)
+// wave-uniform: set the USED bit of pixel A (its current word is W)
+#define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
+                             if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __syncthreads(); } while (0)
+
     for (int base = 0; base < nkeys; base += 64) {
         const bool valid = base + lane < nkeys;
         const int addr = valid ? (int)(keys[base + lane] & 0x3fffffu) : 0;
-        unsigned long long mask = __ballot(valid && used[addr] == 0);
+        unsigned long long mask = __ballot(valid && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
         while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            const int seed = __shfl(addr, l);
+            const int l = __builtin_ctzll(mask);
+            const int seed = rlane(addr, l);
             // ---- region_grow ------------------------------------------------------------------
             int n = 1;
-            double reg_angle;
-            float sumdx, sumdy;
-            {
-                const uint32_t p = grad[seed];
-                reg_angle = grad_angle((int)(int16_t)(p & 0xffffu), (int)(int16_t)(p >> 16));
-                double s, c;
-                sincos(reg_angle, &s, &c);
-                sumdx = (float)c; sumdy = (float)s;
-                if (lane == 0) { used[seed] = 1; reg[0] = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); }
-            }
-            __threadfence_block();
+            const uint32_t pseed = grad[seed];
+            double reg_angle = d_mul((double)dev_fastAtan2((float)unpack_gx(pseed), (float)(-unpack_gy(pseed))), kDegToRads);
+            float sumdx = 0.f, sumdy = 0.f;
+            bool have_sum = false;
+            MARK_USED(seed, pseed);
+            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[0] = pk; }
+            __syncthreads();
             int i = 0;
             while (i < n) {
                 const int nb = min(7, n - i);
                 const int e = lane / 9, k = lane - 9 * e;
+                if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
                 bool cand = false;
-                int a = -1, xx = 0, yy = 0;
+                int a = -1, xy = 0;
+                uint32_t pw = 0;
                 double ang = 0, cs = 0, sn = 0;
                 if (lane < 63 && e < nb && k != 4) {
-                    const uint32_t rp = reg[i + e];
-                    xx = (int)(rp & 0xffffu) + (k % 3) - 1;
-                    yy = (int)(rp >> 16) + (k / 3) - 1;
+                    const uint32_t rp = (n - i > RING) ? reg[i + e] : s_ring[(i + e) & (RING - 1)];
+                    const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                     if (xx >= 0 && yy >= 0 && xx < Ws && yy < Hs) {
                         a = yy * Ws + xx;
-                        const uint32_t p = grad[a];
-                        if (used[a] == 0 && (p & 0xffffu) != kNotDefGx) {
+                        pw = grad[a];
+                        if (!(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a) {
                             cand = true;
-                            ang = grad_angle((int)(int16_t)(p & 0xffffu), (int)(int16_t)(p >> 16));
+                            xy = xx | (yy << 16);
+                            ang = d_mul((double)dev_fastAtan2((float)unpack_gx(pw), (float)(-unpack_gy(pw))), kDegToRads);
                             sincos((double)(float)ang, &sn, &cs);
                         }
                     }
                 }
                 unsigned long long cm = __ballot(cand);
                 while (cm) {
-                    const int c = __ffsll((long long)cm) - 1;
+                    const int c = __builtin_ctzll(cm);
                     cm &= cm - 1;
-                    if (!__shfl((int)cand, c)) continue;       // taken earlier in this batch
-                    const double ang_c = shfl_d(ang, c);
+                    const double ang_c = rlane_d(ang, c);
                     if (is_aligned(ang_c, reg_angle, prec)) {
-                        const int a_c = __shfl(a, c);
-                        const int x_c = __shfl(xx, c), y_c = __shfl(yy, c);
-                        const double cs_c = shfl_d(cs, c), sn_c = shfl_d(sn, c);
-                        if (lane == 0) { used[a_c] = 1; reg[n] = (uint32_t)x_c | ((uint32_t)y_c << 16); }
+                        const int a_c = rlane(a, c);
+                        const uint32_t xy_c = (uint32_t)rlane(xy, c), pw_c = (uint32_t)rlane((int)pw, c);
+                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
+                        if (!have_sum) {
+                            double s0, c0;
+                            sincos(reg_angle, &s0, &c0);
+                            sumdx = (float)c0; sumdy = (float)s0;
+                            have_sum = true;
+                        }
+                        MARK_USED(a_c, pw_c);
+                        if (lane == 0) { s_ring[n & (RING - 1)] = xy_c; reg[n] = xy_c; }
                         ++n;
                         sumdx = (float)d_add((double)sumdx, cs_c);
                         sumdy = (float)d_add((double)sumdy, sn_c);
                         reg_angle = d_mul((double)dev_fastAtan2(sumdy, sumdx), kDegToRads);
-                        if (a == a_c) cand = false;
+                        cm &= ~__ballot(a == a_c);   // the same pixel seen through another FIFO entry of this batch
                     }
                 }
                 i += nb;
-                __threadfence_block();
+                __syncthreads();
             }
             if (n >= g.minRegSize) {
+                __threadfence_block();   // region2rect reads the FIFO back from memory
                 // ---- region2rect: sums follow the region (growth) order exactly --------------------
                 double x = 0, y = 0, sum = 0;
                 for (int cb = 0; cb < n; cb += 64) {
@@ -288,7 +341,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                         const uint32_t rp = reg[cb + lane];
                         const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
                         const uint32_t p = grad[py * Ws + px];
-                        const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
+                        const int gx = unpack_gx(p), gy = unpack_gy(p);
                         s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
                     }
                     __syncthreads();
@@ -308,7 +361,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                         const uint32_t rp = reg[cb + lane];
                         const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
                         const uint32_t p = grad[py * Ws + px];
-                        const int gx = (int)(int16_t)(p & 0xffffu), gy = (int)(int16_t)(p >> 16);
+                        const int gx = unpack_gx(p), gy = unpack_gy(p);
                         s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
                     }
                     __syncthreads();
@@ -389,9 +442,11 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
             }
             // seeds later in this 64-key window may have been consumed by the region just grown
             if (n == 1) mask &= mask - 1;
-            else mask = __ballot(valid && lane > l && used[addr] == 0);
+            else mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
         }
     }
+#undef MARK_USED
+#undef PEND_FLUSH
     if (lane == 0) rawCount[img] = nl;
 }
 
@@ -406,17 +461,16 @@ size_t lsd_sort_temp_bytes(int total_keys, int n_segments)
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
-    OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, n_images * sizeof(int), s));
-    OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, n_images * sizeof(int), s));
-    OLF_HIP_CHECK(hipMemsetAsync(b.used, 0, (size_t)n_images * g.Ps, s));
+    OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, (size_t)n_images * 32 * sizeof(int), s));
+    OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));
     hipLaunchKernelGGL(k_gauss7_img, dim3((g.W + GT_W - 1) / GT_W, (g.H + GT_H - 1) / GT_H, n_images), dim3(256), 0, s, d_in, in_pitch,
                        (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 0);
     {
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }
-    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.keyCount, b.rawCount);
-    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount);
+    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN);
+    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
     size_t tb = b.sortTempBytes;
@@ -427,8 +481,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.used, b.region, b.rawLines, b.rawCount,
-                       b.status);
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, b.rawLines, b.rawCount, b.status);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
