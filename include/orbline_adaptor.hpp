@@ -1,0 +1,210 @@
+// orbline_adaptor.hpp -- header-only C++ adaptor that re-creates the reference's class surfaces on top of the
+// C ABI (include/orbline.h), so that Frame.cc / Tracking.cc of ORB_Line_SLAM compile against it unchanged:
+//   ORB_SLAM2::ORBextractor   include/ORBextractor.h:52-118
+//   ORB_SLAM2::Lineextractor  include/LineExtractor.h:40-72
+//   ORB_SLAM2::ORBmatcher::DescriptorDistance, ORB_SLAM2::match / matchNNR / distance  (include/ORBmatcher.h,
+//   include/LineMatcher.h:57-69)
+// With OpenCV present define ORBLINE_WITH_OPENCV before including: the classes then take/return cv::Mat,
+// cv::KeyPoint and cv::line_descriptor::KeyLine exactly like the reference (olf_keypoint / olf_keyline are
+// layout-identical, so the conversion is a memcpy).  Without it (this repository's own build and tests, which
+// have no OpenCV) the same classes work on the POD records.
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "orbline.h"
+
+#ifdef ORBLINE_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>
+#include <line_descriptor_custom.hpp>
+static_assert(sizeof(cv::KeyPoint) == sizeof(olf_keypoint), "cv::KeyPoint layout");
+static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(olf_keyline), "KeyLine layout");
+#endif
+
+namespace ORB_SLAM2 {
+
+namespace olf_detail {
+inline void check(int rc, const char* where)
+{
+    if (rc != OLF_OK) throw std::runtime_error(std::string(where) + ": " + olf_last_error());
+}
+// one context per (object, image size); created lazily like the reference's lazily sized cv::Mat buffers
+struct Ctx {
+    olf_ctx* h = nullptr;
+    olf_params p;
+    int w = 0, hgt = 0;
+    Ctx() { olf_default_params(&p); }
+    ~Ctx() { if (h) olf_ctx_destroy(h); }
+    olf_ctx* get(int width, int height)
+    {
+        if (!h || w != width || hgt != height) {
+            if (h) olf_ctx_destroy(h);
+            h = nullptr;
+            check(olf_ctx_create(&p, width, height, 2, &h), "olf_ctx_create");
+            w = width; hgt = height;
+        }
+        return h;
+    }
+    Ctx(const Ctx&) = delete;
+    Ctx& operator=(const Ctx&) = delete;
+};
+}  // namespace olf_detail
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+    {
+        c.p.orb.nfeatures = nfeatures; c.p.orb.scale_factor = scaleFactor; c.p.orb.nlevels = nlevels;
+        c.p.orb.ini_th_fast = iniThFAST; c.p.orb.min_th_fast = minThFAST;
+        scale_.assign(nlevels, 1.f); inv_.assign(nlevels, 1.f); s2_.assign(nlevels, 1.f); is2_.assign(nlevels, 1.f);
+    }
+    // POD form: image w x h, row stride = w.  Mask is ignored, as in the reference.
+    void operator()(const uint8_t* image, int w, int h, std::vector<olf_keypoint>& keypoints, std::vector<uint8_t>& descriptors)
+    {
+        keypoints.clear(); descriptors.clear();
+        if (!image || w <= 0 || h <= 0) return;   // src/ORBextractor.cc:1048-1049
+        olf_ctx* x = c.get(w, h);
+        const int cap = olf_orb_capacity(x);
+        keypoints.resize(cap); descriptors.resize((size_t)cap * OLF_DESC_BYTES);
+        int32_t n = 0;
+        olf_detail::check(olf_orb_extract(x, image, 1, keypoints.data(), descriptors.data(), &n), "olf_orb_extract");
+        keypoints.resize(n); descriptors.resize((size_t)n * OLF_DESC_BYTES);
+        olf_orb_scale_tables(x, scale_.data(), inv_.data(), s2_.data(), is2_.data(), nullptr);
+    }
+#ifdef ORBLINE_WITH_OPENCV
+    void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray _descriptors)
+    {
+        if (_image.empty()) return;
+        cv::Mat image = _image.getMat();
+        CV_Assert(image.type() == CV_8UC1);
+        cv::Mat cont = image.isContinuous() ? image : image.clone();
+        std::vector<olf_keypoint> k; std::vector<uint8_t> d;
+        (*this)(cont.data, cont.cols, cont.rows, k, d);
+        keypoints.resize(k.size());
+        if (!k.empty()) std::memcpy(keypoints.data(), k.data(), k.size() * sizeof(olf_keypoint));
+        if (k.empty()) _descriptors.release();
+        else { _descriptors.create((int)k.size(), 32, CV_8U); std::memcpy(_descriptors.getMat().data, d.data(), d.size()); }
+        mvImagePyramid.resize(GetLevels());
+        std::vector<int32_t> lw(GetLevels()), lh(GetLevels());
+        olf_orb_level_sizes(c.h, lw.data(), lh.data());
+        for (int l = 0; l < GetLevels(); ++l) {   // the reference exposes the pyramid as a public member (src/Frame.cc:799-816 reads it)
+            mvImagePyramid[l].create(lh[l], lw[l], CV_8U);
+            olf_orb_pyramid_level(c.h, 0, l, 0, mvImagePyramid[l].data);
+        }
+    }
+    std::vector<cv::Mat> mvImagePyramid;
+#endif
+    int GetLevels() { return c.p.orb.nlevels; }
+    float GetScaleFactor() { return c.p.orb.scale_factor; }
+    std::vector<float> GetScaleFactors() { ensure(); return scale_; }
+    std::vector<float> GetInverseScaleFactors() { ensure(); return inv_; }
+    std::vector<float> GetScaleSigmaSquares() { ensure(); return s2_; }
+    std::vector<float> GetInverseScaleSigmaSquares() { ensure(); return is2_; }
+    // mvImagePyramid[level] of the last call (w*h bytes)
+    std::vector<uint8_t> PyramidLevel(int level, int* w = nullptr, int* h = nullptr)
+    {
+        std::vector<int32_t> lw(GetLevels()), lh(GetLevels());
+        olf_detail::check(olf_orb_level_sizes(c.h, lw.data(), lh.data()), "olf_orb_level_sizes");
+        std::vector<uint8_t> out((size_t)lw[level] * lh[level]);
+        olf_detail::check(olf_orb_pyramid_level(c.h, 0, level, 0, out.data()), "olf_orb_pyramid_level");
+        if (w) *w = lw[level];
+        if (h) *h = lh[level];
+        return out;
+    }
+    olf_ctx* context(int w, int h) { return c.get(w, h); }
+
+private:
+    void ensure()
+    {   // the scale chain does not depend on the image size; any context computes it
+        olf_ctx* x = c.h ? c.h : c.get(640, 480);
+        olf_orb_scale_tables(x, scale_.data(), inv_.data(), s2_.data(), is2_.data(), nullptr);
+    }
+    olf_detail::Ctx c;
+    std::vector<float> scale_, inv_, s2_, is2_;
+};
+
+class Lineextractor {
+public:
+    Lineextractor(int lsd_nfeatures, double llength_th, bool bFLD_ = false) : bFLD(bFLD_)
+    {
+        c.p.line.lsd_nfeatures = lsd_nfeatures; c.p.line.min_line_length = llength_th;
+    }
+    Lineextractor(int lsd_nfeatures, double llength_th, int lsd_refine, double lsd_scale, double lsd_sigma_scale, double lsd_quant,
+                  double lsd_ang_th, double lsd_log_eps, double lsd_density_th, int lsd_n_bins, bool bFLD_ = false)
+        : bFLD(bFLD_)
+    {
+        olf_line_params& l = c.p.line;
+        l.lsd_nfeatures = lsd_nfeatures; l.min_line_length = llength_th; l.lsd_refine = lsd_refine; l.lsd_scale = lsd_scale;
+        l.lsd_sigma_scale = lsd_sigma_scale; l.lsd_quant = lsd_quant; l.lsd_ang_th = lsd_ang_th; l.lsd_log_eps = lsd_log_eps;
+        l.lsd_density_th = lsd_density_th; l.lsd_n_bins = lsd_n_bins;
+    }
+    void operator()(const uint8_t* image, int w, int h, std::vector<olf_keyline>& keylines, std::vector<uint8_t>& descriptors)
+    {
+        keylines.clear(); descriptors.clear();
+        if (bFLD || !image) return;                // src/LineExtractor.cc:68
+        olf_ctx* x = c.get(w, h);
+        const int cap = olf_line_capacity(x);
+        keylines.resize(cap); descriptors.resize((size_t)cap * OLF_DESC_BYTES);
+        int32_t n = 0;
+        olf_detail::check(olf_line_extract(x, image, 1, keylines.data(), descriptors.data(), &n), "olf_line_extract");
+        keylines.resize(n); descriptors.resize((size_t)n * OLF_DESC_BYTES);
+    }
+#ifdef ORBLINE_WITH_OPENCV
+    void operator()(const cv::Mat& image, const cv::Mat& /*mask*/, std::vector<cv::line_descriptor::KeyLine>& keylines, cv::Mat& descriptors_line)
+    {
+        if (image.depth() != 0) throw std::runtime_error("Error, depth image!= 0");   // LSDDetector_custom.cpp:236-237
+        cv::Mat cont = image.isContinuous() ? image : image.clone();
+        std::vector<olf_keyline> k; std::vector<uint8_t> d;
+        (*this)(cont.data, cont.cols, cont.rows, k, d);
+        keylines.resize(k.size());
+        if (!k.empty()) std::memcpy((void*)keylines.data(), k.data(), k.size() * sizeof(olf_keyline));
+        descriptors_line = cv::Mat((int)k.size(), 32, CV_8UC1);
+        if (!k.empty()) std::memcpy(descriptors_line.data, d.data(), d.size());
+    }
+#endif
+private:
+    olf_detail::Ctx c;
+    bool bFLD;
+};
+
+// ---- matchers ---------------------------------------------------------------------------------------------------
+// int distance(const cv::Mat&, const cv::Mat&) / ORBmatcher::DescriptorDistance: the scalar op stays inline on the host,
+// exactly like the reference's bit hack (src/ORBmatcher.cc:1795-1811); the batched searches go through the C ABI.
+inline int distance(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint64_t x, y;
+        std::memcpy(&x, a + 8 * i, 8); std::memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+class ORBmatcher {
+public:
+    static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:39-41
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return distance(a, b); }
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
+// int match(desc1, desc2, nnr, matches_12) with Config::bestLRMatches() passed explicitly (src/LineMatcher.cpp:104-132)
+inline int match(olf_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr, bool bestLRMatches, std::vector<int>& matches_12)
+{
+    matches_12.assign(n1, -1);
+    olf_detail::check(olf_match_bf(ctx, desc1, n1, desc2, n2, nnr, bestLRMatches ? 1 : 0, matches_12.data()), "olf_match_bf");
+    int m = 0;
+    for (int v : matches_12) m += v >= 0;
+    return m;
+}
+inline int matchNNR(olf_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, float nnr, std::vector<int>& matches_12)
+{
+    return match(ctx, desc1, n1, desc2, n2, nnr, false, matches_12);
+}
+
+}  // namespace ORB_SLAM2
