@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liborbline_hip.so")
+LIB_PATH = os.environ.get("OLF_LIB_PATH", os.path.join(_HERE, "csrc", "liborbline_hip.so"))
 SYNTH_PATH = os.path.join(_HERE, "csrc", "libolf_synth.so")
 
 OLF_OK, OLF_ERR_INVALID, OLF_ERR_CAPACITY, OLF_ERR_HIP, OLF_ERR_NODEVICE = 0, -1, -2, -3, -4

@@ -232,7 +232,7 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
     hipLaunchKernelGGL(k_line_select, dim3(n_images), dim3(256), sortN * sizeof(unsigned long long), s, b.geom, b.rawLines, b.rawCount, d_kls,
                        d_counts);
     // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel)
-    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 1, n_images, s));
+    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
     hipLaunchKernelGGL(k_sobel3, dim3((g.W * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
                        reinterpret_cast<float4*>(b.rowSums));
@@ -246,7 +246,7 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
 int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
                     uint8_t* d_desc, const int* d_counts, hipStream_t s)
 {
-    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 1, n_images, s));
+    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
     hipLaunchKernelGGL(k_sobel3, dim3((g.W * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
                        reinterpret_cast<float4*>(b.rowSums));

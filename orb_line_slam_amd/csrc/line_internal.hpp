@@ -74,7 +74,7 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
 int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
                     uint8_t* d_desc, const int* d_counts, hipStream_t s);
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
-                      const LineGeom* d_geom, int which, int n_images, hipStream_t s);
+                      const LineGeom& g, int which, int n_images, hipStream_t s);
 size_t lsd_sort_temp_bytes(int total_keys, int n_segments);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);

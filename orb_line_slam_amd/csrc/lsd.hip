@@ -79,12 +79,9 @@ __global__ __launch_bounds__(256) void k_gauss7_img(const uint8_t* __restrict__ 
 }
 
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
-                      const LineGeom* d_geom, int which, int n_images, hipStream_t s)
+                      const LineGeom& g, int which, int n_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gauss7_img, dim3((W + GT_W - 1) / GT_W, (H + GT_H - 1) / GT_H, n_images), dim3(256), 0, s, src, srcPitch, srcStride, dst,
-                       dstPitch, dstStride, W, H, d_geom, which);
-    OLF_HIP_CHECK(hipGetLastError());
-    return OLF_OK;
+    return launch_sep7(src, srcStride, srcPitch, dst, dstStride, dstPitch, W, H, which ? g.lbdTaps : g.lsdTaps, n_images, s);
 }
 
 // x1.2 bilinear upsample (cv::resize INTER_LINEAR, App. A.2)
@@ -234,6 +231,8 @@ __device__ __forceinline__ double rlane_d(double v, int l)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// (single-wave workgroup: LDS operations of one wave execute in order, so __builtin_amdgcn_wave_barrier() -- a
+// compiler-only barrier -- is enough between a lane-0 LDS write and the other lanes' reads; no s_barrier / vmcnt wait)
 // One wave replays cv::LineSegmentDetector's seed loop for one image.  Visibility of the wave's own stores:
 // FIFO entries are read back from an LDS ring, and a pixel whose USED bit was just stored is also entered in
 // an LDS hash table that every `used` test consults, so no memory fence is needed per step; a fence is only
@@ -257,13 +256,13 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec;
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     int nl = 0;
 
-#define PEND_FLUSH() do { __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __syncthreads(); } while (0)
+#define PEND_FLUSH() do { __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
 #define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
-                             if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __syncthreads(); } while (0)
+                             if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __builtin_amdgcn_wave_barrier(); } while (0)
 
     for (int base = 0; base < nkeys; base += 64) {
         const bool valid = base + lane < nkeys;
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
             bool have_sum = false;
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[0] = pk; }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             int i = 0;
             while (i < n) {
                 const int nb = min(7, n - i);
@@ -329,50 +328,49 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                     }
                 }
                 i += nb;
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
             if (n >= g.minRegSize) {
                 __threadfence_block();   // region2rect reads the FIFO back from memory
-                // ---- region2rect: sums follow the region (growth) order exactly --------------------
+                // ---- region2rect: the products are formed 64 at a time (one per lane), the additions are replayed
+                // in the region's growth order through v_readlane, so every partial sum equals the reference's
                 double x = 0, y = 0, sum = 0;
                 for (int cb = 0; cb < n; cb += 64) {
                     const int cnt = min(64, n - cb);
+                    double wt = 0, xw = 0, yw = 0;
                     if (lane < cnt) {
                         const uint32_t rp = reg[cb + lane];
                         const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
                         const uint32_t p = grad[py * Ws + px];
                         const int gx = unpack_gx(p), gy = unpack_gy(p);
-                        s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                        wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                        xw = d_mul((double)px, wt); yw = d_mul((double)py, wt);
                     }
-                    __syncthreads();
                     for (int q = 0; q < cnt; ++q) {
-                        const double w = s_w[q];
-                        x = d_add(x, d_mul((double)s_x[q], w));
-                        y = d_add(y, d_mul((double)s_y[q], w));
-                        sum = d_add(sum, w);
+                        x = d_add(x, rlane_d(xw, q));
+                        y = d_add(y, rlane_d(yw, q));
+                        sum = d_add(sum, rlane_d(wt, q));
                     }
-                    __syncthreads();
                 }
                 x = x / sum; y = y / sum;
                 double Ixx = 0, Iyy = 0, Ixy = 0;
                 for (int cb = 0; cb < n; cb += 64) {
                     const int cnt = min(64, n - cb);
+                    double t1 = 0, t2 = 0, t3 = 0;
                     if (lane < cnt) {
                         const uint32_t rp = reg[cb + lane];
                         const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
                         const uint32_t p = grad[py * Ws + px];
                         const int gx = unpack_gx(p), gy = unpack_gy(p);
-                        s_x[lane] = px; s_y[lane] = py; s_w[lane] = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                        const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                        const double ex = d_sub((double)px, x), ey = d_sub((double)py, y);
+                        t1 = d_mul(d_mul(ey, ey), wt); t2 = d_mul(d_mul(ex, ex), wt); t3 = d_mul(d_mul(ex, ey), wt);
                     }
-                    __syncthreads();
                     for (int q = 0; q < cnt; ++q) {
-                        const double w = s_w[q];
-                        const double ddx = d_sub((double)s_x[q], x), ddy = d_sub((double)s_y[q], y);
-                        Ixx = d_add(Ixx, d_mul(d_mul(ddy, ddy), w));
-                        Iyy = d_add(Iyy, d_mul(d_mul(ddx, ddx), w));
-                        Ixy = d_sub(Ixy, d_mul(d_mul(ddx, ddy), w));
+                        Ixx = d_add(Ixx, rlane_d(t1, q));
+                        Iyy = d_add(Iyy, rlane_d(t2, q));
+                        Ixy = d_sub(Ixy, rlane_d(t3, q));
                     }
-                    __syncthreads();
                 }
                 const double dI = d_sub(Ixx, Iyy);
                 const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
@@ -387,21 +385,21 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                 }
                 double ddx, ddy;
                 sincos(theta, &ddy, &ddx);
+                // extent along the axis: "if (l > l_max) .. else if (l < l_min) .." from (0, 0) is max(0, max l) / min(0, min l),
+                // which does not depend on the order
                 double l_min = 0, l_max = 0;
                 for (int cb = 0; cb < n; cb += 64) {
-                    const int cnt = min(64, n - cb);
-                    if (lane < cnt) {
+                    if (cb + lane < n) {
                         const uint32_t rp = reg[cb + lane];
-                        s_x[lane] = (int)(rp & 0xffffu); s_y[lane] = (int)(rp >> 16);
-                    }
-                    __syncthreads();
-                    for (int q = 0; q < cnt; ++q) {
-                        const double rdx = d_sub((double)s_x[q], x), rdy = d_sub((double)s_y[q], y);
+                        const double rdx = d_sub((double)(int)(rp & 0xffffu), x), rdy = d_sub((double)(int)(rp >> 16), y);
                         const double lq = d_add(d_mul(rdx, ddx), d_mul(rdy, ddy));
-                        if (lq > l_max) l_max = lq;
-                        else if (lq < l_min) l_min = lq;
+                        l_max = fmax(l_max, lq); l_min = fmin(l_min, lq);
                     }
-                    __syncthreads();
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    l_max = fmax(l_max, __hiloint2double(__shfl_xor(__double2hiint(l_max), o), __shfl_xor(__double2loint(l_max), o)));
+                    l_min = fmin(l_min, __hiloint2double(__shfl_xor(__double2hiint(l_min), o), __shfl_xor(__double2loint(l_min), o)));
                 }
                 double x1 = d_add(x, d_mul(l_min, ddx)), y1 = d_add(y, d_mul(l_min, ddy));
                 double x2 = d_add(x, d_mul(l_max, ddx)), y2 = d_add(y, d_mul(l_max, ddy));
@@ -463,8 +461,8 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 {
     OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, (size_t)n_images * 32 * sizeof(int), s));
     OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));
-    hipLaunchKernelGGL(k_gauss7_img, dim3((g.W + GT_W - 1) / GT_W, (g.H + GT_H - 1) / GT_H, n_images), dim3(256), 0, s, d_in, in_pitch,
-                       (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, b.geom, 0);
+    { int rc = launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 0, n_images, s);
+      if (rc != OLF_OK) return rc; }
     {
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);

@@ -116,6 +116,11 @@ int launch_orb_blur(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipS
 int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
                         int* d_counts, int out_cap, hipStream_t s);
 
+// filters.hip
+struct Taps7 { int t[7]; };
+int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
+                const int* taps7, int n_images, hipStream_t s);
+
 // match.hip
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
                          const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, hipStream_t s);

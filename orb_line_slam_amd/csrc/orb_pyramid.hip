@@ -299,10 +299,10 @@ int launch_orb_blur(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipS
 {
     for (int l = 0; l < g.nlevels; ++l) {
         const LevelGeom& L = g.lv[l];
-        hipLaunchKernelGGL(k_blur7, dim3((L.w + BT_W - 1) / BT_W, (L.h + BT_H - 1) / BT_H, n_images), dim3(256), 0, s, b.pyr,
-                           b.blur, b.geom, l);
+        int rc = launch_sep7(b.pyr + L.offset, (size_t)g.pyrBytes, L.pitch, b.blur + L.offset, (size_t)g.pyrBytes, L.pitch, L.w, L.h, g.blurTaps,
+                             n_images, s);
+        if (rc != OLF_OK) return rc;
     }
-    OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
 
