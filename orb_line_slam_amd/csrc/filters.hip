@@ -6,6 +6,7 @@
 // HBM-bound: each block reads a (128+8) x (32+6) byte halo tile with 4-byte loads (v_alignbit for rows that are not
 // 4-byte aligned), filters 4 pixels per thread out of LDS words and writes 4-byte words: one read + one write of the image.
 #include "olf_internal.hpp"
+#include <algorithm>
 
 namespace olf {
 
@@ -105,6 +106,90 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
     for (int i = 0; i < 7; ++i) t.t[i] = taps7[i];
     hipLaunchKernelGGL(k_sep7, dim3((W + SF_TW - 1) / SF_TW, (H + SF_TH - 1) / SF_TH, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch,
                        dst, dstImgStride, dstPitch, W, H, t);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR) for 8UC1 with host-built coefficient tables, LDS tiled:
+// a block produces 256 x 8 output pixels; the source rows/columns it needs are staged once with word loads,
+// the horizontal pass (S[sx]*a0 + S[sx+1]*a1) >> 4 is computed once per (source row, output column) into LDS as u16
+// (the reference only ever uses h >> 4, which fits: 255*2048 >> 4 = 32640), the vertical pass reads two of them.
+constexpr int RZ_TW = 256, RZ_TH = 8, RZ_SW = 96 /* words per staged source row */, RZ_SH = 16;
+
+__global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, int sw, int sh,
+                                                      uint8_t* __restrict__ dst, size_t dstImgStride, int dstPitch, int dw, int dh,
+                                                      const ResizeCoef* __restrict__ rx, const ResizeCoef* __restrict__ ry)
+{
+    __shared__ uint32_t s_src[RZ_SH * RZ_SW];
+    __shared__ uint16_t s_h[RZ_SH * RZ_TW];
+    __shared__ ResizeCoef s_rx[RZ_TW];
+    const int img = blockIdx.z, dx0 = blockIdx.x * RZ_TW, dy0 = blockIdx.y * RZ_TH;
+    const int nx = min(RZ_TW, dw - dx0), ny = min(RZ_TH, dh - dy0);
+    const uint8_t* s = src + (size_t)img * srcImgStride;
+    // source window: rows [ry0, ry1], columns from the aligned word holding rx[dx0].ofs
+    const int ry0 = min(max((int)ry[dy0].ofs, 0), sh - 1), ry1 = min(max((int)ry[dy0 + ny - 1].ofs + 1, 0), sh - 1);
+    const int cx0 = ((int)rx[dx0].ofs) & ~3;
+    const int cx1 = min((int)rx[dx0 + nx - 1].ofs + 1, sw - 1);
+    const int nrows = ry1 - ry0 + 1, nwords = (cx1 - cx0) / 4 + 1;
+    if (threadIdx.x < nx) s_rx[threadIdx.x] = rx[dx0 + threadIdx.x];
+    for (int i = threadIdx.x; i < nrows * nwords; i += 256) {
+        const int r = i / nwords, j = i - r * nwords;
+        // rows are 4-byte aligned (pitch % 4 == 0 and aligned base); the last word may run past sw but stays inside the pitch
+        s_src[r * RZ_SW + j] = *reinterpret_cast<const uint32_t*>(s + (size_t)(ry0 + r) * srcPitch + cx0 + 4 * j);
+    }
+    __syncthreads();
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_src);
+    for (int i = threadIdx.x; i < nrows * RZ_TW; i += 256) {
+        const int r = i >> 8, x = i & 255;
+        if (x < nx) {
+            const ResizeCoef c = s_rx[x];
+            const int sx = c.ofs, sx1 = min(sx + 1, sw - 1);
+            const int h = (int)sb[r * RZ_SW * 4 + sx - cx0] * c.a0 + (int)sb[r * RZ_SW * 4 + sx1 - cx0] * c.a1;
+            s_h[r * RZ_TW + x] = (uint16_t)(h >> 4);
+        }
+    }
+    __syncthreads();
+    uint8_t* d = dst + (size_t)img * dstImgStride;
+    for (int i = threadIdx.x; i < ny * (RZ_TW / 4); i += 256) {
+        const int yy = i >> 6, q = i & 63;
+        if (4 * q >= nx) continue;
+        const ResizeCoef cy = ry[dy0 + yy];
+        const int r0 = min(max((int)cy.ofs, 0), sh - 1) - ry0, r1 = min(max((int)cy.ofs + 1, 0), sh - 1) - ry0;
+        const int b0 = cy.a0, b1 = cy.a1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int h0 = s_h[r0 * RZ_TW + 4 * q + k], h1 = s_h[r1 * RZ_TW + 4 * q + k];
+            const int v = (((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        // columns beyond dw inside the last quad are scratch bytes of the padded pitch
+        *reinterpret_cast<uint32_t*>(d + (size_t)(dy0 + yy) * dstPitch + dx0 + 4 * q) = out;
+    }
+}
+
+// host: largest source window any tile needs; the tiled kernel is used when it fits the LDS staging area
+bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int sh, int dw, int dh)
+{
+    for (int x0 = 0; x0 < dw; x0 += RZ_TW) {
+        const int nx = std::min(RZ_TW, dw - x0);
+        const int c0 = ((int)rx[x0].ofs) & ~3, c1 = std::min((int)rx[x0 + nx - 1].ofs + 1, sw - 1);
+        if ((c1 - c0) / 4 + 1 > RZ_SW) return false;
+    }
+    for (int y0 = 0; y0 < dh; y0 += RZ_TH) {
+        const int ny = std::min(RZ_TH, dh - y0);
+        const int r0 = std::min(std::max((int)ry[y0].ofs, 0), sh - 1), r1 = std::min(std::max((int)ry[y0 + ny - 1].ofs + 1, 0), sh - 1);
+        if (r1 - r0 + 1 > RZ_SH) return false;
+    }
+    return true;
+}
+
+int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,
+                        int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_resize_tiled, dim3((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, n_images), dim3(256), 0, s, src, srcImgStride,
+                       srcPitch, sw, sh, dst, dstImgStride, dstPitch, dw, dh, d_rx, d_ry);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

@@ -134,6 +134,7 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
             double inv_x = (double)L.w / P.w, inv_y = (double)L.h / P.h;
             resize_axis_coefs(P.w, L.w, 1. / inv_x, true, &rx[L.resizeTabX]);
             resize_axis_coefs(P.h, L.h, 1. / inv_y, false, &ry[L.resizeTabY]);
+            L.resizeTiled = resize_tiled_fits(&rx[L.resizeTabX], &ry[L.resizeTabY], P.w, P.h, L.w, L.h) ? 1 : 0;
         }
     }
     g.pyrBytes = off;
@@ -214,6 +215,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE, INTER_LINEAR): scale_x = 1/SCALE
     resize_axis_coefs(W, g.Ws, 1. / p.lsd_scale, true, rx.data());
     resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
+    g.resizeTiled = resize_tiled_fits(rx.data(), ry.data(), W, H, g.Ws, g.Hs) ? 1 : 0;
     return OLF_OK;
 }
 

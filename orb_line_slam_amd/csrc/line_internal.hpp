@@ -34,6 +34,7 @@ struct LineGeom {
     float gaussCoefL[21];      // (float) of the reference's double weights
     float gaussCoefG[63];
     int resizeTabX, resizeTabY;
+    int resizeTiled;
 };
 
 struct LineDeviceBufs {

@@ -222,6 +222,37 @@ __device__ __forceinline__ bool is_aligned(double a, double theta, double prec)
     return n_theta <= prec;
 }
 
+// sin/cos of a double in [0, 2*pi + eps] (all the path ever asks for): Cody-Waite reduction by pi/2 and the fdlibm
+// kernel polynomials, < 1 ulp like ocml's sincos but a third of the instructions (no large-argument path).  The
+// reference evaluates libm's double cos/sin here and immediately rounds the float accumulation, so any sub-ulp
+// accurate double result gives the same float except when it straddles a rounding boundary.
+__device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
+{
+    const int k = (int)__fma_rn(x, 0.63661977236758134308, 0.5);
+    double r = __fma_rn(-(double)k, 1.57079632679489655800e+00, x);
+    r = __fma_rn(-(double)k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = __fma_rn(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __fma_rn(z, ps, 2.75573137070700676789e-06);
+    ps = __fma_rn(z, ps, -1.98412698298579493134e-04);
+    ps = __fma_rn(z, ps, 8.33333333332248946124e-03);
+    ps = __fma_rn(z, ps, -1.66666666666666324348e-01);
+    const double s0 = __fma_rn(r * z, ps, r);
+    double pc = __fma_rn(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __fma_rn(z, pc, -2.75573143513906633035e-07);
+    pc = __fma_rn(z, pc, 2.48015872894767294178e-05);
+    pc = __fma_rn(z, pc, -1.38888888888741095749e-03);
+    pc = __fma_rn(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c0 = w + (((1.0 - w) - hz) + z * z * pc);
+    const bool sw = k & 1;
+    double so = sw ? c0 : s0, co = sw ? s0 : c0;
+    if (k & 2) so = -so;
+    if ((k + 1) & 2) co = -co;
+    *sn = so; *cs = co;
+}
+
 constexpr int RING = 1024;   // FIFO window of the growing region kept in LDS
 constexpr int PEND = 2048;   // hash table of pixels whose USED store may not be visible to a load yet
 
@@ -299,33 +330,53 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                             cand = true;
                             xy = xx | (yy << 16);
                             ang = d_mul((double)dev_fastAtan2((float)unpack_gx(pw), (float)(-unpack_gy(pw))), kDegToRads);
-                            sincos((double)(float)ang, &sn, &cs);
+                            sincos_2pi((double)(float)ang, &sn, &cs);
                         }
                     }
                 }
+                // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
+                // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
+                // that same angle, as in the reference), the angle is updated and the rest is re-tested.
                 unsigned long long cm = __ballot(cand);
+                unsigned long long acc = 0;
+                const int n0 = n;
                 while (cm) {
-                    const int c = __builtin_ctzll(cm);
-                    cm &= cm - 1;
-                    const double ang_c = rlane_d(ang, c);
-                    if (is_aligned(ang_c, reg_angle, prec)) {
-                        const int a_c = rlane(a, c);
-                        const uint32_t xy_c = (uint32_t)rlane(xy, c), pw_c = (uint32_t)rlane((int)pw, c);
-                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
-                        if (!have_sum) {
-                            double s0, c0;
-                            sincos(reg_angle, &s0, &c0);
-                            sumdx = (float)c0; sumdy = (float)s0;
-                            have_sum = true;
-                        }
-                        MARK_USED(a_c, pw_c);
-                        if (lane == 0) { s_ring[n & (RING - 1)] = xy_c; reg[n] = xy_c; }
-                        ++n;
-                        sumdx = (float)d_add((double)sumdx, cs_c);
-                        sumdy = (float)d_add((double)sumdy, sn_c);
-                        reg_angle = d_mul((double)dev_fastAtan2(sumdy, sumdx), kDegToRads);
-                        cm &= ~__ballot(a == a_c);   // the same pixel seen through another FIFO entry of this batch
+                    const unsigned long long al = __ballot(cand && is_aligned(ang, reg_angle, prec)) & cm;
+                    if (!al) break;
+                    const int c = __builtin_ctzll(al);
+                    cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
+                    const int a_c = rlane(a, c);
+                    const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
+                    if (!have_sum) {
+                        double s0, c0;
+                        sincos_2pi(reg_angle, &s0, &c0);
+                        sumdx = (float)c0; sumdy = (float)s0;
+                        have_sum = true;
                     }
+                    acc |= 1ull << c;
+                    ++n;
+                    sumdx = (float)d_add((double)sumdx, cs_c);
+                    sumdy = (float)d_add((double)sumdy, sn_c);
+                    reg_angle = d_mul((double)dev_fastAtan2(sumdy, sumdx), kDegToRads);
+                    const unsigned long long dup = __ballot(a == a_c);   // the same pixel seen through another FIFO entry of this batch
+                    cm &= ~dup;
+                    if (a == a_c) cand = false;
+                }
+                // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
+                if (acc) {
+                    const bool mine = (acc >> lane) & 1ull;
+                    const int slot = a & (PEND - 1);
+                    if (__ballot(mine && s_pend[slot] != -1)) PEND_FLUSH();
+                    if (mine) {
+                        const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
+                        grad[a] = pw | kUsed;
+                        s_ring[idx & (RING - 1)] = (uint32_t)xy;
+                        reg[idx] = (uint32_t)xy;
+                        s_pend[slot] = a;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // two accepted pixels of this batch hashing to one slot: only one survived in the table -> make both visible
+                    if (__ballot(mine && s_pend[slot] != a)) PEND_FLUSH();
                 }
                 i += nb;
                 __builtin_amdgcn_wave_barrier();
@@ -463,7 +514,11 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));
     { int rc = launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 0, n_images, s);
       if (rc != OLF_OK) return rc; }
-    {
+    if (g.resizeTiled) {
+        int rc = launch_resize_tiled(b.lsdBlur, (size_t)g.pitchW * g.H, g.pitchW, g.W, g.H, b.scaled, (size_t)g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, b.rx,
+                                     b.ry, n_images, s);
+        if (rc != OLF_OK) return rc;
+    } else {
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }

@@ -54,6 +54,7 @@ struct LevelGeom {
     int candCap;            // capacity of this level's candidate array
     int kpBase, kpCap;      // per-level survivor array (kpCap = quota + 8)
     int resizeTabX, resizeTabY;  // offsets into the resize coefficient tables (level >= 1)
+    int resizeTiled;             // 1: the LDS-tiled resize kernel's staging area covers every tile of this level
 };
 
 struct ResizeCoef { int16_t ofs; int16_t a0; int16_t a1; int16_t pad; };
@@ -120,6 +121,10 @@ int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, 
 struct Taps7 { int t[7]; };
 int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
                 const int* taps7, int n_images, hipStream_t s);
+
+bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int sh, int dw, int dh);
+int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,
+                        int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s);
 
 // match.hip
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,

@@ -273,9 +273,15 @@ int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* 
                            g.lv[0].pitch, g.pyrBytes);
     }
     for (int l = 1; l < g.nlevels; ++l) {
-        const int quads = ((g.lv[l].w + 3) >> 2) * g.lv[l].h;
-        hipLaunchKernelGGL(k_resize, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.pyr, g.pyrBytes, g.lv[l - 1], g.lv[l],
-                           b.rx, b.ry);
+        const LevelGeom &P = g.lv[l - 1], &L = g.lv[l];
+        if (L.resizeTiled) {
+            int rc = launch_resize_tiled(b.pyr + P.offset, (size_t)g.pyrBytes, P.pitch, P.w, P.h, b.pyr + L.offset, (size_t)g.pyrBytes, L.pitch, L.w, L.h,
+                                         b.rx + L.resizeTabX, b.ry + L.resizeTabY, n_images, s);
+            if (rc != OLF_OK) return rc;
+        } else {
+            const int quads = ((L.w + 3) >> 2) * L.h;
+            hipLaunchKernelGGL(k_resize, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.pyr, g.pyrBytes, P, L, b.rx, b.ry);
+        }
     }
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
