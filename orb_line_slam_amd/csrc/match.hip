@@ -19,10 +19,71 @@ __device__ __forceinline__ int ham256(const uint4 a0, const uint4 a1, const uint
 // ComputeStereoMatches, one wave per left key point of one stereo pair (images 2p, 2p+1).
 constexpr int TH_HIGH = 100, TH_LOW = 50;
 
+// Candidate search of ComputeStereoMatches (src/Frame.cc:719-786), one THREAD per left key point.  The right key
+// points stream through LDS in tiles (row span [floor(y-r), ceil(y+r)], octave, x, descriptor) and are read at a
+// wave-uniform address; a left key point only pays the Hamming distance for right points that pass the row / octave /
+// disparity-range gates.  best = min (distance, iR): the reference scans candidates in increasing iR with a strict '<'.
+constexpr int ST_TILE = 128;
+
+__global__ __launch_bounds__(256) void k_stereo_cand(const OrbGeom* __restrict__ gp, const olf_keypoint* __restrict__ kps,
+                                                     const uint8_t* __restrict__ desc, const int* __restrict__ counts, int cap, float mbf,
+                                                     float fx, unsigned* __restrict__ bestKey)
+{
+    __shared__ uint4 s_d[ST_TILE * 2];
+    __shared__ int s_rows[ST_TILE];      // minr | maxr << 16
+    __shared__ int s_oct[ST_TILE];
+    __shared__ float s_x[ST_TILE];
+    const OrbGeom& g = *gp;
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 256 + threadIdx.x;
+    const int nL = counts[2 * pair], nR = counts[2 * pair + 1];
+    if (blockIdx.x * 256 >= nL) return;
+    const size_t oL = (size_t)(2 * pair) * cap, oR = (size_t)(2 * pair + 1) * cap;
+    const bool live = iL < nL;
+    olf_keypoint kL = kps[oL + (live ? iL : 0)];
+    const uint4* dLp = reinterpret_cast<const uint4*>(desc + (oL + (live ? iL : 0)) * OLF_DESC_BYTES);
+    const uint4 a0 = dLp[0], a1 = dLp[1];
+    const int levelL = kL.octave, row = (int)kL.y;
+    const float mb = f_div(mbf, fx);
+    const float maxD = f_div(mbf, mb);
+    const float minU = f_sub(kL.x, maxD), maxU = kL.x;
+    unsigned best = ((unsigned)TH_HIGH << 16) | 0xffffu;
+    for (int t0 = 0; t0 < nR; t0 += ST_TILE) {
+        const int cnt = min(ST_TILE, nR - t0);
+        __syncthreads();
+        if (threadIdx.x < cnt) {
+            const olf_keypoint kR = kps[oR + t0 + threadIdx.x];
+            const float r = f_mul(2.0f, g.lv[kR.octave].scale);
+            const int maxr = (int)ceilf(f_add(kR.y, r)), minr = (int)floorf(f_sub(kR.y, r));
+            s_rows[threadIdx.x] = (minr & 0xffff) | (maxr << 16);
+            s_oct[threadIdx.x] = kR.octave;
+            s_x[threadIdx.x] = kR.x;
+        }
+        {
+            const uint4* dRp = reinterpret_cast<const uint4*>(desc + (oR + t0) * OLF_DESC_BYTES);
+            if (threadIdx.x < 2 * cnt) s_d[threadIdx.x] = dRp[threadIdx.x];
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const int rw = s_rows[j];
+            const int minr = (int)(short)(rw & 0xffff), maxr = rw >> 16;
+            if (row < minr || row > maxr) continue;
+            const int oc = s_oct[j];
+            if (oc < levelL - 1 || oc > levelL + 1) continue;
+            const float xr = s_x[j];
+            if (!(xr >= minU && xr <= maxU)) continue;
+            const unsigned d = (unsigned)ham256(a0, a1, s_d[2 * j], s_d[2 * j + 1]);
+            best = min(best, (d << 16) | (unsigned)(t0 + j));
+        }
+    }
+    if (live) bestKey[(size_t)pair * cap + iL] = best;
+}
+
 __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict__ gp, const uint8_t* __restrict__ pyr,
                                                       const olf_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                       const int* __restrict__ counts, int cap, float mbf, float fx,
-                                                      float* __restrict__ uRight, float* __restrict__ depth, int* __restrict__ sad)
+                                                      const unsigned* __restrict__ bestKey, float* __restrict__ uRight,
+                                                      float* __restrict__ depth, int* __restrict__ sad)
 {
     const OrbGeom& g = *gp;
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
@@ -39,24 +100,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
     const float maxD = f_div(mbf, mb);
     const float minU = f_sub(uL, maxD), maxU = uL;
     const int row = (int)vL;
-    const uint4* dLp = reinterpret_cast<const uint4*>(desc + (oL + iL) * OLF_DESC_BYTES);
-    const uint4 a0 = dLp[0], a1 = dLp[1];
-    // best = min (distance, iR): the reference scans candidates in increasing iR with a strict '<'
-    unsigned best = ((unsigned)TH_HIGH << 16) | 0xffffu;
-    for (int iR = lane; iR < nR; iR += 64) {
-        const olf_keypoint kR = kps[oR + iR];
-        const float r = f_mul(2.0f, g.lv[kR.octave].scale);
-        const int maxr = (int)ceilf(f_add(kR.y, r)), minr = (int)floorf(f_sub(kR.y, r));
-        if (row < minr || row > maxr) continue;
-        if (kR.octave < levelL - 1 || kR.octave > levelL + 1) continue;
-        if (!(kR.x >= minU && kR.x <= maxU)) continue;
-        const uint4* dRp = reinterpret_cast<const uint4*>(desc + (oR + iR) * OLF_DESC_BYTES);
-        const unsigned d = (unsigned)ham256(a0, a1, dRp[0], dRp[1]);
-        const unsigned key = (d << 16) | (unsigned)iR;
-        best = min(best, key);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+    const unsigned best = bestKey[(size_t)pair * cap + iL];
     const int bestDist = (int)(best >> 16);
     const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
     if (bestDist < thOrbDist && (best & 0xffffu) != 0xffffu && bestDist < TH_HIGH) {
@@ -182,48 +226,42 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ c
 // Brute-force 2-nearest-neighbour search (cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2), App. A.10):
 // per query the two smallest distances; ties keep the lower train index first.  One wave per query.
 // Sets are batched: set s has nQ[s] queries at q + s*strideQ*32 and nT[s] train rows at t + s*strideT*32.
-struct Knn2 { unsigned k0; unsigned d1; };   // k0 = (d0 << 16 | idx), d1 = second distance
-
-__device__ __forceinline__ Knn2 knn_merge(Knn2 a, Knn2 b)
-{
-    Knn2 r;
-    if (a.k0 <= b.k0) { r.k0 = a.k0; r.d1 = min(a.d1, b.k0 >> 16); }
-    else { r.k0 = b.k0; r.d1 = min(b.d1, a.k0 >> 16); }
-    return r;
-}
+// One THREAD per query: the query's 256 bits live in 8 registers, the train descriptors stream through LDS in tiles
+// and are read at a wave-uniform address (broadcast), so the inner loop is 8 x (xor, popcount, add) + the top-2 update.
+constexpr int KNN_TILE = 128;   // train descriptors per LDS tile (4 KB)
 
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nQ, int strideQ, int qSetStep,
                                               const uint8_t* __restrict__ t, const int* __restrict__ nT, int strideT, int tSetStep,
                                               int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ dist1)
 {
-    const int set = blockIdx.y, lane = threadIdx.x & 63;
-    const int iq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint4 s_t[KNN_TILE * 2];
+    const int set = blockIdx.y;
+    const int iq = blockIdx.x * 256 + threadIdx.x;
     const int nq = nQ[set * qSetStep], nt = nT[set * tSetStep];
-    if (iq >= nq) return;
-    const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
-    const uint4 a0 = qp[0], a1 = qp[1];
-    Knn2 best;
-    best.k0 = 0xffffffffu; best.d1 = 0xffffu;
+    if (blockIdx.x * 256 >= nq) return;                      // whole block beyond the query set
+    const bool live = iq < nq;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (live) {
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
+        a0 = qp[0]; a1 = qp[1];
+    }
+    int b0 = 0x7fffffff, b1 = 0x7fffffff, i0 = -1;
     const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)set * strideT * OLF_DESC_BYTES);
-    for (int j = lane; j < nt; j += 64) {
-        const unsigned d = (unsigned)ham256(a0, a1, tp[2 * j], tp[2 * j + 1]);
-        Knn2 c;
-        c.k0 = (d << 16) | (unsigned)j; c.d1 = 0xffffu;
-        best = knn_merge(best, c);
+    for (int t0 = 0; t0 < nt; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, nt - t0);
+        __syncthreads();
+        if (threadIdx.x < 2 * cnt) s_t[threadIdx.x] = tp[2 * t0 + threadIdx.x];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const int d = ham256(a0, a1, s_t[2 * j], s_t[2 * j + 1]);
+            // ascending train index + strict '<' == "ties keep the lower train index first" (App. A.10)
+            if (d < b0) { b1 = b0; b0 = d; i0 = t0 + j; }
+            else if (d < b1) b1 = d;
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Knn2 other;
-        other.k0 = (unsigned)__shfl_xor((int)best.k0, o);
-        other.d1 = (unsigned)__shfl_xor((int)best.d1, o);
-        best = knn_merge(best, other);
-    }
-    if (lane == 0) {
+    if (live) {
         const size_t o = (size_t)set * strideQ + iq;
-        const bool has0 = best.k0 != 0xffffffffu, has1 = best.d1 != 0xffffu;
-        idx0[o] = has0 ? (int)(best.k0 & 0xffffu) : -1;
-        dist0[o] = has0 ? (int)(best.k0 >> 16) : 0x7fffffff;
-        dist1[o] = has1 ? (int)best.d1 : 0x7fffffff;
+        idx0[o] = i0; dist0[o] = b0; dist1[o] = b1;
     }
 }
 
@@ -262,10 +300,14 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 
 // ---------------------------------------------------------------------------------------------
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
-                         const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, hipStream_t s)
+                         const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, int* d_bestKey,
+                         hipStream_t s)
 {
+    // d_sad doubles as the (distance, index) scratch of the candidate search until k_stereo_match overwrites it per key point
+    unsigned* bestKey = reinterpret_cast<unsigned*>(d_bestKey);
+    hipLaunchKernelGGL(k_stereo_cand, dim3((cap + 255) / 256, n_pairs), dim3(256), 0, s, b.geom, d_kps, d_desc, d_counts, cap, mbf, fx, bestKey);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, b.geom, b.pyr, d_kps, d_desc, d_counts, cap, mbf,
-                       fx, d_uRight, d_depth, d_sad);
+                       fx, bestKey, d_uRight, d_depth, d_sad);
     int sortN = 64;
     while (sortN < cap) sortN <<= 1;
     hipLaunchKernelGGL(k_stereo_median, dim3(n_pairs), dim3(256), sortN * sizeof(unsigned), s, d_counts, cap, sortN, d_uRight, d_depth,
@@ -279,9 +321,9 @@ int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, co
 {
     int* idxAB = ws; int* d0AB = idxAB + (size_t)n_sets * strideA; int* d1AB = d0AB + (size_t)n_sets * strideA;
     int* idxBA = d1AB + (size_t)n_sets * strideA; int* d0BA = idxBA + (size_t)n_sets * strideB; int* d1BA = d0BA + (size_t)n_sets * strideB;
-    hipLaunchKernelGGL(k_knn2, dim3((strideA + 3) / 4, n_sets), dim3(256), 0, s, dA, nA, strideA, aStep, dB, nB, strideB, bStep, idxAB, d0AB, d1AB);
+    hipLaunchKernelGGL(k_knn2, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, dA, nA, strideA, aStep, dB, nB, strideB, bStep, idxAB, d0AB, d1AB);
     if (best_lr)
-        hipLaunchKernelGGL(k_knn2, dim3((strideB + 3) / 4, n_sets), dim3(256), 0, s, dB, nB, strideB, bStep, dA, nA, strideA, aStep, idxBA, d0BA, d1BA);
+        hipLaunchKernelGGL(k_knn2, dim3((strideB + 255) / 256, n_sets), dim3(256), 0, s, dB, nB, strideB, bStep, dA, nA, strideA, aStep, idxBA, d0BA, d1BA);
     hipLaunchKernelGGL(k_ratio_mutual, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, nA, strideA, aStep, nB, strideB, bStep, idxAB, d0AB,
                        d1AB, idxBA, d0BA, d1BA, nnr, best_lr, m12);
     OLF_HIP_CHECK(hipGetLastError());
@@ -291,7 +333,7 @@ int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, co
 int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
                 int* dist0, int* dist1, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_knn2, dim3((strideA + 3) / 4, n_sets), dim3(256), 0, s, dA, nA, strideA, 1, dB, nB, strideB, 1, idx0, dist0, dist1);
+    hipLaunchKernelGGL(k_knn2, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, dA, nA, strideA, 1, dB, nB, strideB, 1, idx0, dist0, dist1);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
