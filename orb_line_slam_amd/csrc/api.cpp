@@ -168,14 +168,14 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(b.cells, n * g.totalCells * g.cellCap); A(b.cellCount, n * g.totalCells);
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
-    A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 4);
+    A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 64);
     A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap); A(c->d_bestkey, ((n + 1) / 2) * g.outCap);
     A(c->d_images, n * width * height); A(c->d_kps, n * g.outCap); A(c->d_desc, n * g.outCap * OLF_DESC_BYTES); A(c->d_counts, n);
 #undef A
     if (hipMemcpy(b.rx, c->orb.rx.data(), c->orb.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.ry, c->orb.ry.data(), c->orb.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.geom, &g, sizeof(OrbGeom), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(b.status, 0, 16) != hipSuccess || hipMemset(b.score, 0, n * g.pyrBytes) != hipSuccess) {
+        hipMemset(b.status, 0, 256) != hipSuccess || hipMemset(b.score, 0, n * g.pyrBytes) != hipSuccess) {
         set_error("olf_ctx_create: table upload failed");
         return fail(OLF_ERR_HIP);
     }
@@ -333,6 +333,14 @@ int olf_orb_pyramid_level(olf_ctx* c, int image, int level, int blurred, uint8_t
     const uint8_t* src = (blurred ? c->ob.blur : c->ob.pyr) + (size_t)image * c->orb.geom.pyrBytes + L.offset;
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     OLF_HIP_CHECK(hipMemcpy2D(dst, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return OLF_OK;
+}
+
+int olf_debug_status(olf_ctx* c, int32_t* out64)
+{
+    if (!c || !out64) return OLF_ERR_INVALID;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    OLF_HIP_CHECK(hipMemcpy(out64, c->ob.status, 256, hipMemcpyDeviceToHost));
     return OLF_OK;
 }
 

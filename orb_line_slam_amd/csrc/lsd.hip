@@ -289,6 +289,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int nl = 0;
+#ifdef OLF_TIMING
+    long long t_seed = 0, t_small = 0, t_big = 0, t_rect = 0, n_small = 0, n_big = 0, it_small = 0, it_big = 0; long long t0 = __builtin_readcyclecounter();
+#endif
 
 #define PEND_FLUSH() do { __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
@@ -311,8 +314,15 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[0] = pk; }
             __builtin_amdgcn_wave_barrier();
+#ifdef OLF_TIMING
+            { long long t1 = __builtin_readcyclecounter(); t_seed += t1 - t0; t0 = t1; }
+            int iters = 0;
+#endif
             int i = 0;
             while (i < n) {
+#ifdef OLF_TIMING
+                ++iters;
+#endif
                 const int nb = min(7, n - i);
                 const int e = lane / 9, k = lane - 9 * e;
                 if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
@@ -381,6 +391,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                 i += nb;
                 __builtin_amdgcn_wave_barrier();
             }
+#ifdef OLF_TIMING
+            { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; it_big += iters; } else { t_small += t1 - t0; ++n_small; it_small += iters; } t0 = t1; }
+#endif
             if (n >= g.minRegSize) {
                 __threadfence_block();   // region2rect reads the FIFO back from memory
                 // ---- region2rect: the products are formed 64 at a time (one per lane), the additions are replayed
@@ -489,6 +502,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                     } else if (lane == 0) atomicOr(status, 8);
                 }
             }
+#ifdef OLF_TIMING
+            { long long t1 = __builtin_readcyclecounter(); t_rect += t1 - t0; t0 = t1; }
+#endif
             // seeds later in this 64-key window may have been consumed by the region just grown
             if (n == 1) mask &= mask - 1;
             else mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
@@ -496,6 +512,9 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
     }
 #undef MARK_USED
 #undef PEND_FLUSH
+#ifdef OLF_TIMING
+    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = t_seed; o[1] = t_small; o[2] = t_big; o[3] = t_rect; o[4] = n_small; o[5] = n_big; o[6] = it_small; o[7] = it_big; }
+#endif
     if (lane == 0) rawCount[img] = nl;
 }
 
