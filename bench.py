@@ -185,6 +185,16 @@ def main():
         per_launch_bytes = {"lsd_grow": ab["grow_per_image"] * 2 * B,
                             "orb_octree": 0, "orb_describe": (749 + 512 + 32 + 28) * nk * 2 * B}[dom]
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/*_pmc_hbm_traffic.json,
+        # KiB counters, per image), scaled to this launch's image count; null when no PMC summary has been committed for the kernel.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_hbm_traffic.json")))
+            kname = {"lsd_grow": "olf::k_lsd_grow", "orb_octree": "olf::k_octree", "orb_describe": "olf::k_describe"}[dom]
+            if kname in pm["kernels"]:
+                traffic = int(pm["kernels"][kname]["bytes_per_image"] * 2 * B)
+        except Exception:
+            traffic = None
         out = {
             "metric": "stereo frames/s extract+match (ORB+LBD), KITTI 1242x375", "value": round(fps, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -193,7 +203,7 @@ def main():
                                    f"f2f LBD match + f2f dense ORB kNN match", "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
                        "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1), "mean_line_pixels": round(mean_len, 1)},
             "roofline": {"bound": "hbm", "kernel": {"lsd_grow": "olf::k_lsd_grow", "orb_octree": "olf::k_octree", "orb_describe": "olf::k_describe"}[dom],
-                         "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
+                         "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(dom_ms, 4),
                          "path_bytes_per_pair": int(ab["pair"]), "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6)},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
