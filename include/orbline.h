@@ -89,6 +89,14 @@ int olf_match_bf(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* desc
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (host buffers): per query best index, best and second distance
  * (-1 / INT_MAX where the train set is too small) */
 int olf_knn2(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx0, int32_t* dist0, int32_t* dist1);
+/* Candidate-list distances for ORBmatcher::SearchByProjection (src/ORBmatcher.cc:1330-1472) / SearchByBoW (:161-290):
+ * query i is compared with train rows cand_idx[cand_offsets[i] .. cand_offsets[i+1]) (CSR, built by the caller from
+ * Frame::GetFeaturesInArea / the BoW feature vectors); dist[k] receives the Hamming distance of pair k (0xffff for an
+ * out-of-range index).  The order-dependent greedy resolution stays with the caller. */
+int olf_match_candidates_dev(olf_ctx* ctx, const uint8_t* d_descQ, int nQ, const uint8_t* d_descT, int nT, const int32_t* d_cand_offsets,
+                             const int32_t* d_cand_idx, uint16_t* d_dist, void* stream);
+int olf_match_candidates(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const int32_t* cand_offsets,
+                         const int32_t* cand_idx, uint16_t* dist);
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1795-1811) over all pairs: out[nA][nB] uint16 (host buffers) */
 int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out);
 

@@ -1,0 +1,207 @@
+// search_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code).
+//
+// Restates (paths relative to /root/reference), on plain arrays instead of Frame / KeyFrame / MapPoint objects:
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)   src/ORBmatcher.cc:1330-1472
+//   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)     src/ORBmatcher.cc:161-290
+//   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
+//   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
+// cv::Mat products of CV_32F operands (Rcw*x3Dw+tcw) accumulate in double and round once (cv::gemm generic path).
+// PARITY UNPINNED (see oracle_common.hpp).
+#include "oracle_common.hpp"
+
+namespace orc {
+static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30, GC = 64, GR = 48;
+
+struct Cam { float fx, fy, cx, cy, mbf, minX, maxX, minY, maxY; };
+
+struct GridFrame {
+    const olf_keypoint* keys; int N; Cam c;
+    float wInv, hInv;
+    std::vector<size_t> grid[GC][GR];
+    void build()
+    {
+        wInv = static_cast<float>(GC) / (c.maxX - c.minX);
+        hInv = static_cast<float>(GR) / (c.maxY - c.minY);
+        for (int i = 0; i < N; ++i) {
+            int posX = (int)std::round((keys[i].x - c.minX) * wInv), posY = (int)std::round((keys[i].y - c.minY) * hInv);
+            if (posX < 0 || posX >= GC || posY < 0 || posY >= GR) continue;
+            grid[posX][posY].push_back(i);
+        }
+    }
+    std::vector<size_t> area(float x, float y, float r, int minLevel = -1, int maxLevel = -1) const
+    {
+        std::vector<size_t> v;
+        const int nMinCellX = std::max(0, (int)std::floor((x - c.minX - r) * wInv));
+        if (nMinCellX >= GC) return v;
+        const int nMaxCellX = std::min(GC - 1, (int)std::ceil((x - c.minX + r) * wInv));
+        if (nMaxCellX < 0) return v;
+        const int nMinCellY = std::max(0, (int)std::floor((y - c.minY - r) * hInv));
+        if (nMinCellY >= GR) return v;
+        const int nMaxCellY = std::min(GR - 1, (int)std::ceil((y - c.minY + r) * hInv));
+        if (nMaxCellY < 0) return v;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (size_t j : grid[ix][iy]) {
+                    const olf_keypoint& kp = keys[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(j);
+                }
+        return v;
+    }
+};
+
+static void three_maxima(std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+
+static void mat3_mul_add(const float* T /*4x4 row-major*/, const float v[3], float out[3])   // R*v + t
+{
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)T[4 * r + k] * v[k];
+        out[r] = (float)(acc + (double)T[4 * r + 3]);
+    }
+}
+}  // namespace orc
+
+using namespace orc;
+extern "C" {
+
+int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
+                             uint8_t* cur_mp_obs, const float* curTcw, const olf_keypoint* lastKeys, int lastN, const uint8_t* last_mp_valid,
+                             const float* last_mp_world, const uint8_t* last_mp_desc, const uint8_t* last_mp_obs, const uint8_t* last_outlier,
+                             const float* lastTcw, const float* cam9, const float* scaleFactors, float th, int bMono, int checkOri, int* matches)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    const float mb = c.mbf / c.fx;
+    GridFrame G; G.keys = curKeys; G.N = curN; G.c = c; G.build();
+    for (int i = 0; i < curN; ++i) matches[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    // twc = -Rcw^T * tcw ; tlc = Rlw*twc + tlw
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)curTcw[4 * k + r] * curTcw[4 * k + 3];
+        twc[r] = (float)(-acc);
+    }
+    mat3_mul_add(lastTcw, twc, tlc);
+    const bool bForward = tlc[2] > mb && !bMono, bBackward = -tlc[2] > mb && !bMono;
+    for (int i = 0; i < lastN; i++) {
+        if (!last_mp_valid[i] || last_outlier[i]) continue;
+        float x3Dc[3];
+        mat3_mul_add(curTcw, last_mp_world + 3 * i, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        if (invzc < 0) continue;
+        float u = c.fx * xc * invzc + c.cx, v = c.fy * yc * invzc + c.cy;
+        if (u < c.minX || u > c.maxX) continue;
+        if (v < c.minY || v > c.maxY) continue;
+        const int nLastOctave = lastKeys[i].octave;
+        const float radius = th * scaleFactors[nLastOctave];
+        std::vector<size_t> vIndices2;
+        if (bForward) vIndices2 = G.area(u, v, radius, nLastOctave);
+        else if (bBackward) vIndices2 = G.area(u, v, radius, 0, nLastOctave);
+        else vIndices2 = G.area(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = last_mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (cur_mp_valid[i2] && cur_mp_obs[i2]) continue;
+            if (curURight[i2] > 0) {
+                const float ur = u - c.mbf * invzc;
+                const float er = std::fabs(ur - curURight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = hamming256(dMP, curDesc + 32 * i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_mp_valid[bestIdx2] = 1; cur_mp_obs[bestIdx2] = last_mp_obs[i];
+            matches[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                float rot = lastKeys[i].angle - curKeys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { cur_mp_valid[j] = 0; matches[j] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+// feature vectors as CSR: node ids ascending (std::map order), offsets, indices
+int orc_search_by_bow(const olf_keypoint* kfKeys, const uint8_t* kfDesc, const uint8_t* kf_mp_valid, const uint8_t* kf_mp_bad, const int* kfNodes,
+                      const int* kfOffs, const int* kfIdx, int kfNNodes, const olf_keypoint* fKeys, const uint8_t* fDesc, int fN, const int* fNodes,
+                      const int* fOffs, const int* fIdx, int fNNodes, float nnratio, int checkOri, int* matched)
+{
+    for (int i = 0; i < fN; ++i) matched[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int a = 0, b = 0;
+    while (a < kfNNodes && b < fNNodes) {
+        if (kfNodes[a] == fNodes[b]) {
+            for (int p = kfOffs[a]; p < kfOffs[a + 1]; ++p) {
+                const int realIdxKF = kfIdx[p];
+                if (!kf_mp_valid[realIdxKF] || kf_mp_bad[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int q = fOffs[b]; q < fOffs[b + 1]; ++q) {
+                    const int realIdxF = fIdx[q];
+                    if (matched[realIdxF] >= 0) continue;
+                    const int dist = hamming256(kfDesc + 32 * (size_t)realIdxKF, fDesc + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    matched[bestIdxF] = realIdxKF;
+                    if (checkOri) {
+                        float rot = kfKeys[realIdxKF].angle - fKeys[bestIdxF].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(bestIdxF);
+                    }
+                    nmatches++;
+                }
+            }
+            ++a; ++b;
+        } else if (kfNodes[a] < fNodes[b]) { while (a < kfNNodes && kfNodes[a] < fNodes[b]) ++a; }   // lower_bound
+        else { while (b < fNNodes && fNodes[b] < kfNodes[a]) ++b; }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matched[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+}  // extern "C"

@@ -444,6 +444,37 @@ int olf_knn2(olf_ctx* c, const uint8_t* descQ, int nQ, const uint8_t* descT, int
     return OLF_OK;
 }
 
+int olf_match_candidates_dev(olf_ctx* c, const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, const int32_t* d_offs, const int32_t* d_cand,
+                             uint16_t* d_dist, void* stream)
+{
+    if (!c || nQ < 0 || nT < 0 || (nQ && (!dQ || !d_offs || !d_dist))) { set_error("olf_match_candidates_dev: bad argument"); return OLF_ERR_INVALID; }
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    StageScope t(c, s, ST_MATCH_BF);
+    return launch_match_candidates(dQ, nQ, dT, nT, d_offs, d_cand, d_dist, s);
+}
+
+int olf_match_candidates(olf_ctx* c, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const int32_t* offs, const int32_t* cand,
+                         uint16_t* dist)
+{
+    if (!c || nQ < 0 || nT < 0 || (nQ && (!descQ || !offs)) || (nT && !descT)) { set_error("olf_match_candidates: bad argument"); return OLF_ERR_INVALID; }
+    if (nQ == 0) return OLF_OK;
+    const int nnz = offs[nQ];
+    if (nnz < 0 || offs[0] != 0 || (nnz && (!cand || !dist))) { set_error("olf_match_candidates: bad CSR"); return OLF_ERR_INVALID; }
+    if (nnz == 0) return OLF_OK;
+    void* st = nullptr;
+    const size_t bQ = (size_t)nQ * 32, bT = (size_t)std::max(nT, 1) * 32, bO = ((size_t)(nQ + 1) * 4 + 15) & ~(size_t)15, bC = ((size_t)nnz * 4 + 15) & ~(size_t)15;
+    OLF_TRY(scratch_get(c, 1, bQ + bT + bO + bC + (size_t)nnz * 2 + 64, &st));
+    uint8_t* dQ = (uint8_t*)st; uint8_t* dT = dQ + bQ; int* dO = (int*)(dT + bT); int* dC = (int*)((uint8_t*)dO + bO); uint16_t* dD = (uint16_t*)((uint8_t*)dC + bC);
+    OLF_HIP_CHECK(hipMemcpyAsync(dQ, descQ, bQ, hipMemcpyHostToDevice, c->stream));
+    if (nT) OLF_HIP_CHECK(hipMemcpyAsync(dT, descT, (size_t)nT * 32, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dO, offs, (size_t)(nQ + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dC, cand, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_match_candidates_dev(c, dQ, nQ, dT, nT, dO, dC, dD, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dist, dD, (size_t)nnz * 2, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 int olf_hamming_matrix(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out)
 {
     if (!c || !out || nA < 0 || nB < 0 || (nA && !descA) || (nB && !descB)) { set_error("olf_hamming_matrix: bad argument"); return OLF_ERR_INVALID; }

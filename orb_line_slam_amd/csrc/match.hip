@@ -287,6 +287,35 @@ __global__ __launch_bounds__(256) void k_ratio_mutual(const int* __restrict__ nA
     m12[oa] = m;
 }
 
+// Candidate-list Hamming (the distance part of ORBmatcher::SearchByProjection / SearchByBoW, src/ORBmatcher.cc:1395-1431,
+// :199-234): CSR lists of train indices per query, one distance per (query, candidate) pair in list order.  The greedy,
+// order-dependent resolution (already-matched skips, MapPoint state) stays on the host, SURVEY 8(b) / App. C.7.
+__global__ __launch_bounds__(256) void k_match_candidates(const uint8_t* __restrict__ q, int nQ, const uint8_t* __restrict__ t, int nT,
+                                                          const int* __restrict__ offs, const int* __restrict__ cand, uint16_t* __restrict__ out)
+{
+    const int iq = blockIdx.x * 256 + threadIdx.x;
+    if (iq >= nQ) return;
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)iq * OLF_DESC_BYTES);
+    const uint4 a0 = qp[0], a1 = qp[1];
+    for (int k = offs[iq]; k < offs[iq + 1]; ++k) {
+        const int j = cand[k];
+        uint16_t d = 0xffff;
+        if (j >= 0 && j < nT) {
+            const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)j * OLF_DESC_BYTES);
+            d = (uint16_t)ham256(a0, a1, tp[0], tp[1]);
+        }
+        out[k] = d;
+    }
+}
+
+int launch_match_candidates(const uint8_t* q, int nQ, const uint8_t* t, int nT, const int* offs, const int* cand, uint16_t* out, hipStream_t s)
+{
+    if (nQ <= 0) return OLF_OK;
+    hipLaunchKernelGGL(k_match_candidates, dim3((nQ + 255) / 256), dim3(256), 0, s, q, nQ, t, nT, offs, cand, out);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 // dense distance matrix (DescriptorDistance over all pairs), int16 out[nA][nB]
 __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restrict__ a, int nA, const uint8_t* __restrict__ b, int nB,
                                                         uint16_t* __restrict__ out)

@@ -75,3 +75,259 @@ class ORBmatcher:
     @staticmethod
     def DescriptorDistance(a, b):
         return distance(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ORBmatcher searches that need Frame / MapPoint state.  The reference walks C++ objects (Frame, KeyFrame, MapPoint*);
+# here a frame is a FrameView: plain arrays with the members those functions read.  Host code builds the candidate
+# lists (Frame::GetFeaturesInArea / the BoW feature vectors) and replays the greedy, order-dependent resolution exactly
+# as the reference does; every descriptor distance comes from the GPU (olf_match_candidates).
+class FrameView:
+    """The Frame / KeyFrame members read by SearchByProjection (src/ORBmatcher.cc:1330-1472) and SearchByBoW (:161-290).
+
+    mvKeysUn / mvKeys : KEYPOINT_DTYPE arrays;  mDescriptors : (N, 32) uint8;  mvuRight : (N,) float32
+    mp_valid[i]  : mvpMapPoints[i] != NULL        mp_world[i] : pMP->GetWorldPos() (float32 x3)
+    mp_desc[i]   : pMP->GetDescriptor()           mp_obs[i]   : pMP->Observations() > 0      mp_bad[i] : pMP->isBad()
+    mvbOutlier   : (N,) bool                      mTcw : (4, 4) float32
+    fx, fy, cx, cy, mbf, mb, mnMinX, mnMaxX, mnMinY, mnMaxY : camera / image bounds;  mvScaleFactors : (nlevels,) float32
+    mFeatVec     : {node id: [feature indices]} (DBoW2::FeatureVector), only for SearchByBoW
+    """
+    FRAME_GRID_COLS, FRAME_GRID_ROWS = 64, 48
+
+    def __init__(self, mvKeysUn, mDescriptors, mvuRight=None, mvScaleFactors=None, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157,
+                 mbf=386.1448, bounds=(0.0, 1241.0, 0.0, 376.0), mTcw=None, mFeatVec=None):
+        self.mvKeysUn = np.ascontiguousarray(mvKeysUn)
+        self.mvKeys = self.mvKeysUn          # identical when the camera has no distortion (src/Frame.cc:601-605)
+        self.N = len(self.mvKeysUn)
+        self.mDescriptors = np.ascontiguousarray(mDescriptors, np.uint8).reshape(self.N, 32)
+        self.mvuRight = np.full(self.N, -1.0, np.float32) if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        self.mvScaleFactors = np.ascontiguousarray(mvScaleFactors if mvScaleFactors is not None else 1.2 ** np.arange(8), np.float32)
+        f32 = np.float32
+        self.fx, self.fy, self.cx, self.cy, self.mbf = f32(fx), f32(fy), f32(cx), f32(cy), f32(mbf)
+        self.mb = f32(self.mbf / self.fx)
+        self.mnMinX, self.mnMaxX, self.mnMinY, self.mnMaxY = (f32(v) for v in bounds)
+        self.mfGridElementWidthInv = f32(f32(self.FRAME_GRID_COLS) / f32(self.mnMaxX - self.mnMinX))
+        self.mfGridElementHeightInv = f32(f32(self.FRAME_GRID_ROWS) / f32(self.mnMaxY - self.mnMinY))
+        self.mTcw = np.eye(4, dtype=np.float32) if mTcw is None else np.ascontiguousarray(mTcw, np.float32)
+        self.mp_valid = np.zeros(self.N, bool)
+        self.mp_world = np.zeros((self.N, 3), np.float32)
+        self.mp_desc = np.zeros((self.N, 32), np.uint8)
+        self.mp_obs = np.zeros(self.N, bool)
+        self.mp_bad = np.zeros(self.N, bool)
+        self.mvbOutlier = np.zeros(self.N, bool)
+        self.mFeatVec = mFeatVec or {}
+        self.AssignFeaturesToGrid()
+
+    def AssignFeaturesToGrid(self):
+        """src/Frame.cc:334-349 + PosInGrid :572-582 (C round(): half away from zero)"""
+        self.mGrid = [[[] for _ in range(self.FRAME_GRID_ROWS)] for _ in range(self.FRAME_GRID_COLS)]
+        f32 = np.float32
+        for i in range(self.N):
+            px = float(f32(f32(self.mvKeysUn["x"][i] - self.mnMinX) * self.mfGridElementWidthInv))
+            py = float(f32(f32(self.mvKeysUn["y"][i] - self.mnMinY) * self.mfGridElementHeightInv))
+            gx, gy = int(np.floor(abs(px) + 0.5) * np.sign(px)), int(np.floor(abs(py) + 0.5) * np.sign(py))
+            if 0 <= gx < self.FRAME_GRID_COLS and 0 <= gy < self.FRAME_GRID_ROWS:
+                self.mGrid[gx][gy].append(i)
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        """src/Frame.cc:517-570"""
+        f32 = np.float32
+        x, y, r = f32(x), f32(y), f32(r)
+        C, R = self.FRAME_GRID_COLS, self.FRAME_GRID_ROWS
+        nMinCellX = max(0, int(np.floor(f32(f32(f32(x - self.mnMinX) - r) * self.mfGridElementWidthInv))))
+        if nMinCellX >= C:
+            return []
+        nMaxCellX = min(C - 1, int(np.ceil(f32(f32(f32(x - self.mnMinX) + r) * self.mfGridElementWidthInv))))
+        if nMaxCellX < 0:
+            return []
+        nMinCellY = max(0, int(np.floor(f32(f32(f32(y - self.mnMinY) - r) * self.mfGridElementHeightInv))))
+        if nMinCellY >= R:
+            return []
+        nMaxCellY = min(R - 1, int(np.ceil(f32(f32(f32(y - self.mnMinY) + r) * self.mfGridElementHeightInv))))
+        if nMaxCellY < 0:
+            return []
+        bCheckLevels = (minLevel > 0) or (maxLevel >= 0)
+        out = []
+        kx, ky, ko = self.mvKeysUn["x"], self.mvKeysUn["y"], self.mvKeysUn["octave"]
+        for ix in range(nMinCellX, nMaxCellX + 1):
+            for iy in range(nMinCellY, nMaxCellY + 1):
+                for j in self.mGrid[ix][iy]:
+                    if bCheckLevels:
+                        if ko[j] < minLevel:
+                            continue
+                        if maxLevel >= 0 and ko[j] > maxLevel:
+                            continue
+                    if abs(f32(kx[j] - x)) < r and abs(f32(ky[j] - y)) < r:
+                        out.append(j)
+        return out
+
+
+def _candidate_distances(descQ, lists, descT, context=None):
+    """GPU Hamming distances for CSR candidate lists; returns a list of uint16 arrays (one per query)."""
+    offs = np.zeros(len(lists) + 1, np.int32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    cand = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32) for l in lists]) if offs[-1] else np.zeros(0, np.int32), np.int32)
+    dist = np.zeros(int(offs[-1]), np.uint16)
+    dq, dt = _desc(descQ), _desc(descT)
+    if len(lists) and offs[-1]:
+        check(lib().olf_match_candidates(_ctx(context).handle, ptr(dq), dq.shape[0], ptr(dt), dt.shape[0], ptr(offs), ptr(cand), ptr(dist)),
+              "olf_match_candidates")
+    return [dist[offs[i]:offs[i + 1]] for i in range(len(lists))]
+
+
+def _c_round(v):
+    v = float(v)
+    return int(np.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+
+def ComputeThreeMaxima(histo):
+    """src/ORBmatcher.cc:1749-1790"""
+    max1 = max2 = max3 = 0
+    ind1 = ind2 = ind3 = -1
+    for i, h in enumerate(histo):
+        s = len(h)
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            ind3, ind2, ind1 = ind2, ind1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            ind3, ind2 = ind2, i
+        elif s > max3:
+            max3, ind3 = s, i
+    if max2 < np.float32(0.1) * np.float32(max1):
+        ind2 = ind3 = -1
+    elif max3 < np.float32(0.1) * np.float32(max1):
+        ind3 = -1
+    return ind1, ind2, ind3
+
+
+def _search_by_projection(self, CurrentFrame, LastFrame, th, bMono):
+    """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono),
+    src/ORBmatcher.cc:1330-1472.  Returns (nmatches, matches) with matches[i2] = index i of the LastFrame map point
+    assigned to CurrentFrame feature i2 (-1 = none); CurrentFrame.mp_valid / mp_obs are updated like mvpMapPoints."""
+    f32 = np.float32
+    HL = self.HISTO_LENGTH
+    rotHist = [[] for _ in range(HL)]
+    factor = f32(1.0) / f32(HL)
+    Rcw, tcw = CurrentFrame.mTcw[:3, :3], CurrentFrame.mTcw[:3, 3]
+    # cv::Mat products of CV_32F matrices accumulate in double and round once (cv::gemm's generic path)
+    twc = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
+    Rlw, tlw = LastFrame.mTcw[:3, :3], LastFrame.mTcw[:3, 3]
+    tlc = (Rlw.astype(np.float64) @ twc.astype(np.float64) + tlw.astype(np.float64)).astype(f32)
+    bForward = bool(tlc[2] > CurrentFrame.mb) and not bMono
+    bBackward = bool(-tlc[2] > CurrentFrame.mb) and not bMono
+    queries, lists, meta = [], [], []
+    for i in range(LastFrame.N):
+        if not LastFrame.mp_valid[i] or LastFrame.mvbOutlier[i]:
+            continue
+        x3Dc = (Rcw.astype(np.float64) @ LastFrame.mp_world[i].astype(np.float64) + tcw.astype(np.float64)).astype(f32)
+        xc, yc = x3Dc[0], x3Dc[1]
+        invzc = f32(1.0 / np.float64(x3Dc[2])) if x3Dc[2] != 0 else f32(np.inf)
+        if invzc < 0:
+            continue
+        u = f32(f32(f32(CurrentFrame.fx * xc) * invzc) + CurrentFrame.cx)
+        v = f32(f32(f32(CurrentFrame.fy * yc) * invzc) + CurrentFrame.cy)
+        if u < CurrentFrame.mnMinX or u > CurrentFrame.mnMaxX or v < CurrentFrame.mnMinY or v > CurrentFrame.mnMaxY:
+            continue
+        nLastOctave = int(LastFrame.mvKeys["octave"][i])
+        radius = f32(f32(th) * CurrentFrame.mvScaleFactors[nLastOctave])
+        if bForward:
+            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nLastOctave)
+        elif bBackward:
+            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, 0, nLastOctave)
+        else:
+            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1)
+        if not idx:
+            continue
+        queries.append(i); lists.append(idx); meta.append((u, invzc, radius))
+    dists = _candidate_distances(LastFrame.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, CurrentFrame.mDescriptors,
+                                 self._context)
+    matches = np.full(CurrentFrame.N, -1, np.int32)
+    nmatches = 0
+    for qi, i in enumerate(queries):
+        u, invzc, radius = meta[qi]
+        bestDist, bestIdx2 = 256, -1
+        for i2, dist in zip(lists[qi], dists[qi]):
+            if CurrentFrame.mp_valid[i2] and CurrentFrame.mp_obs[i2]:
+                continue
+            if CurrentFrame.mvuRight[i2] > 0:
+                ur = f32(u - f32(CurrentFrame.mbf * invzc))
+                if abs(f32(ur - CurrentFrame.mvuRight[i2])) > radius:
+                    continue
+            if int(dist) < bestDist:
+                bestDist, bestIdx2 = int(dist), i2
+        if bestDist <= self.TH_HIGH:
+            CurrentFrame.mp_valid[bestIdx2] = True
+            CurrentFrame.mp_obs[bestIdx2] = LastFrame.mp_obs[i]
+            matches[bestIdx2] = i
+            nmatches += 1
+            if self.mbCheckOrientation:
+                rot = f32(LastFrame.mvKeysUn["angle"][i] - CurrentFrame.mvKeysUn["angle"][bestIdx2])
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = _c_round(f32(rot * factor))
+                if b == HL:
+                    b = 0
+                rotHist[b].append(bestIdx2)
+    if self.mbCheckOrientation:
+        ind = ComputeThreeMaxima(rotHist)
+        for b in range(HL):
+            if b not in ind:
+                for j in rotHist[b]:
+                    CurrentFrame.mp_valid[j] = False
+                    matches[j] = -1
+                    nmatches -= 1
+    return nmatches, matches
+
+
+def _search_by_bow(self, pKF, F):
+    """int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290.
+    Returns (nmatches, vpMapPointMatches) with vpMapPointMatches[iF] = KF feature index whose map point was matched (-1 = none)."""
+    f32 = np.float32
+    HL = self.HISTO_LENGTH
+    rotHist = [[] for _ in range(HL)]
+    factor = f32(1.0) / f32(HL)
+    common = sorted(set(pKF.mFeatVec) & set(F.mFeatVec))       # the merge-join of the two ordered maps visits exactly these nodes
+    queries, lists = [], []
+    for node in common:
+        for realIdxKF in pKF.mFeatVec[node]:
+            if not pKF.mp_valid[realIdxKF] or pKF.mp_bad[realIdxKF]:
+                continue
+            queries.append(realIdxKF); lists.append(list(F.mFeatVec[node]))
+    dists = _candidate_distances(pKF.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, F.mDescriptors, self._context)
+    matched = np.full(F.N, -1, np.int32)
+    nmatches = 0
+    for qi, realIdxKF in enumerate(queries):
+        bestDist1, bestIdxF, bestDist2 = 256, -1, 256
+        for realIdxF, dist in zip(lists[qi], dists[qi]):
+            if matched[realIdxF] >= 0:
+                continue
+            dist = int(dist)
+            if dist < bestDist1:
+                bestDist2, bestDist1, bestIdxF = bestDist1, dist, realIdxF
+            elif dist < bestDist2:
+                bestDist2 = dist
+        if bestDist1 <= self.TH_LOW and f32(bestDist1) < f32(self.mfNNratio) * f32(bestDist2):
+            matched[bestIdxF] = realIdxKF
+            if self.mbCheckOrientation:
+                rot = f32(pKF.mvKeysUn["angle"][realIdxKF] - F.mvKeys["angle"][bestIdxF])
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = _c_round(f32(rot * factor))
+                if b == HL:
+                    b = 0
+                rotHist[b].append(bestIdxF)
+            nmatches += 1
+    if self.mbCheckOrientation:
+        ind = ComputeThreeMaxima(rotHist)
+        for b in range(HL):
+            if b in ind:
+                continue
+            for j in rotHist[b]:
+                matched[j] = -1
+                nmatches -= 1
+    return nmatches, matched
+
+
+ORBmatcher.SearchByProjection = _search_by_projection
+ORBmatcher.SearchByBoW = _search_by_bow

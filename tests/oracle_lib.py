@@ -201,3 +201,37 @@ def stereo_lines(klL, descL, klR, descR, w, h, sp):
     le = np.zeros((nL, 3), np.float64)
     _L.orc_stereo_lines(_p(klL), _p(descL), nL, _p(klR), _p(descR), nR, w, h, C.byref(sp), _p(m), _p(disp), _p(le))
     return m, disp, le
+
+
+def search_by_projection(cur, last, th, bMono=False, checkOri=True):
+    """cur/last: orb_line_slam_amd.FrameView; cur's map point state is copied, not modified. -> (nmatches, matches)"""
+    cv, co = cur.mp_valid.astype(np.uint8).copy(), cur.mp_obs.astype(np.uint8).copy()
+    cam = np.array([cur.fx, cur.fy, cur.cx, cur.cy, cur.mbf, cur.mnMinX, cur.mnMaxX, cur.mnMinY, cur.mnMaxY], np.float32)
+    matches = np.full(cur.N, -1, np.int32)
+    a = lambda x, dt=None: np.ascontiguousarray(x if dt is None else x.astype(dt))
+    args = [a(cur.mvKeysUn), a(cur.mDescriptors), a(cur.mvuRight), None, cv, co, a(cur.mTcw), a(last.mvKeysUn), None, a(last.mp_valid, np.uint8),
+            a(last.mp_world), a(last.mp_desc), a(last.mp_obs, np.uint8), a(last.mvbOutlier, np.uint8), a(last.mTcw), cam, a(cur.mvScaleFactors)]
+    _L.orc_search_by_projection.restype = C.c_int
+    n = _L.orc_search_by_projection(_p(args[0]), _p(args[1]), _p(args[2]), cur.N, _p(cv), _p(co), _p(args[6]), _p(args[7]), last.N, _p(args[9]),
+                                    _p(args[10]), _p(args[11]), _p(args[12]), _p(args[13]), _p(args[14]), _p(cam), _p(args[16]), C.c_float(th),
+                                    int(bMono), int(checkOri), _p(matches))
+    return n, matches
+
+
+def _featvec_csr(fv):
+    nodes = np.array(sorted(fv), np.int32)
+    offs = np.zeros(len(nodes) + 1, np.int32)
+    offs[1:] = np.cumsum([len(fv[k]) for k in nodes])
+    idx = np.array([i for k in nodes for i in fv[k]], np.int32)
+    return nodes, offs, idx
+
+
+def search_by_bow(kf, f, nnratio, checkOri=True):
+    kn, ko, ki = _featvec_csr(kf.mFeatVec)
+    fn, fo, fi = _featvec_csr(f.mFeatVec)
+    matched = np.full(f.N, -1, np.int32)
+    a = np.ascontiguousarray
+    n = _L.orc_search_by_bow(_p(a(kf.mvKeysUn)), _p(a(kf.mDescriptors)), _p(a(kf.mp_valid.astype(np.uint8))), _p(a(kf.mp_bad.astype(np.uint8))),
+                             _p(kn), _p(ko), _p(ki), len(kn), _p(a(f.mvKeys)), _p(a(f.mDescriptors)), f.N, _p(fn), _p(fo), _p(fi), len(fn),
+                             C.c_float(nnratio), int(checkOri), _p(matched))
+    return n, matched
