@@ -71,3 +71,46 @@ def test_stereo_frames(oracle, w, h, nf, nl, fx, bf):
         assert np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
         assert np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64))
         assert (m >= 0).sum() > 20 and (disp[:, 0] >= 0).sum() > 10
+
+
+def test_stereo_frames_sweep_kitti(oracle):
+    """wider seed sweep at the benchmark configuration (1242x375, 2000 ORB + 500 LBD): everything bit-identical for every pair"""
+    w, h = 1242, 375
+    p = oracle.full_params(2000, 500)
+    n = 12
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=n)
+    imgs = synth.stereo_batch(7000, n, w, h)          # the bench's own inputs
+    f = fe.frames(imgs)
+    for i in range(n):
+        g = f.pair(i)
+        o = oracle.stereo_points(imgs[2 * i], imgs[2 * i + 1], p)
+        assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"]), i
+        assert np.array_equal(g["mvKeysRight"], o["kpsR"]) and np.array_equal(g["mDescriptorsRight"], o["descR"]), i
+        assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32)), i
+        assert np.array_equal(g["mvDepth"].view(np.uint32), o["depth"].view(np.uint32)), i
+        ol, orr = oracle.line_extract(imgs[2 * i], p.line), oracle.line_extract(imgs[2 * i + 1], p.line)
+        _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+        _cmp_keylines(g["mvKeysRight_Line"], orr["kls"])
+        assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"]), i
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        assert np.array_equal(g["line_matches_12"], m), i
+        assert np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32)), i
+        assert np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64)), i
+
+
+def test_line_edge_cases(oracle):
+    ex = ola.Lineextractor(100, 0.025)
+    k, d = ex(np.full((240, 320), 128, np.uint8))                     # flat image: no gradient, no lines, no crash
+    assert len(k) == 0 and d.shape == (0, 32)
+    img = np.zeros((240, 320), np.uint8); img[:, 160:] = 255          # one perfect vertical edge
+    k, d = ex(img)
+    p = oracle.full_params(500, 100)
+    o = oracle.line_extract(img, p.line)
+    _cmp_keylines(k, o["kls"])
+    assert np.array_equal(d, o["desc"]) and len(k) >= 1
+    rng = np.random.default_rng(0)
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)          # pure noise: thousands of tiny regions
+    k, d = ex(noise)
+    o = oracle.line_extract(noise, p.line)
+    _cmp_keylines(k, o["kls"])
+    assert np.array_equal(d, o["desc"])

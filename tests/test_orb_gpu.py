@@ -58,3 +58,19 @@ def test_orb_flat_image_has_no_keypoints():
     ex = ola.ORBextractor(500, 1.2, 8, 20, 7)
     k, d = ex(np.full((240, 320), 77, np.uint8))
     assert len(k) == 0 and d.shape == (0, 32)
+
+
+def test_orb_noise_and_1080p(oracle):
+    """stress the octree (many candidates, equal-count ties) and the largest BASELINE size (1920x1080, 4000 features)"""
+    rng = np.random.default_rng(1)
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    ex = ola.ORBextractor(1000, 1.2, 8, 20, 7)
+    gk, gd = ex(noise)
+    o = oracle.orb_extract(noise, oracle.orb_params(1000))
+    _compare(gk, gd, o["kps"], o["desc"])
+    left, _ = synth.stereo_pair(5, 1920, 1080)
+    ex2 = ola.ORBextractor(4000, 1.2, 8, 20, 7)
+    gk, gd = ex2(left)
+    o = oracle.orb_extract(left, oracle.orb_params(4000), cap=5000)
+    _compare(gk, gd, o["kps"], o["desc"])
+    assert len(gk) >= 3900
