@@ -90,56 +90,97 @@ __device__ __forceinline__ bool run9(uint32_t m)   // >= 9 contiguous set bits i
     return (r & 0xffffu) != 0;
 }
 
-constexpr int FT_W = 64, FT_H = 16, FT_PITCH = 72;   // LDS tile (64+6) x (16+6), pitch 72
+constexpr int FT_W = 128, FT_H = 32;                 // output tile; LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+34
+constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
+
+// byte `idx` (0..11) of three consecutive little-endian words
+#define FB(w0, w1, w2, idx) ((int)((((idx) < 4 ? (w0) : (idx) < 8 ? (w1) : (w2)) >> (8 * ((idx) & 3))) & 0xffu))
 
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
                                                     int pyrBytes, LevelGeom L, int minTh)
 {
-    __shared__ uint8_t tile[(FT_H + 6) * FT_PITCH];
+    __shared__ uint32_t tile[FT_INH * FT_INW];
     const int img = blockIdx.z;
-    // scores are needed on x in [minBorder+3, maxBorderX-3), y likewise
-    const int x0 = kMinBorder + 3 + blockIdx.x * FT_W, y0 = kMinBorder + 3 + blockIdx.y * FT_H;
-    const int xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
+    // scores are needed on x in [minBorder+3, maxBorderX-3), y likewise; tiles start at x = 16 (4-byte aligned rows)
+    const int x0 = kMinBorder + blockIdx.x * FT_W, y0 = kMinBorder + 3 + blockIdx.y * FT_H;
+    const int xBeg = kMinBorder + 3, xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
     const uint8_t* src = pyr + (size_t)img * pyrBytes + L.offset;
-    for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-        const int ty = i / (FT_W + 6), tx = i - ty * (FT_W + 6);
-        const int gx = min(x0 - 3 + tx, L.w - 1), gy = min(y0 - 3 + ty, L.h - 1);
-        tile[ty * FT_PITCH + tx] = src[(size_t)gy * L.pitch + gx];
+    for (int i = threadIdx.x; i < FT_INH * FT_INW; i += 256) {
+        const int r = i / FT_INW, j = i - r * FT_INW;
+        const int gy = min(y0 - 3 + r, L.h - 1);
+        const int xw = min(x0 - 4 + 4 * j, L.pitch - 4);          // rows are 64-byte aligned and padded to the pitch
+        tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw);
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+    __shared__ unsigned short s_list[FT_W * FT_H];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4;
     uint8_t* dst = score + (size_t)img * pyrBytes + L.offset;
+    // ---- phase A: corner test of the thread's 4x4 pixels (tile rows ry0 .. ry0+9, tile bytes 4q .. 4q+11; pixel p sits
+    // at byte 4q+4+p).  Corners are queued; every word of the score map is cleared.
+    uint32_t w[10][3];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ly = ly0 + 4 * r;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= xEnd || gy >= yEnd) continue;
-        const uint8_t* c = &tile[(ly + 3) * FT_PITCH + lx + 3];
+    for (int r = 0; r < 10; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[r][k] = tile[(ry0 + r) * FT_INW + q + k];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int gy = y0 + ry0 + rr;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int gx = x0 + 4 * q + p;
+            const int c = rr + 3, b = p + 4;                       // centre row in w[], centre byte
+            const int v = FB(w[c][0], w[c][1], w[c][2], b);
+            // a 9-arc of the 16-ring always contains two of the four compass points: cheap rejection for flat areas
+            const int n0 = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b), n8 = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b);
+            const int n4 = FB(w[c][0], w[c][1], w[c][2], b + 3), n12 = FB(w[c][0], w[c][1], w[c][2], b - 3);
+            const int hiT = v + minTh, loT = v - minTh;
+            const int nb = (n0 > hiT) + (n4 > hiT) + (n8 > hiT) + (n12 > hiT), nd = (n0 < loT) + (n4 < loT) + (n8 < loT) + (n12 < loT);
+            if ((nb >= 2 || nd >= 2) && gx >= xBeg && gx < xEnd && gy < yEnd) {
+                int ring[16];
+                ring[0] = n0; ring[4] = n4; ring[8] = n8; ring[12] = n12;
+                ring[1] = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b + 1);  ring[2] = FB(w[c + 2][0], w[c + 2][1], w[c + 2][2], b + 2);
+                ring[3] = FB(w[c + 1][0], w[c + 1][1], w[c + 1][2], b + 3);  ring[5] = FB(w[c - 1][0], w[c - 1][1], w[c - 1][2], b + 3);
+                ring[6] = FB(w[c - 2][0], w[c - 2][1], w[c - 2][2], b + 2);  ring[7] = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b + 1);
+                ring[9] = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b - 1);  ring[10] = FB(w[c - 2][0], w[c - 2][1], w[c - 2][2], b - 2);
+                ring[11] = FB(w[c - 1][0], w[c - 1][1], w[c - 1][2], b - 3); ring[13] = FB(w[c + 1][0], w[c + 1][1], w[c + 1][2], b - 3);
+                ring[14] = FB(w[c + 2][0], w[c + 2][1], w[c + 2][2], b - 2); ring[15] = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b - 1);
+                uint32_t dark = 0, bright = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    dark |= (uint32_t)(ring[k] < loT) << k;
+                    bright |= (uint32_t)(ring[k] > hiT) << k;
+                }
+                if (run9(dark) || run9(bright)) s_list[atomicAdd(&s_n, 1)] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
+            }
+        }
+        const int gx0 = x0 + 4 * q;
+        if (gy < yEnd && gx0 < xEnd) *reinterpret_cast<uint32_t*>(dst + (size_t)gy * L.pitch + gx0) = 0u;
+    }
+    __syncthreads();
+    // ---- phase B: scores of the queued corners, one corner per thread (dense lanes)
+    const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+    const int nC = s_n;
+    for (int i = threadIdx.x; i < nC; i += 256) {
+        const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
+        const uint8_t* c = tb + (ty + 3) * (FT_INW * 4) + tx + 4;
+        constexpr int P = FT_INW * 4;
         const int v = c[0];
-        int ring[16];
-        ring[0] = c[3 * FT_PITCH];       ring[1] = c[3 * FT_PITCH + 1];   ring[2] = c[2 * FT_PITCH + 2];
-        ring[3] = c[FT_PITCH + 3];       ring[4] = c[3];                  ring[5] = c[-FT_PITCH + 3];
-        ring[6] = c[-2 * FT_PITCH + 2];  ring[7] = c[-3 * FT_PITCH + 1];  ring[8] = c[-3 * FT_PITCH];
-        ring[9] = c[-3 * FT_PITCH - 1];  ring[10] = c[-2 * FT_PITCH - 2]; ring[11] = c[-FT_PITCH - 3];
-        ring[12] = c[-3];                ring[13] = c[FT_PITCH - 3];      ring[14] = c[2 * FT_PITCH - 2];
-        ring[15] = c[3 * FT_PITCH - 1];
-        uint32_t dark = 0, bright = 0;
+        int d[16], ndv[16];
+        d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+        d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+        d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+        d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            dark |= (uint32_t)(ring[k] < v - minTh) << k;
-            bright |= (uint32_t)(ring[k] > v + minTh) << k;
-        }
-        int s = 0;
-        if (run9(dark) || run9(bright)) {
-            int d[16], nd[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { d[k] = v - ring[k]; nd[k] = -d[k]; }
-            s = max(arc9_maxmin(d), arc9_maxmin(nd)) - 1;
-            if (s < minTh) s = 0;
-        }
-        dst[(size_t)gy * L.pitch + gx] = (uint8_t)s;
+        for (int k = 0; k < 16; ++k) ndv[k] = -d[k];
+        int sc = max(arc9_maxmin(d), arc9_maxmin(ndv)) - 1;
+        if (sc < minTh) sc = 0;
+        dst[(size_t)(y0 + ty) * L.pitch + x0 + tx] = (uint8_t)sc;
     }
 }
+#undef FB
 
 // ---------------------------------------------------------------------------------------------
 // Per-cell detection (src/ORBextractor.cc:791-831): cv::FAST(cell sub-image, iniThFAST, nms) and,
@@ -150,9 +191,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(64) void k_cells(const uint8_t* __restrict__ score, const OrbGeom* __restrict__ gp,
                                               uint32_t* __restrict__ cells, int* __restrict__ cellCount)
 {
-    __shared__ uint8_t t[64 * 64];                // (ih+2) x (iw+2), pitch 64
-    __shared__ unsigned long long keepM[64], iniM[64];
-    __shared__ int rowBase[64];
+    // lane = one column of the cell interior (<= 60 wide); rows stream through a 3-row register window, horizontal
+    // neighbours come from the adjacent lanes (DPP shuffles) -- no LDS.  Row y's keep / ini ballot is parked in lane y.
     const OrbGeom& g = *gp;
     const int img = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
     int l = 0;
@@ -165,46 +205,47 @@ __global__ __launch_bounds__(64) void k_cells(const uint8_t* __restrict__ score,
     const int maxX = min(iniX + L.wCell + 6, L.maxBorderX), maxY = min(iniY + L.hCell + 6, L.maxBorderY);
     const int ix0 = iniX + 3, iy0 = iniY + 3, iw = maxX - 3 - ix0, ih = maxY - 3 - iy0;
     if (iw <= 0 || ih <= 0) { if (lane == 0) *cnt = 0; return; }
-    const uint8_t* src = score + (size_t)img * g.pyrBytes + L.offset;
-    for (int i = lane; i < (ih + 2) * 64; i += 64) {
-        const int ty = i >> 6, tx = i & 63;
-        uint8_t v = 0;
-        if (tx >= 1 && tx <= iw && ty >= 1 && ty <= ih) v = src[(size_t)(iy0 + ty - 1) * L.pitch + ix0 + tx - 1];
-        t[i] = v;
-    }
-    __syncthreads();
-    unsigned long long anyIni = 0;
+    const uint8_t* src = score + (size_t)img * g.pyrBytes + L.offset + (size_t)iy0 * L.pitch + ix0 + lane;
+    const bool col = lane < iw;
+    int prev = 0, cur = col ? (int)src[0] : 0, nxt;
+    unsigned long long myKeep = 0, myIni = 0;
     for (int y = 0; y < ih; ++y) {
-        bool keep = false, ini = false;
-        if (lane < iw) {
-            const uint8_t* c = &t[(y + 1) * 64 + lane + 1];
-            const int s = c[0];
-            keep = s > 0 && s > c[-1] && s > c[1] && s > c[-65] && s > c[-64] && s > c[-63] && s > c[63] && s > c[64] && s > c[65];
-            ini = keep && s >= g.iniTh;
-        }
-        const unsigned long long km = __ballot(keep), im = __ballot(ini);
-        if (lane == 0) { keepM[y] = km; iniM[y] = im; }
-        anyIni |= im;
+        nxt = (col && y + 1 < ih) ? (int)src[(size_t)(y + 1) * L.pitch] : 0;
+        // max over the 8 neighbours; everything outside the cell interior counts as 0 (lanes >= iw hold 0, lane -1 / 64 masked)
+        const int v3 = max(prev, nxt);                       // vertical neighbours of this column
+        const int c3 = max(v3, cur);                         // column maximum incl. the centre (for the side columns)
+        int lft = __shfl_up(c3, 1), rgt = __shfl_down(c3, 1);
+        if (lane == 0) lft = 0;
+        if (lane == 63) rgt = 0;
+        const int nb = max(v3, max(lft, rgt));
+        const bool keep = cur > 0 && cur > nb;
+        const unsigned long long km = __ballot(keep), im = __ballot(keep && cur >= g.iniTh);
+        if (lane == y) { myKeep = km; myIni = im; }
+        prev = cur; cur = nxt;
     }
-    __syncthreads();
-    const unsigned long long* chosen = anyIni ? iniM : keepM;
-    int c = (lane < ih) ? __popcll(chosen[lane]) : 0;
+    const bool anyIni = __ballot(myIni != 0) != 0;
+    const unsigned long long chosen = anyIni ? myIni : myKeep;      // lane y: the surviving columns of row y
+    const int c = __popcll(chosen);
     int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(inc, o);
+        const int v = __shfl_up(inc, o);
         if (lane >= o) inc += v;
     }
-    rowBase[lane] = inc - c;
-    const int total = __shfl(inc, 63);
-    __syncthreads();
+    const int myBase = inc - c, total = __shfl(inc, 63);
     uint32_t* slot = cells + ((size_t)img * g.totalCells + cell) * g.cellCap;
-    for (int y = 0; y < ih; ++y) {
-        const unsigned long long m = chosen[y];
-        if (lane < iw && ((m >> lane) & 1ull)) {
-            const int pos = rowBase[y] + __popcll(m & ((1ull << lane) - 1ull));
-            const int s = t[(y + 1) * 64 + lane + 1];
-            slot[pos] = ((uint32_t)(ix0 + lane - kMinBorder) << 20) | ((uint32_t)(iy0 + y - kMinBorder) << 8) | (uint32_t)s;
+    unsigned long long rows = __ballot(chosen != 0);
+    while (rows) {
+        const int y = __builtin_ctzll(rows);
+        rows &= rows - 1;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)chosen, y);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(chosen >> 32), y);
+        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        const int base = __builtin_amdgcn_readlane(myBase, y);
+        if ((m >> lane) & 1ull) {
+            const int sc = src[(size_t)y * L.pitch];
+            slot[base + __popcll(m & ((1ull << lane) - 1ull))] =
+                ((uint32_t)(ix0 + lane - kMinBorder) << 20) | ((uint32_t)(iy0 + y - kMinBorder) << 8) | (uint32_t)sc;
         }
     }
     if (lane == 0) *cnt = total;
@@ -291,7 +332,7 @@ int launch_orb_fast(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipS
 {
     for (int l = 0; l < g.nlevels; ++l) {
         const LevelGeom& L = g.lv[l];
-        const int fw = L.maxBorderX - 3 - (kMinBorder + 3), fh = L.maxBorderY - 3 - (kMinBorder + 3);
+        const int fw = L.maxBorderX - 3 - kMinBorder, fh = L.maxBorderY - 3 - (kMinBorder + 3);
         if (fw <= 0 || fh <= 0) continue;
         hipLaunchKernelGGL(k_fast_score, dim3((fw + FT_W - 1) / FT_W, (fh + FT_H - 1) / FT_H, n_images), dim3(256), 0, s, b.pyr,
                            b.score, g.pyrBytes, L, g.minTh);
