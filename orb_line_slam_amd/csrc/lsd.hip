@@ -21,7 +21,7 @@ constexpr double kPI = 3.1415926535897932384626433832795;
 constexpr double kDegToRads = kPI / 180;
 constexpr double kM32PI = (3 * kPI) / 2, kM2PI = 2 * kPI;
 // grad word: bits 0-10 gx, 11-21 gy (11-bit two's complement, |g| <= 510), bit 30 NOTDEF, bit 31 USED
-constexpr unsigned kNotDef = 0x40000000u, kUsed = 0x80000000u;
+constexpr unsigned kNotDef = 0x40000000u, kUsed = 0x80000000u, kIso = 0x00400000u;   // bit 22: no neighbour is aligned with this pixel
 __device__ __forceinline__ int unpack_gx(uint32_t p) { return ((int)(p << 21)) >> 21; }
 __device__ __forceinline__ int unpack_gy(uint32_t p) { return ((int)(p << 10)) >> 21; }
 __device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0x7ffu) | (((uint32_t)gy & 0x7ffu) << 11); }
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 
 // ll_angle, second half: bin of every defined pixel -> sort key (one atomic per block)
 __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
-                                                  const int* __restrict__ maxN, uint32_t* __restrict__ keys, int* __restrict__ keyCount)
+                                                  const int* __restrict__ maxN, uint32_t* __restrict__ keys, int* __restrict__ keyCount,
+                                                  uint32_t* __restrict__ degbuf)
 {
     __shared__ uint32_t s_keys[LG_CHUNK];
     __shared__ int s_cnt, s_base;
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ g
                 const int bin = (int)(norm * bin_coef);
                 key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
                 def = true;
+                // level-line angle (degrees) of the defined pixel, kept for k_lsd_iso in the (not yet used) FIFO buffer
+                degbuf[(size_t)img * g.Ps + idx] = __float_as_uint(dev_fastAtan2((float)gx, (float)(-gy)));
             }
         }
         const unsigned long long m = __ballot(def);
@@ -193,6 +196,39 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ g
     __syncthreads();
     const int cnt = s_cnt, base = s_base;
     for (int i = threadIdx.x; i < cnt; i += 256) keys[(size_t)img * g.Ps + base + i] = s_keys[i];
+}
+
+// A seed whose 8 neighbours are all undefined or not aligned with the seed's own angle can never grow: its region is
+// the seed alone (region_grow tests every neighbour against reg_angle == the seed angle and nothing is ever added), whatever
+// has been used before.  That is a static property of the gradient field; it is flagged here, in parallel, so that the
+// sequential agent can retire such seeds without running a growth step.
+__global__ __launch_bounds__(256) void k_lsd_iso(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
+                                                 const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
+                                                 const uint32_t* __restrict__ degbuf)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;      // dense over the defined pixels (the key list)
+    if (i >= keyCount[img * 32]) return;
+    uint32_t* grad = gradAll + (size_t)img * g.Ps;
+    const uint32_t* deg = degbuf + (size_t)img * g.Ps;
+    const int idx = (int)(keysAll[(size_t)img * g.Ps + i] & 0x3fffffu);
+    const int y = idx / g.Ws, x = idx - y * g.Ws;
+    const double a0 = d_mul((double)__uint_as_float(deg[idx]), kDegToRads);
+    bool iso = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k == 4) continue;
+        const int xx = x + (k % 3) - 1, yy = y + (k / 3) - 1;
+        if (xx < 0 || yy < 0 || xx >= g.Ws || yy >= g.Hs) continue;
+        const int na = yy * g.Ws + xx;
+        if (grad[na] & kNotDef) continue;
+        const double a = d_mul((double)__uint_as_float(deg[na]), kDegToRads);
+        double n_theta = d_sub(a0, a);
+        if (n_theta < 0) n_theta = -n_theta;
+        if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
+        if (n_theta <= g.prec) iso = false;
+    }
+    if (iso) grad[idx] |= kIso;      // neighbours only read the NOTDEF bit of this word
 }
 
 __global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, unsigned* __restrict__ b, unsigned* __restrict__ e)
@@ -253,8 +289,8 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     *sn = so; *cs = co;
 }
 
-constexpr int RING = 1024;   // FIFO window of the growing region kept in LDS
-constexpr int PEND = 2048;   // hash table of pixels whose USED store may not be visible to a load yet
+constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
+constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
 
 __device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ double rlane_d(double v, int l)
@@ -275,8 +311,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
-    __shared__ int s_x[64], s_y[64];
-    __shared__ double s_w[64];
+    __shared__ double s_w[64], s_a[64], s_b[64];
     const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     const int Ws = g.Ws, Hs = g.Hs;
@@ -301,8 +336,26 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
     for (int base = 0; base < nkeys; base += 64) {
         const bool valid = base + lane < nkeys;
         const int addr = valid ? (int)(keys[base + lane] & 0x3fffffu) : 0;
-        unsigned long long mask = __ballot(valid && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+        const uint32_t wseed = valid ? grad[addr] : kUsed;
+        const bool isoSeed = (wseed & kIso) != 0;
+        unsigned long long mask = __ballot(valid && !(wseed & kUsed) && s_pend[addr & (PEND - 1)] != addr);
         while (mask) {
+            // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
+            {
+                const unsigned long long isoM = __ballot(isoSeed) & mask;
+                const unsigned long long grow = mask & ~isoM;
+                const unsigned long long lead = isoM & (grow ? ((1ull << __builtin_ctzll(grow)) - 1ull) : ~0ull);
+                if (lead) {
+                    const bool mine = (lead >> lane) & 1ull;
+                    const int slot = addr & (PEND - 1);
+                    if (__ballot(mine && s_pend[slot] != -1)) PEND_FLUSH();
+                    if (mine) { grad[addr] = wseed | kUsed; s_pend[slot] = addr; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (__ballot(mine && s_pend[slot] != addr)) PEND_FLUSH();
+                    mask &= ~lead;
+                    if (!mask) break;
+                }
+            }
             const int l = __builtin_ctzll(mask);
             const int seed = rlane(addr, l);
             // ---- region_grow ------------------------------------------------------------------
@@ -410,11 +463,15 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                         wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
                         xw = d_mul((double)px, wt); yw = d_mul((double)py, wt);
                     }
-                    for (int q = 0; q < cnt; ++q) {
-                        x = d_add(x, rlane_d(xw, q));
-                        y = d_add(y, rlane_d(yw, q));
-                        sum = d_add(sum, rlane_d(wt, q));
+                    s_w[lane] = wt; s_a[lane] = xw; s_b[lane] = yw;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+                    for (int q = 0; q < cnt; ++q) {       // wave-uniform LDS reads (broadcast), additions in growth order
+                        x = d_add(x, s_a[q]);
+                        y = d_add(y, s_b[q]);
+                        sum = d_add(sum, s_w[q]);
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 x = x / sum; y = y / sum;
                 double Ixx = 0, Iyy = 0, Ixy = 0;
@@ -430,11 +487,15 @@ __global__ __launch_bounds__(64) void k_lsd_grow(const LineGeom* __restrict__ gp
                         const double ex = d_sub((double)px, x), ey = d_sub((double)py, y);
                         t1 = d_mul(d_mul(ey, ey), wt); t2 = d_mul(d_mul(ex, ex), wt); t3 = d_mul(d_mul(ex, ey), wt);
                     }
+                    s_w[lane] = t1; s_a[lane] = t2; s_b[lane] = t3;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
                     for (int q = 0; q < cnt; ++q) {
-                        Ixx = d_add(Ixx, rlane_d(t1, q));
-                        Iyy = d_add(Iyy, rlane_d(t2, q));
-                        Ixy = d_sub(Ixy, rlane_d(t3, q));
+                        Ixx = d_add(Ixx, s_w[q]);
+                        Iyy = d_add(Iyy, s_a[q]);
+                        Ixy = d_sub(Ixy, s_b[q]);
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 const double dI = d_sub(Ixx, Iyy);
                 const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
@@ -542,7 +603,8 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }
     hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN);
-    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount);
+    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount, b.region);
+    hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
     size_t tb = b.sortTempBytes;
