@@ -168,8 +168,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # the only collective of the design: gather the (trimmed) feature records to rank 0, outside the timed region
-        from orb_line_slam_amd.distributed import gather_counts
-        gather_counts(counts, lcounts, dist)
+        try:
+            from orb_line_slam_amd.distributed import gather_counts
+            gather_counts(counts, lcounts, dist)
+        except Exception as e:   # the gather is not part of the measurement: report, do not lose the bench line
+            print(f"[rank {rank}] gather_to_rank0 failed: {e}", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_pairs = world * B * args.steps

@@ -45,6 +45,21 @@ int olf_profile_stage_count(void);
 const char* olf_profile_stage_name(int stage);
 int olf_profile_read(olf_ctx* ctx, double* total_ms, int32_t* calls);   /* arrays of olf_profile_stage_count() */
 
+/* ---- input conditioning ahead of the path ------------------------------------------------- */
+enum { OLF_RGB2GRAY = 0, OLF_BGR2GRAY = 1, OLF_RGBA2GRAY = 2, OLF_BGRA2GRAY = 3 };
+/* cv::cvtColor(img, gray, CV_*2GRAY) of Tracking::GrabImageStereo (src/Tracking.cc:193-218): n_images interleaved 8-bit
+ * images (3 or 4 channels) of the context's size -> n_images gray images.  Device pointers. */
+int olf_cvt_gray_dev(olf_ctx* ctx, const uint8_t* d_src, int code, int n_images, uint8_t* d_gray, void* stream);
+/* cv::remap(src, dst, M1, M2, INTER_LINEAR) with two CV_32FC1 maps and BORDER_CONSTANT 0, the EuRoC rectification of
+ * Examples/PL/PL_stereo_euroc.cc:136-137.  src: n_images images src_w x src_h (stride src_w); maps: dst_w*dst_h floats each
+ * (shared by all images, e.g. one call per camera); dst: n_images images dst_w x dst_h.  Device pointers. */
+int olf_remap_linear_dev(olf_ctx* ctx, const uint8_t* d_src, int src_w, int src_h, const float* d_mapx, const float* d_mapy, int dst_w,
+                         int dst_h, int n_images, uint8_t* d_dst, void* stream);
+/* host-buffer forms (copy, run, copy back, block) */
+int olf_cvt_gray(olf_ctx* ctx, const uint8_t* src, int code, int n_images, uint8_t* gray);
+int olf_remap_linear(olf_ctx* ctx, const uint8_t* src, int src_w, int src_h, const float* mapx, const float* mapy, int dst_w, int dst_h,
+                     int n_images, uint8_t* dst);
+
 /* ---- ORBextractor (include/ORBextractor.h:52-118, src/ORBextractor.cc) -------------------- */
 /* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:68-91) + mnFeaturesPerLevel; arrays of nlevels */

@@ -101,6 +101,8 @@ def lib():
         L.olf_stereo_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers)]
         L.olf_match_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_match_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_cvt_gray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.olf_remap_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.olf_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.olf_profile_reset.argtypes = [C.c_void_p]
         L.olf_profile_stage_name.restype = C.c_char_p

@@ -475,6 +475,53 @@ int olf_match_candidates(olf_ctx* c, const uint8_t* descQ, int nQ, const uint8_t
     return OLF_OK;
 }
 
+int olf_cvt_gray_dev(olf_ctx* c, const uint8_t* d_src, int code, int n_images, uint8_t* d_gray, void* stream)
+{
+    if (!c || !d_src || !d_gray || code < 0 || code > 3 || n_images < 0) { set_error("olf_cvt_gray_dev: bad argument"); return OLF_ERR_INVALID; }
+    if (n_images == 0) return OLF_OK;
+    return launch_cvt_gray(d_src, d_gray, c->W, c->H, code, n_images, stream ? (hipStream_t)stream : c->stream);
+}
+
+int olf_remap_linear_dev(olf_ctx* c, const uint8_t* d_src, int sw, int sh, const float* d_mapx, const float* d_mapy, int dw, int dh, int n_images,
+                         uint8_t* d_dst, void* stream)
+{
+    if (!c || !d_src || !d_mapx || !d_mapy || !d_dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || n_images < 0) { set_error("olf_remap_linear_dev: bad argument"); return OLF_ERR_INVALID; }
+    if (n_images == 0) return OLF_OK;
+    return launch_remap_linear(d_src, sw, sh, d_mapx, d_mapy, dw, dh, d_dst, n_images, stream ? (hipStream_t)stream : c->stream);
+}
+
+int olf_cvt_gray(olf_ctx* c, const uint8_t* src, int code, int n_images, uint8_t* gray)
+{
+    if (!c || !src || !gray || code < 0 || code > 3 || n_images < 0) { set_error("olf_cvt_gray: bad argument"); return OLF_ERR_INVALID; }
+    if (n_images == 0) return OLF_OK;
+    const size_t npx = (size_t)c->W * c->H * n_images, cn = code >= 2 ? 4 : 3;
+    void* st = nullptr;
+    OLF_TRY(scratch_get(c, 2, npx * (cn + 1) + 64, &st));
+    uint8_t* ds = (uint8_t*)st; uint8_t* dd = ds + ((npx * cn + 15) & ~(size_t)15);
+    OLF_HIP_CHECK(hipMemcpyAsync(ds, src, npx * cn, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_cvt_gray_dev(c, ds, code, n_images, dd, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(gray, dd, npx, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_remap_linear(olf_ctx* c, const uint8_t* src, int sw, int sh, const float* mapx, const float* mapy, int dw, int dh, int n_images, uint8_t* dst)
+{
+    if (!c || !src || !mapx || !mapy || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || n_images < 0) { set_error("olf_remap_linear: bad argument"); return OLF_ERR_INVALID; }
+    if (n_images == 0) return OLF_OK;
+    const size_t bs = ((size_t)sw * sh * n_images + 15) & ~(size_t)15, bm = (size_t)dw * dh * 4, bd = (size_t)dw * dh * n_images;
+    void* st = nullptr;
+    OLF_TRY(scratch_get(c, 2, bs + 2 * bm + bd + 64, &st));
+    uint8_t* ds = (uint8_t*)st; float* mx = (float*)(ds + bs); float* my = mx + (size_t)dw * dh; uint8_t* dd = (uint8_t*)(my + (size_t)dw * dh);
+    OLF_HIP_CHECK(hipMemcpyAsync(ds, src, (size_t)sw * sh * n_images, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(mx, mapx, bm, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(my, mapy, bm, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_remap_linear_dev(c, ds, sw, sh, mx, my, dw, dh, n_images, dd, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dst, dd, bd, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 int olf_hamming_matrix(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out)
 {
     if (!c || !out || nA < 0 || nB < 0 || (nA && !descA) || (nB && !descB)) { set_error("olf_hamming_matrix: bad argument"); return OLF_ERR_INVALID; }

@@ -126,6 +126,11 @@ bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int s
 int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,
                         int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s);
 
+// precond.hip
+int launch_cvt_gray(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n_images, hipStream_t s);
+int launch_remap_linear(const uint8_t* src, int sw, int sh, const float* mapx, const float* mapy, int dw, int dh, uint8_t* dst, int n_images,
+                        hipStream_t s);
+
 // match.hip
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
                          const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, int* d_bestKey,

@@ -1,0 +1,42 @@
+"""Input conditioning ahead of the feature path, on the GPU.
+
+  cvtColor(im, gray, CV_RGB2GRAY | CV_BGR2GRAY | CV_RGBA2GRAY | CV_BGRA2GRAY)   Tracking::GrabImageStereo, src/Tracking.cc:193-218
+  remap(im, rect, M1, M2, INTER_LINEAR)                                         Examples/PL/PL_stereo_euroc.cc:136-137
+"""
+import numpy as np
+from . import _lib
+from ._lib import check, lib, ptr
+
+RGB2GRAY, BGR2GRAY, RGBA2GRAY, BGRA2GRAY = 0, 1, 2, 3
+
+
+def _ctx(context, w, h):
+    return context if context is not None else _lib.Context(_lib.default_params(), w, h, 1)
+
+
+def cvtColor(images, code, context=None):
+    """images: (n, H, W, 3|4) uint8 -> (n, H, W) uint8.  Mirrors mbRGB handling: code RGB2GRAY when Camera.RGB = 1, else BGR2GRAY."""
+    images = np.ascontiguousarray(images)
+    n, h, w, cn = images.shape
+    if images.dtype != np.uint8 or cn != (4 if code >= 2 else 3):
+        raise TypeError("cvtColor: (n, H, W, 3|4) uint8 expected for this code")
+    c = _ctx(context, w, h)
+    if (c.width, c.height) != (w, h):
+        raise ValueError("context size differs from the image size")
+    out = np.zeros((n, h, w), np.uint8)
+    check(lib().olf_cvt_gray(c.handle, ptr(images), int(code), n, ptr(out)), "olf_cvt_gray")
+    return out
+
+
+def remap(images, map1, map2, context=None):
+    """images: (n, H, W) uint8; map1/map2: (H2, W2) float32 (CV_32FC1 x and y maps) -> (n, H2, W2) uint8, INTER_LINEAR, BORDER_CONSTANT 0."""
+    images = np.ascontiguousarray(images)
+    map1, map2 = np.ascontiguousarray(map1, np.float32), np.ascontiguousarray(map2, np.float32)
+    n, h, w = images.shape
+    dh, dw = map1.shape
+    if images.dtype != np.uint8 or map2.shape != map1.shape:
+        raise TypeError("remap: (n, H, W) uint8 images and two equal-shape float32 maps expected")
+    c = _ctx(context, max(w, 640), max(h, 480))
+    out = np.zeros((n, dh, dw), np.uint8)
+    check(lib().olf_remap_linear(c.handle, ptr(images), w, h, ptr(map1), ptr(map2), dw, dh, n, ptr(out)), "olf_remap_linear")
+    return out

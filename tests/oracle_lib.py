@@ -235,3 +235,20 @@ def search_by_bow(kf, f, nnratio, checkOri=True):
                              _p(kn), _p(ko), _p(ki), len(kn), _p(a(f.mvKeys)), _p(a(f.mDescriptors)), f.N, _p(fn), _p(fo), _p(fi), len(fn),
                              C.c_float(nnratio), int(checkOri), _p(matched))
     return n, matched
+
+
+def cvt_gray(img, code):
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    out = np.zeros((h, w), np.uint8)
+    _L.orc_cvt_gray(_p(img), w, h, int(code), _p(out))
+    return out
+
+
+def remap_linear(img, mapx, mapy):
+    img = np.ascontiguousarray(img); mapx = np.ascontiguousarray(mapx, np.float32); mapy = np.ascontiguousarray(mapy, np.float32)
+    sh, sw = img.shape
+    dh, dw = mapx.shape
+    out = np.zeros((dh, dw), np.uint8)
+    _L.orc_remap_linear(_p(img), sw, sh, _p(mapx), _p(mapy), dw, dh, _p(out))
+    return out

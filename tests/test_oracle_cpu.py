@@ -153,3 +153,15 @@ def test_oracle_edge_cases(oracle):
     assert len(m) == 0
     assert list(oracle.match_bf(np.zeros((3, 32), np.uint8), np.zeros((1, 32), np.uint8), 0.9)) == [-1, -1, -1]   # < 2 train rows
     assert list(oracle.match_bf(np.zeros((0, 32), np.uint8), np.zeros((5, 32), np.uint8), 0.9)) == []
+
+
+def test_precond_known_answers(oracle):
+    # cvtColor: OpenCV's 8-bit RGB2GRAY fixed point (4899, 9617, 1868, >>14): documented values for the primaries
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [12, 200, 77]]], np.uint8)
+    assert oracle.cvt_gray(px, 0).tolist() == [[76, 150, 29, 255, 130]]
+    assert oracle.cvt_gray(px, 1).tolist() == [[29, 150, 76, 255, 142]]
+    # remap: identity map reproduces the image; a half-pixel shift averages neighbours with round-half-up of the >>15
+    img = np.array([[10, 20, 31], [40, 50, 61]], np.uint8)
+    ys, xs = np.mgrid[0:2, 0:3].astype(np.float32)
+    assert np.array_equal(oracle.remap_linear(img, xs, ys), img)
+    assert oracle.remap_linear(img, xs + 0.5, ys).tolist() == [[15, 26, 16], [45, 56, 31]]
