@@ -638,6 +638,14 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
     // fork: the line path runs beside the ORB path (the reference's 4 extraction threads, src/Frame.cc:164-171)
+    static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
+    if (one_stream) {
+        OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
+        OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, s));
+        OLF_TRY(olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s));
+        OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
+        return OLF_OK;
+    }
     OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2));

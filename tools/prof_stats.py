@@ -1,0 +1,13 @@
+import sys, ctypes as C, numpy as np
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import orb_line_slam_amd as ola
+from orb_line_slam_amd import synth, _lib
+n = 64
+imgs = synth.stereo_batch(7000, 16, 1242, 375)
+imgs = np.tile(imgs, (n // 32 + 1, 1, 1))[:n].copy()
+ex = ola.Lineextractor(500, 0.025, max_images=n)
+k, d, c = ex.extract_batch(imgs)
+out = np.zeros(64, np.int32)
+_lib.lib().olf_debug_status(ex._ctx.handle, out.ctypes.data_as(C.c_void_p))
+t = out[16:32].view(np.int64)
+print(dict(zip(["iters", "rounds", "unc", "acc", "iters_big", "rounds_big", "unc_big", "acc_big"], t.tolist())))

@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import orb_line_slam_amd as ola
 from orb_line_slam_amd import synth, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
