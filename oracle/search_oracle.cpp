@@ -3,6 +3,7 @@
 // Restates (paths relative to /root/reference), on plain arrays instead of Frame / KeyFrame / MapPoint objects:
 //   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)   src/ORBmatcher.cc:1330-1472
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)     src/ORBmatcher.cc:161-290
+//   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:47-131 (+ RadiusByViewingCos :133-139)
 //   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
 //   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
 // cv::Mat products of CV_32F operands (Rcw*x3Dw+tcw) accumulate in double and round once (cv::gemm generic path).
@@ -204,4 +205,46 @@ int orc_search_by_bow(const olf_keypoint* kfKeys, const uint8_t* kfDesc, const u
     return nmatches;
 }
 
+
+// Local-map tracking search (Tracking::SearchLocalPoints, src/Tracking.cc:1941): map points as SoA
+//   in_view = mbTrackInView, bad = isBad(), level = mnTrackScaleLevel, view_cos = mTrackViewCos, proj = (mTrackProjX, mTrackProjY, mTrackProjXR),
+//   desc = GetDescriptor(), obs = Observations() > 0.   matches[idx] = index of the map point assigned to feature idx.
+int orc_search_local_map(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
+                         uint8_t* cur_mp_obs, const float* cam9, const float* scaleFactors, int nMP, const uint8_t* in_view, const uint8_t* bad,
+                         const int* level, const float* view_cos, const float* proj3, const uint8_t* mp_desc, const uint8_t* mp_obs, float th,
+                         float nnratio, int* matches)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = curKeys; G.N = curN; G.c = c; G.build();
+    for (int i = 0; i < curN; ++i) matches[i] = -1;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < nMP; iMP++) {
+        if (!in_view[iMP]) continue;
+        if (bad[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos: float compared with the double literal
+        if (bFactor) r *= th;
+        const std::vector<size_t> vIndices = G.area(proj3[3 * iMP], proj3[3 * iMP + 1], r * scaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (cur_mp_valid[idx] && cur_mp_obs[idx]) continue;
+            if (curURight[idx] > 0) {
+                const float er = std::fabs(proj3[3 * iMP + 2] - curURight[idx]);
+                if (er > r * scaleFactors[nPredictedLevel]) continue;
+            }
+            const int dist = hamming256(mp_desc + 32 * (size_t)iMP, curDesc + 32 * idx);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = curKeys[idx].octave; bestIdx = (int)idx; }
+            else if (dist < bestDist2) { bestLevel2 = curKeys[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            cur_mp_valid[bestIdx] = 1; cur_mp_obs[bestIdx] = mp_obs[iMP];
+            matches[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
 }  // extern "C"

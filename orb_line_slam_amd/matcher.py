@@ -329,5 +329,82 @@ def _search_by_bow(self, pKF, F):
     return nmatches, matched
 
 
-ORBmatcher.SearchByProjection = _search_by_projection
+class MapPointView:
+    """The MapPoint members read by SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:47-131), gathered by the
+    host (mutex-guarded in the reference, src/MapPoint.cc:321-325) into SoA buffers:
+    mbTrackInView, isBad : (n,) bool;  mnTrackScaleLevel : (n,) int32;  mTrackViewCos, mTrackProjX, mTrackProjY, mTrackProjXR : (n,) float32;
+    descriptor : (n, 32) uint8 (GetDescriptor());  obs : (n,) bool (Observations() > 0)."""
+
+    def __init__(self, descriptor, mTrackProjX, mTrackProjY, mTrackProjXR, mnTrackScaleLevel, mTrackViewCos, mbTrackInView=None, isBad=None,
+                 obs=None):
+        self.descriptor = np.ascontiguousarray(descriptor, np.uint8).reshape(-1, 32)
+        self.n = n = len(self.descriptor)
+        f = lambda v: np.ascontiguousarray(v, np.float32).reshape(n)
+        self.mTrackProjX, self.mTrackProjY, self.mTrackProjXR, self.mTrackViewCos = f(mTrackProjX), f(mTrackProjY), f(mTrackProjXR), f(mTrackViewCos)
+        self.mnTrackScaleLevel = np.ascontiguousarray(mnTrackScaleLevel, np.int32).reshape(n)
+        b = lambda v, d: np.full(n, d, bool) if v is None else np.ascontiguousarray(v, bool).reshape(n)
+        self.mbTrackInView, self.isBad, self.obs = b(mbTrackInView, True), b(isBad, False), b(obs, True)
+
+
+def RadiusByViewingCos(viewCos):
+    """src/ORBmatcher.cc:133-139 (the float is compared with the double literal 0.998)"""
+    return np.float32(2.5) if float(np.float32(viewCos)) > 0.998 else np.float32(4.0)
+
+
+def _search_local_map(self, F, vpMapPoints, th=1.0):
+    """int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:47-131
+    (Tracking::SearchLocalPoints, every frame).  Returns (nmatches, matches) with matches[idx] = index into vpMapPoints assigned to feature
+    idx (-1 = none); F.mp_valid / F.mp_obs are updated like F.mvpMapPoints."""
+    f32 = np.float32
+    mp = vpMapPoints
+    bFactor = float(th) != 1.0
+    queries, lists, radii = [], [], []
+    for iMP in range(mp.n):
+        if not mp.mbTrackInView[iMP] or mp.isBad[iMP]:
+            continue
+        lvl = int(mp.mnTrackScaleLevel[iMP])
+        r = RadiusByViewingCos(mp.mTrackViewCos[iMP])
+        if bFactor:
+            r = f32(r * f32(th))
+        rs = f32(r * F.mvScaleFactors[lvl])
+        idx = F.GetFeaturesInArea(mp.mTrackProjX[iMP], mp.mTrackProjY[iMP], rs, lvl - 1, lvl)
+        if not idx:
+            continue
+        queries.append(iMP); lists.append(idx); radii.append(rs)
+    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, F.mDescriptors, self._context)
+    matches = np.full(F.N, -1, np.int32)
+    nmatches = 0
+    octave = F.mvKeysUn["octave"]
+    for qi, iMP in enumerate(queries):
+        bestDist = bestDist2 = 256
+        bestLevel = bestLevel2 = bestIdx = -1
+        for idx, dist in zip(lists[qi], dists[qi]):
+            if F.mp_valid[idx] and F.mp_obs[idx]:
+                continue
+            if F.mvuRight[idx] > 0:
+                if abs(f32(mp.mTrackProjXR[iMP] - F.mvuRight[idx])) > radii[qi]:
+                    continue
+            dist = int(dist)
+            if dist < bestDist:
+                bestDist2, bestDist, bestLevel2, bestLevel, bestIdx = bestDist, dist, bestLevel, int(octave[idx]), idx
+            elif dist < bestDist2:
+                bestLevel2, bestDist2 = int(octave[idx]), dist
+        if bestDist <= self.TH_HIGH:
+            if bestLevel == bestLevel2 and f32(bestDist) > f32(self.mfNNratio) * f32(bestDist2):
+                continue
+            F.mp_valid[bestIdx] = True
+            F.mp_obs[bestIdx] = mp.obs[iMP]
+            matches[bestIdx] = iMP
+            nmatches += 1
+    return nmatches, matches
+
+
+def _search_by_projection_dispatch(self, a, b, th=1.0, bMono=False):
+    """The reference overloads SearchByProjection on the second argument: a Frame (:1330) or a vector<MapPoint*> (:47)."""
+    if isinstance(b, MapPointView):
+        return _search_local_map(self, a, b, th)
+    return _search_by_projection(self, a, b, th, bMono)
+
+
+ORBmatcher.SearchByProjection = _search_by_projection_dispatch
 ORBmatcher.SearchByBoW = _search_by_bow

@@ -252,3 +252,19 @@ def remap_linear(img, mapx, mapy):
     out = np.zeros((dh, dw), np.uint8)
     _L.orc_remap_linear(_p(img), sw, sh, _p(mapx), _p(mapy), dw, dh, _p(out))
     return out
+
+
+def search_local_map(cur, mp, th, nnratio):
+    """cur: FrameView (state copied, not modified); mp: MapPointView -> (nmatches, matches)"""
+    cv, co = cur.mp_valid.astype(np.uint8).copy(), cur.mp_obs.astype(np.uint8).copy()
+    cam = np.array([cur.fx, cur.fy, cur.cx, cur.cy, cur.mbf, cur.mnMinX, cur.mnMaxX, cur.mnMinY, cur.mnMaxY], np.float32)
+    matches = np.full(cur.N, -1, np.int32)
+    a = lambda x, dt=None: np.ascontiguousarray(x if dt is None else x.astype(dt))
+    keys, desc, ur, sf = a(cur.mvKeysUn), a(cur.mDescriptors), a(cur.mvuRight), a(cur.mvScaleFactors)
+    inv, bad, lvl, vc = a(mp.mbTrackInView, np.uint8), a(mp.isBad, np.uint8), a(mp.mnTrackScaleLevel), a(mp.mTrackViewCos)
+    proj = a(np.stack([mp.mTrackProjX, mp.mTrackProjY, mp.mTrackProjXR], 1).astype(np.float32))
+    md, mo = a(mp.descriptor), a(mp.obs, np.uint8)
+    _L.orc_search_local_map.restype = C.c_int
+    n = _L.orc_search_local_map(_p(keys), _p(desc), _p(ur), cur.N, _p(cv), _p(co), _p(cam), _p(sf), mp.n, _p(inv), _p(bad), _p(lvl), _p(vc),
+                                _p(proj), _p(md), _p(mo), C.c_float(th), C.c_float(nnratio), _p(matches))
+    return n, matches

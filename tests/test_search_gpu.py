@@ -75,3 +75,25 @@ def test_candidate_distances_edge_cases(oracle):
     assert [len(x) for x in d] == [3, 0, 1, 3, 6]
     assert d[0][1] == oracle.hamming256(q[0], t[8]) and d[3][0] == 0xffff and d[3][1] == 0xffff and d[3][2] == oracle.hamming256(q[3], t[4])
     assert matcher._candidate_distances(np.zeros((0, 32), np.uint8), [], t) == []
+
+
+@pytest.mark.parametrize("th,ratio", [(1.0, 0.8), (3.0, 0.8), (5.0, 0.6)])
+def test_search_local_map(oracle, th, ratio):
+    """SearchByProjection(Frame, vector<MapPoint*>, th): the local map = the last frame's stereo points, projected with a small offset"""
+    last, cur = _frames(oracle, seed=47)
+    rng = np.random.default_rng(5)
+    sel = np.flatnonzero(last.mp_valid)
+    n = len(sel)
+    px = (last.mvKeysUn["x"][sel] + 3 + rng.normal(0, 1.0, n)).astype(np.float32)      # frame 1 is frame 0 shifted by 3 px
+    py = (last.mvKeysUn["y"][sel] + rng.normal(0, 1.0, n)).astype(np.float32)
+    pxr = (px - (last.mvKeysUn["x"][sel] - np.where(last.mvuRight[sel] > 0, last.mvuRight[sel], 0))).astype(np.float32)
+    lvl = np.clip(last.mvKeysUn["octave"][sel] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
+    cos = rng.choice(np.array([0.9, 0.9979, 0.998, 0.9981, 1.0], np.float32), n)
+    mp = ola.MapPointView(last.mDescriptors[sel], px, py, pxr, lvl, cos, mbTrackInView=rng.random(n) > 0.1, isBad=rng.random(n) < 0.05,
+                          obs=rng.random(n) > 0.3)
+    cur.mp_valid[::7] = True; cur.mp_obs[::14] = True       # some features already carry a map point (with / without observations)
+    cur_o = copy.deepcopy(cur)
+    n_o, m_o = oracle.search_local_map(cur_o, mp, th, ratio)
+    n_g, m_g = ola.ORBmatcher(ratio, True).SearchByProjection(cur, mp, th)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
+    assert n_g > 200
