@@ -60,6 +60,31 @@ int olf_cvt_gray(olf_ctx* ctx, const uint8_t* src, int code, int n_images, uint8
 int olf_remap_linear(olf_ctx* ctx, const uint8_t* src, int src_w, int src_h, const float* mapx, const float* mapy, int dst_w, int dst_h,
                      int n_images, uint8_t* dst);
 
+/* ---- BoW transform: ORBVocabulary / LineVocabulary (include/ORBVocabulary.h:30-34) ----------
+ * = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>; transform() is called by Frame::ComputeBoW (src/Frame.cc:585-597) and
+ * KeyFrame::ComputeBoW (src/KeyFrame.cc:96-112) with levelsup = 4. */
+typedef struct olf_voc olf_voc;
+/* scoring: 0 L1_NORM 1 L2_NORM 2 CHI_SQUARE 3 KL 4 BHATTACHARYYA 5 DOT_PRODUCT; weighting: 0 TF_IDF 1 TF 2 IDF 3 BINARY
+ * (Thirdparty/DBoW2/DBoW2/BowVector.h:36-53).  Nodes in id order (node 0 = root, entry ignored): parent[i] < i, is_leaf[i] marks a
+ * word (word ids are assigned in node order), desc 32 bytes per node, weight per node.  The tree is uploaded to the current device. */
+int olf_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent, const uint8_t* is_leaf, const uint8_t* desc,
+                   const double* weight, olf_voc** out);
+/* TemplatedVocabulary::loadFromTextFile (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425): "k L scoring weighting" then one
+ * "parent isLeaf d0..d31 weight" line per node. */
+int olf_voc_load_text(const char* path, olf_voc** out);
+void olf_voc_destroy(olf_voc* voc);
+int olf_voc_info(const olf_voc* voc, int* k, int* L, int* scoring, int* weighting, int* n_nodes, int* n_words);
+/* transform(feature, word_id, weight, nid, levelsup) (:1217-1261) for n descriptors; device pointers. */
+int olf_bow_words_dev(olf_ctx* ctx, const olf_voc* voc, const uint8_t* d_desc, int n, int levelsup, int32_t* d_word, double* d_weight,
+                      int32_t* d_node, void* stream);
+/* host: per-feature (word, weight, node) -> BowVector (ascending word id) + FeatureVector (CSR over ascending node id), with the
+ * vocabulary's weighting / normalisation (:1127-1195, BowVector.cpp:34-84, FeatureVector.cpp:31-45).  Capacities: n (fv_offs n+1). */
+int olf_bow_assemble(const olf_voc* voc, const int32_t* word, const double* weight, const int32_t* node, int n, int32_t* bow_ids,
+                     double* bow_vals, int* n_bow, int32_t* fv_nodes, int32_t* fv_offs, int32_t* fv_idx, int* n_fv);
+/* transform(features, v, fv, levelsup) for one image's descriptors (host buffers): descent on the GPU, assembly on the host. */
+int olf_bow_transform(olf_ctx* ctx, const olf_voc* voc, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals,
+                      int* n_bow, int32_t* fv_nodes, int32_t* fv_offs, int32_t* fv_idx, int* n_fv);
+
 /* ---- ORBextractor (include/ORBextractor.h:52-118, src/ORBextractor.cc) -------------------- */
 /* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:68-91) + mnFeaturesPerLevel; arrays of nlevels */

@@ -103,6 +103,16 @@ def lib():
         L.olf_match_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_cvt_gray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.olf_remap_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.olf_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.olf_voc_load_text.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.olf_voc_destroy.argtypes = [C.c_void_p]
+        L.olf_voc_destroy.restype = None
+        L.olf_voc_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 6
+        L.olf_bow_words_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_bow_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.olf_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.olf_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.olf_profile_reset.argtypes = [C.c_void_p]
         L.olf_profile_stage_name.restype = C.c_char_p

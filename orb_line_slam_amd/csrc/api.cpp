@@ -70,6 +70,11 @@ static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
     return OLF_OK;
 }
 
+namespace olf {
+hipStream_t ctx_stream(olf_ctx* c) { return c->stream; }
+int ctx_scratch(olf_ctx* c, int slot, size_t bytes, void** out) { return scratch_get(c, slot, bytes, out); }
+}
+
 enum { ST_ORB_PYRAMID, ST_ORB_FAST, ST_ORB_OCTREE, ST_ORB_BLUR, ST_ORB_DESCRIBE, ST_STEREO_POINTS, ST_LSD_FRONT, ST_LSD_GROW, ST_LINE_LBD,
        ST_STEREO_LINES, ST_MATCH_BF, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"orb_pyramid", "orb_fast_cells", "orb_octree", "orb_blur", "orb_describe", "stereo_points",

@@ -268,3 +268,81 @@ def search_local_map(cur, mp, th, nnratio):
     n = _L.orc_search_local_map(_p(keys), _p(desc), _p(ur), cur.N, _p(cv), _p(co), _p(cam), _p(sf), mp.n, _p(inv), _p(bad), _p(lvl), _p(vc),
                                 _p(proj), _p(md), _p(mo), C.c_float(th), C.c_float(nnratio), _p(matches))
     return n, matches
+
+
+# ---- BoW (oracle/bow_oracle.cpp) -------------------------------------------------------------
+_L.orc_voc_create.restype = C.c_void_p
+_L.orc_voc_load_text.restype = C.c_void_p
+_L.orc_voc_destroy.argtypes = [C.c_void_p]
+
+
+def random_vocabulary(k, L, seed, tie_every=0, stop_every=0):
+    """complete k-ary tree of depth L in DBoW2's creation order (HKmeansStep recursion: a node's children are created together, then each
+    child's subtree): random descriptors, idf-like weights; tie_every: duplicate a sibling descriptor; stop_every: weight 0 words"""
+    rng = np.random.default_rng(seed)
+    parent, leaf, level = [0], [0], [0]
+
+    def grow(pid, lvl):
+        ids = []
+        for _ in range(k):
+            ids.append(len(parent)); parent.append(pid); leaf.append(1 if lvl == L else 0); level.append(lvl)
+        if lvl < L:
+            for c in ids:
+                grow(c, lvl + 1)
+    grow(0, 1)
+    n = len(parent)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    if tie_every:
+        for i in range(2, n, tie_every):
+            if parent[i] == parent[i - 1]:
+                desc[i] = desc[i - 1]                      # equal distance to two siblings -> the first must win
+    weight = np.where(np.array(leaf) > 0, rng.uniform(0.5, 9.0, n), 0.0)
+    if stop_every:
+        weight[np.flatnonzero(np.array(leaf))[::stop_every]] = 0.0
+    return np.array(parent, np.int32), np.array(leaf, np.uint8), desc, weight
+
+
+class OracleVoc:
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def create(cls, k, L, parent, leaf, desc, weight, scoring=0, weighting=0):
+        return cls(_L.orc_voc_create(k, L, scoring, weighting, len(parent), _p(parent), _p(leaf), _p(np.ascontiguousarray(desc)), _p(weight)))
+
+    @classmethod
+    def load_text(cls, path):
+        h = _L.orc_voc_load_text(str(path).encode())
+        return cls(h) if h else None
+
+    def export(self):
+        k, L, s, w, nw = (C.c_int() for _ in range(5))
+        n = _L.orc_voc_info(self.h, C.byref(k), C.byref(L), C.byref(s), C.byref(w), C.byref(nw))
+        parent, leaf, desc, weight = np.zeros(n, np.int32), np.zeros(n, np.uint8), np.zeros((n, 32), np.uint8), np.zeros(n, np.float64)
+        _L.orc_voc_export(self.h, _p(parent), _p(leaf), _p(desc), _p(weight))
+        return dict(k=k.value, L=L.value, scoring=s.value, weighting=w.value, n_words=nw.value), parent, leaf, desc, weight
+
+    def words(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+        _L.orc_bow_words(self.h, _p(d), n, levelsup, _p(word), _p(weight), _p(node))
+        return word, weight, node
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        ids, vals = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        nodes, offs, idx = np.zeros(max(n, 1), np.int32), np.zeros(n + 1, np.int32), np.zeros(max(n, 1), np.int32)
+        nb, nf = C.c_int(), C.c_int()
+        _L.orc_bow_transform(self.h, _p(d), n, levelsup, _p(ids), _p(vals), C.byref(nb), _p(nodes), _p(offs), _p(idx), C.byref(nf))
+        return ({int(ids[i]): float(vals[i]) for i in range(nb.value)},
+                {int(nodes[a]): idx[offs[a]:offs[a + 1]].tolist() for a in range(nf.value)})
+
+
+def write_voc_text(path, k, L, parent, leaf, desc, weight, scoring=0, weighting=0, final_newline=True):
+    """the layout TemplatedVocabulary::saveToTextFile writes (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1430-1460)"""
+    with open(path, "w") as f:
+        f.write(f"{k} {L} {scoring} {weighting}\n")
+        lines = [f"{parent[i]} {int(leaf[i])} " + " ".join(str(int(b)) for b in desc[i]) + f" {float(weight[i])!r}" for i in range(1, len(parent))]
+        f.write("\n".join(lines) + ("\n" if final_newline else ""))

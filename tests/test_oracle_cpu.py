@@ -165,3 +165,50 @@ def test_precond_known_answers(oracle):
     ys, xs = np.mgrid[0:2, 0:3].astype(np.float32)
     assert np.array_equal(oracle.remap_linear(img, xs, ys), img)
     assert oracle.remap_linear(img, xs + 0.5, ys).tolist() == [[15, 26, 16], [45, 56, 31]]
+
+
+def test_bow_oracle_vs_reference_containers(oracle, tmp_path):
+    """oracle/bow_oracle.cpp's BowVector / FeatureVector logic against the real DBoW2 classes (oracle/_ref/libref_bow.so, built from the
+    reference checkout), for every weighting x scoring; and the text loader round trip incl. the phantom node after the final newline."""
+    import ctypes as C
+    ref_path = os.path.join(os.path.dirname(oracle.__file__), "..", "oracle", "_ref", "libref_bow.so")
+    rng = np.random.default_rng(12)
+    k, L = 4, 3
+    parent, leaf, desc, weight = oracle.random_vocabulary(k, L, 5, tie_every=7, stop_every=9)
+    feats = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    feats[:40] = desc[np.flatnonzero(leaf)[rng.integers(0, leaf.sum(), 40)]]          # exact hits on words, repeated words
+    if os.path.exists(ref_path):
+        R = C.CDLL(ref_path)
+        for scoring in range(6):
+            for weighting in range(4):
+                V = oracle.OracleVoc.create(k, L, parent, leaf, desc, weight, scoring, weighting)
+                word, w, node = V.words(feats, 1)
+                bow, fv = V.transform(feats, 1)
+                ids, vals = np.zeros(300, np.int32), np.zeros(300, np.float64)
+                must, tf = scoring != 5, weighting in (0, 1)
+                nb = R.ref_bow_build(oracle._p(word), oracle._p(w), 300, 0 if tf else 1, int(tf and not must), (1 if scoring == 1 else 0) if must else -1,
+                                     oracle._p(ids), oracle._p(vals))
+                assert list(bow) == ids[:nb].tolist() and list(bow.values()) == vals[:nb].tolist(), (scoring, weighting)
+                nodes, offs, idx = np.zeros(300, np.int32), np.zeros(301, np.int32), np.zeros(300, np.int32)
+                nf = R.ref_fv_build(oracle._p(node), oracle._p(w), 300, oracle._p(nodes), oracle._p(offs), oracle._p(idx))
+                assert list(fv) == nodes[:nf].tolist() and [fv[n] for n in fv] == [idx[offs[a]:offs[a + 1]].tolist() for a in range(nf)]
+                if must and scoring != 1 and bow:
+                    assert abs(sum(bow.values()) - 1.0) < 1e-12
+    # stop words (weight 0) never appear; every kept feature appears exactly once in the feature vector
+    V = oracle.OracleVoc.create(k, L, parent, leaf, desc, weight)
+    word, w, node = V.words(feats, 1)
+    bow, fv = V.transform(feats, 1)
+    assert sorted(i for v in fv.values() for i in v) == np.flatnonzero(w > 0).tolist() and set(bow) == set(word[w > 0].tolist())
+    # text round trip
+    for final_newline in (True, False):
+        path = tmp_path / f"voc{int(final_newline)}.txt"
+        oracle.write_voc_text(path, k, L, parent, leaf, desc, weight, 0, 0, final_newline)
+        T = oracle.OracleVoc.load_text(path)
+        info, p2, l2, d2, w2 = T.export()
+        n = len(parent)
+        assert info["k"] == k and info["L"] == L and info["n_words"] == int(leaf.sum()) and len(p2) == n + int(final_newline)
+        assert np.array_equal(p2[:n], parent) and np.array_equal(l2[1:n], leaf[1:]) and np.array_equal(d2[1:n], desc[1:]) and np.array_equal(w2[1:n], weight[1:])
+        if final_newline:
+            assert p2[n] == 0 and l2[n] == 0 and w2[n] == 0 and not d2[n].any()       # the reference's extra root child (convention C.8)
+        assert T.transform(feats, 1)[1] == fv or final_newline     # without the phantom the result is the array-built one
+    assert oracle.OracleVoc.load_text(tmp_path / "missing.txt") is None
