@@ -60,6 +60,12 @@ int olf_cvt_gray(olf_ctx* ctx, const uint8_t* src, int code, int n_images, uint8
 int olf_remap_linear(olf_ctx* ctx, const uint8_t* src, int src_w, int src_h, const float* mapx, const float* mapy, int dst_w, int dst_h,
                      int n_images, uint8_t* dst);
 
+/* ---- MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:254-318, src/MapLine.cc:257-322) --
+ * n_points landmarks; landmark p is observed by descriptors desc[offs[p] .. offs[p+1]) (32 bytes each, the rows the reference gathers
+ * from the non-bad key frames, in its std::map iteration order).  best[p] = index inside that list of the descriptor with the least
+ * median distance to the others (first minimum), -1 for an empty list.  Host buffers; at most 1024 observations per landmark. */
+int olf_distinctive_descriptors(olf_ctx* ctx, const uint8_t* desc, const int32_t* offs, int n_points, int32_t* best);
+
 /* ---- BoW transform: ORBVocabulary / LineVocabulary (include/ORBVocabulary.h:30-34) ----------
  * = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>; transform() is called by Frame::ComputeBoW (src/Frame.cc:585-597) and
  * KeyFrame::ComputeBoW (src/KeyFrame.cc:96-112) with levelsup = 4. */

@@ -9,6 +9,7 @@
 // cv::Mat products of CV_32F operands (Rcw*x3Dw+tcw) accumulate in double and round once (cv::gemm generic path).
 // PARITY UNPINNED (see oracle_common.hpp).
 #include "oracle_common.hpp"
+#include <climits>
 
 namespace orc {
 static const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30, GC = 64, GR = 48;
@@ -248,3 +249,30 @@ int orc_search_local_map(const olf_keypoint* curKeys, const uint8_t* curDesc, co
     return nmatches;
 }
 }  // extern "C"
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:254-318) == MapLine::ComputeDistinctiveDescriptors (src/MapLine.cc:257-322)
+// on a batch of landmarks given as CSR lists of observing descriptors.
+extern "C" void orc_distinctive_descriptors(const uint8_t* desc, const int* offs, int n_points, int* best)
+{
+    for (int p = 0; p < n_points; ++p) {
+        const size_t N = (size_t)(offs[p + 1] - offs[p]);
+        if (N == 0) { best[p] = -1; continue; }
+        const uint8_t* d = desc + 32 * (size_t)offs[p];
+        std::vector<float> Distances(N * N);
+        for (size_t i = 0; i < N; i++) {
+            Distances[i * N + i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                const int distij = orc::hamming256(d + 32 * i, d + 32 * j);
+                Distances[i * N + j] = (float)distij; Distances[j * N + i] = (float)distij;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+            std::sort(vDists.begin(), vDists.end());
+            const int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+        }
+        best[p] = BestIdx;
+    }
+}

@@ -543,6 +543,28 @@ int olf_hamming_matrix(olf_ctx* c, const uint8_t* descA, int nA, const uint8_t* 
     return OLF_OK;
 }
 
+int olf_distinctive_descriptors(olf_ctx* c, const uint8_t* desc, const int32_t* offs, int n_points, int32_t* best)
+{
+    if (!c || !offs || !best || n_points < 0) { set_error("olf_distinctive_descriptors: bad argument"); return OLF_ERR_INVALID; }
+    if (n_points == 0) return OLF_OK;
+    const int total = offs[n_points];
+    if (offs[0] != 0 || total < 0 || (total > 0 && !desc)) { set_error("olf_distinctive_descriptors: bad offsets"); return OLF_ERR_INVALID; }
+    for (int i = 0; i < n_points; ++i) {
+        if (offs[i + 1] < offs[i]) { set_error("olf_distinctive_descriptors: offsets must not decrease"); return OLF_ERR_INVALID; }
+        if (offs[i + 1] - offs[i] > 1024) { set_error("olf_distinctive_descriptors: more than 1024 observations of one landmark"); return OLF_ERR_CAPACITY; }
+    }
+    void* st = nullptr;
+    const size_t bD = ((size_t)total * 32 + 15) & ~(size_t)15, bO = (size_t)(n_points + 1) * 4;
+    OLF_TRY(scratch_get(c, 1, bD + bO + (size_t)n_points * 4 + 64, &st));
+    uint8_t* dD = (uint8_t*)st; int* dO = (int*)(dD + bD); int* dB = dO + n_points + 1;
+    if (total) OLF_HIP_CHECK(hipMemcpyAsync(dD, desc, (size_t)total * 32, hipMemcpyHostToDevice, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(dO, offs, bO, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_distinctive(dD, dO, n_points, dB, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(best, dB, (size_t)n_points * 4, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int olf_line_capacity(const olf_ctx* c) { return c ? c->line.geom.outCap : OLF_ERR_INVALID; }
 

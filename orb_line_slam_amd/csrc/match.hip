@@ -327,6 +327,45 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
     out[(size_t)i * nB + j] = (uint16_t)ham256(ap[0], ap[1], bp[0], bp[1]);
 }
 
+// MapPoint / MapLine::ComputeDistinctiveDescriptors (src/MapPoint.cc:254-318, src/MapLine.cc:257-322): among the N descriptors
+// observing one landmark, the one whose median Hamming distance to all N (itself included, distance 0) is smallest; median = element
+// floor(0.5 * (N - 1)) of the sorted row; the first minimum wins.  One 64-thread workgroup per landmark, descriptors staged in LDS;
+// a row's median is found by bisection on the distance value (count(d <= v) >= rank + 1), so no N x N matrix is ever stored.
+constexpr int kDistinctMax = 1024;
+__global__ __launch_bounds__(64) void k_distinctive(const uint8_t* __restrict__ desc, const int* __restrict__ offs, int* __restrict__ best)
+{
+    __shared__ uint4 s_d[2 * kDistinctMax];
+    const int p = blockIdx.x, b = offs[p], N = offs[p + 1] - b, lane = threadIdx.x;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const uint4* src = reinterpret_cast<const uint4*>(desc + (size_t)b * OLF_DESC_BYTES);
+    for (int i = lane; i < 2 * N; i += 64) s_d[i] = src[i];
+    __syncthreads();
+    const int rank = (int)(0.5 * (double)(N - 1));
+    unsigned key = 0xffffffffu;
+    for (int i = lane; i < N; i += 64) {
+        const uint4 a0 = s_d[2 * i], a1 = s_d[2 * i + 1];
+        int lo = 0, hi = 256;                     // smallest v with count(d <= v) > rank
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; ++j) cnt += ham256(a0, a1, s_d[2 * j], s_d[2 * j + 1]) <= mid;
+            if (cnt > rank) hi = mid; else lo = mid + 1;
+        }
+        key = min(key, ((unsigned)lo << 16) | (unsigned)i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+    if (lane == 0) best[p] = (int)(key & 0xffffu);
+}
+
+int launch_distinctive(const uint8_t* desc, const int* offs, int n_points, int* best, hipStream_t s)
+{
+    if (n_points <= 0) return OLF_OK;
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), 0, s, desc, offs, best);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
                          const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, int* d_bestKey,

@@ -140,6 +140,7 @@ int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, co
 int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
                 int* dist0, int* dist1, hipStream_t s);
 int launch_match_candidates(const uint8_t* q, int nQ, const uint8_t* t, int nT, const int* offs, const int* cand, uint16_t* out, hipStream_t s);
+int launch_distinctive(const uint8_t* desc, const int* offs, int n_points, int* best, hipStream_t s);
 int launch_hamming_matrix(const uint8_t* a, int nA, const uint8_t* b, int nB, uint16_t* out, hipStream_t s);
 
 }  // namespace olf

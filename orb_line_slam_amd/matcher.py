@@ -66,6 +66,20 @@ def distance(a, b, context=None):
     return int(distance_matrix(np.asarray(a).reshape(1, 32), np.asarray(b).reshape(1, 32), context)[0, 0])
 
 
+def ComputeDistinctiveDescriptors(observations, context=None):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:254-318) / MapLine::ComputeDistinctiveDescriptors (src/MapLine.cc:257-322)
+    for a batch of landmarks.  observations: list of (N_p, 32) uint8 arrays (the descriptors observing landmark p, bad key frames already
+    dropped).  Returns BestIdx per landmark (-1 where the list is empty: the reference returns early and keeps the old descriptor)."""
+    obs = [np.ascontiguousarray(o, np.uint8).reshape(-1, 32) for o in observations]
+    offs = np.zeros(len(obs) + 1, np.int32)
+    offs[1:] = np.cumsum([len(o) for o in obs])
+    desc = np.ascontiguousarray(np.concatenate(obs)) if len(obs) and offs[-1] else np.zeros((0, 32), np.uint8)
+    best = np.full(len(obs), -1, np.int32)
+    if len(obs):
+        check(lib().olf_distinctive_descriptors(_ctx(context).handle, ptr(desc), ptr(offs), len(obs), ptr(best)), "olf_distinctive_descriptors")
+    return best
+
+
 class ORBmatcher:
     TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30   # src/ORBmatcher.cc:39-41
 

@@ -346,3 +346,13 @@ def write_voc_text(path, k, L, parent, leaf, desc, weight, scoring=0, weighting=
         f.write(f"{k} {L} {scoring} {weighting}\n")
         lines = [f"{parent[i]} {int(leaf[i])} " + " ".join(str(int(b)) for b in desc[i]) + f" {float(weight[i])!r}" for i in range(1, len(parent))]
         f.write("\n".join(lines) + ("\n" if final_newline else ""))
+
+
+def distinctive_descriptors(observations):
+    obs = [np.ascontiguousarray(o, np.uint8).reshape(-1, 32) for o in observations]
+    offs = np.zeros(len(obs) + 1, np.int32)
+    offs[1:] = np.cumsum([len(o) for o in obs])
+    desc = np.ascontiguousarray(np.concatenate(obs)) if offs[-1] else np.zeros((1, 32), np.uint8)
+    best = np.zeros(len(obs), np.int32)
+    _L.orc_distinctive_descriptors(_p(desc), _p(offs), len(obs), _p(best))
+    return best

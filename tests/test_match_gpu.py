@@ -59,3 +59,24 @@ def test_stereo_points(oracle, w, h, nf, fx, bf):
         assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
         assert np.array_equal(g["mvDepth"].view(np.uint32), o["depth"].view(np.uint32))
         assert (o["uRight"] >= 0).sum() > 50   # the synthetic pair must actually produce stereo matches
+
+
+def test_distinctive_descriptors(oracle):
+    """MapPoint / MapLine::ComputeDistinctiveDescriptors over a batch of landmarks (SURVEY 8(f) rank 4)"""
+    from orb_line_slam_amd import matcher
+    rng = np.random.default_rng(21)
+    obs = []
+    for n in [0, 1, 2, 3, 4, 5, 7, 8, 16, 33, 64, 65, 130, 300, 1024] + rng.integers(1, 40, 400).tolist():
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        d = np.repeat(base[None], n, 0)
+        noise = rng.random((n, 256)) < rng.uniform(0.0, 0.2)             # observations = one descriptor with a few bits flipped
+        d ^= np.packbits(noise, axis=1)
+        if n > 3 and rng.random() < 0.3:
+            d[1] = d[0]                                                  # identical rows -> equal medians -> the first must win
+        obs.append(d)
+    got = matcher.ComputeDistinctiveDescriptors(obs)
+    want = oracle.distinctive_descriptors(obs)
+    assert np.array_equal(got, want) and got[0] == -1 and got[1] == 0
+    with pytest.raises(Exception):
+        matcher.ComputeDistinctiveDescriptors([np.zeros((1025, 32), np.uint8)])
+    assert len(matcher.ComputeDistinctiveDescriptors([])) == 0
