@@ -165,3 +165,42 @@ def test_cpp_adaptor_compiles_and_links(tmp_path):
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert out.returncode == 0 and b"ADAPTOR_OK" in out.stdout, out.stdout
+
+
+def test_keyframe_record_bytes(oracle):
+    """Map::SaveKeyFrame's byte layout (SURVEY 8(f) rank 4): the host packer equals the oracle's field-by-field writes; unpack inverts it"""
+    import ctypes as C
+    from orb_line_slam_amd import maprecord, _lib
+    rng = np.random.default_rng(4)
+    n, nl = 37, 11
+    keys = np.zeros(n, _lib.KEYPOINT_DTYPE)
+    for f in ("x", "y", "size", "angle", "response"):
+        keys[f] = rng.random(n, np.float32) * 100
+    keys["octave"] = rng.integers(0, 8, n); keys["class_id"] = -1
+    kls = np.zeros(nl, _lib.KEYLINE_DTYPE)
+    for f in _lib.KEYLINE_DTYPE.names:
+        kls[f] = rng.integers(0, 500, nl) if kls.dtype[f].kind == "i" else rng.random(nl, np.float32) * 300
+    ur, dp = rng.random(n, np.float32) * 50 - 1, rng.random(n, np.float32) * 30
+    desc, dl = rng.integers(0, 256, (n, 32), dtype=np.uint8), rng.integers(0, 256, (nl, 32), dtype=np.uint8)
+    mp = rng.integers(0, 1 << 40, n).astype(np.uint64); mp[::5] = maprecord.ULONG_MAX
+    ml = rng.integers(0, 1 << 40, nl).astype(np.uint64); ml[::3] = maprecord.ULONG_MAX
+    disp, le = rng.random((nl, 2), np.float32) * 9, rng.standard_normal((nl, 3))
+    t, q = rng.standard_normal(3).astype(np.float32), rng.standard_normal(4).astype(np.float32)
+    got = maprecord.pack_keyframe(123456789012, 42, 1403636579.763555527, t, q, keys, ur, dp, desc, mp, kls, disp, le, dl, ml)
+    out = np.zeros(len(got) + 64, np.uint8)
+    L = oracle._L
+    L.orc_keyframe_record.restype = C.c_size_t
+    L.orc_keyframe_record.argtypes = [C.c_ulong, C.c_ulong, C.c_double] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 6
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(a) for a in (t, q, keys, ur, dp, desc, mp, kls, disp, le, dl, ml)]
+    size = L.orc_keyframe_record(123456789012, 42, 1403636579.763555527, p(keep[0]), p(keep[1]), n, *[p(a) for a in keep[2:7]], nl,
+                                 *[p(a) for a in keep[7:]], out.ctypes.data_as(C.c_void_p))
+    assert size == len(got) == 52 + 4 + 72 * n + 4 + 140 * nl
+    assert out[:size].tobytes() == got
+    rec, end = maprecord.unpack_keyframe(got + b"tail")
+    assert end == len(got) and rec["mnFrameId"] == 123456789012 and rec["mnId"] == 42 and rec["mTimeStamp"] == 1403636579.763555527
+    assert np.array_equal(rec["mvKeys"], keys) and np.array_equal(rec["mvKeys_Line"], kls) and np.array_equal(rec["mappoint_ids"], mp)
+    assert np.array_equal(rec["mvle_l"], le) and np.array_equal(rec["mvDisparity_l"], disp) and np.array_equal(rec["mDescriptors_l"], dl)
+    assert np.array_equal(rec["mvuRight"], ur) and np.array_equal(rec["mvDepth"], dp) and np.array_equal(rec["mDescriptors"], desc)
+    empty = maprecord.pack_keyframe(0, 0, 0.0, [0, 0, 0], [0, 0, 0, 1], np.zeros(0, _lib.KEYPOINT_DTYPE), [], [], np.zeros((0, 32), np.uint8))
+    assert len(empty) == 60 and maprecord.unpack_keyframe(empty)[1] == 60
