@@ -60,6 +60,8 @@ struct LineDeviceBufs {
     void* sortTemp = nullptr;
     size_t sortTempBytes = 0;
     int* status = nullptr;
+    float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
+    double2* cosSin = nullptr;     // [2^22] cos / sin of that angle as the reference evaluates them
 };
 
 struct LineHostTables {
@@ -76,6 +78,7 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
                     uint8_t* d_desc, const int* d_counts, hipStream_t s);
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
                       const LineGeom& g, int which, int n_images, hipStream_t s);
+int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 size_t lsd_sort_temp_bytes(int total_keys, int n_segments);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);

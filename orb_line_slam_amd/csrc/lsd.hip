@@ -289,6 +289,29 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     *sn = so; *cs = co;
 }
 
+// The level-line angle of a pixel and its cos / sin are pure functions of the integer gradient pair, so they are tabulated once per
+// context over the packed 22-bit (gx:11 | gy:11) field of the gradient word -- 84 MB, image independent, shared by every agent; real
+// images touch a small, L2 / Infinity-Cache resident part of it.  This takes fastAtan2 and the double sincos out of the agent's
+// per-iteration instruction stream (the agent is VALU-issue bound), at the price of one more dependent load.
+__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, double2* __restrict__ cosSin)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const int gx = unpack_gx(i), gy = unpack_gy(i);
+    const float deg = dev_fastAtan2((float)gx, (float)(-gy));
+    const double ang = d_mul((double)deg, kDegToRads);
+    double sn, cs;
+    sincos_2pi((double)(float)ang, &sn, &cs);
+    angDeg[i] = deg;
+    cosSin[i] = make_double2(cs, sn);
+}
+
+int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, b.cosSin);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
 constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
 
@@ -310,7 +333,8 @@ __device__ __forceinline__ double rlane_d(double v, int l)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, olf_keyline* __restrict__ rawLines,
-                                                 int* __restrict__ rawCount, int* __restrict__ status)
+                                                 int* __restrict__ rawCount, int* __restrict__ status, const float* __restrict__ angDeg,
+                                                 const double2* __restrict__ cosSin)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
@@ -395,8 +419,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         if (!(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a) {
                             cand = true;
                             xy = xx | (yy << 16);
-                            ang = d_mul((double)dev_fastAtan2((float)unpack_gx(pw), (float)(-unpack_gy(pw))), kDegToRads);
-                            sincos_2pi((double)(float)ang, &sn, &cs);
+                            const uint32_t ti = pw & 0x3fffffu;
+                            ang = d_mul((double)angDeg[ti], kDegToRads);
+                            const double2 t = cosSin[ti];
+                            cs = t.x; sn = t.y;
                         }
                     }
                 }
@@ -618,7 +644,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, b.rawLines, b.rawCount, b.status);
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, b.rawLines, b.rawCount, b.status, b.angDeg, b.cosSin);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
