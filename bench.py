@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=2048, help="stereo pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=3072, help="stereo pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--features", type=int, default=2000)

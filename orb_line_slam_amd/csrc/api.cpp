@@ -44,7 +44,6 @@ struct olf_ctx {
     float* d_ldisp = nullptr;
     double* d_lle = nullptr;
     hipStream_t stream2 = nullptr;
-    int agent_capacity = 4096;      // LSD agents resident at once: CUs x 4 SIMDs x 4 waves
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
     bool prof_on = false;
@@ -165,7 +164,6 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (rc != OLF_OK) { set_error("olf_ctx_create: image size / ORB parameters not supported"); delete c; return rc; }
     auto fail = [&](int code) { olf_ctx_destroy(c); return code; };
     if (hipGetDevice(&c->device) != hipSuccess) return fail(OLF_ERR_HIP);
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->agent_capacity = cus * 16; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(OLF_ERR_HIP); }
     const OrbGeom& g = c->orb.geom;
     const size_t n = (size_t)max_images;
@@ -198,7 +196,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.segBegin, n); A(l.segEnd, n); A(l.region, n * lg.Ps);
-    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
+    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
     A(l.angDeg, (size_t)1 << 22); A(l.cosSin, (size_t)1 << 22);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
@@ -669,12 +667,10 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
     // fork: the line path runs beside the ORB path (the reference's 4 extraction threads, src/Frame.cc:164-171)
-    // The LSD agents hold 4 waves x 126 VGPRs per SIMD: once a batch fills every SIMD with agents (n_images >= 16 per CU) nothing can
-    // run beside them and forking only interleaves the ORB kernels into the agents' tail; below that the line path runs beside the
-    // ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  OLF_ONE_STREAM / OLF_TWO_STREAMS
-    // force either schedule (measurement knobs).
-    static const bool force_one = getenv("OLF_ONE_STREAM") != nullptr, force_two = getenv("OLF_TWO_STREAMS") != nullptr;
-    const bool one_stream = force_one || (!force_two && n_images >= c->agent_capacity);
+    // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171): the LSD
+    // agents are long latency-bound waves that need only 64 VGPRs, so the ORB kernels fill the issue slots and registers they leave idle
+    // (7.8k vs 6.5k stereo frames/s at 2048 pairs).  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
+    static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
     if (one_stream) {
         OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
         OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, s));

@@ -185,6 +185,9 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.minRegSize = int(-LOG_NT / std::log10(pp));
     g.minLength = p.min_line_length * std::min(W, H);
     g.maxDetect = 4096;
+    // 16-byte region records alias the unsorted key buffer, 24-byte segment candidates the sorted one (4 bytes per pixel each)
+    g.maxRegions = std::min(g.Ps / std::max(g.minRegSize, 1) + 1, g.Ps / 6 - 1);
+    g.rectGrid = g.maxRegions;
     g.nFeatures = p.lsd_nfeatures;
     g.outCap = p.lsd_nfeatures > 0 ? p.lsd_nfeatures : g.maxDetect;
     for (int i = 0; i < 7; ++i) { g.lsdTaps[i] = 0; g.lbdTaps[i] = 0; }

@@ -27,6 +27,8 @@ struct LineGeom {
     double scale;              // lsd_scale
     double minLength;          // min_line_length * min(W, H)
     int maxDetect;             // capacity of the raw key line list
+    int rectGrid;              // regions per image covered by a k_lsd_rect launch (blocks past regCount exit at once)
+    int maxRegions;            // capacity of the per-image region log (a logged region owns >= minRegSize pixels of its own)
     int nFeatures;             // lsd_nfeatures (0 = keep all)
     int outCap;                // key lines returned per image
     int lsdTaps[7];            // sigma 0.6 (7x7)
@@ -51,6 +53,7 @@ struct LineDeviceBufs {
     uint32_t* region = nullptr;
     olf_keyline* rawLines = nullptr;
     int* rawCount = nullptr;
+    int* regCount = nullptr;       // [n] regions logged by the agent (records alias keysA, free once the keys are sorted)
     uint8_t* lbdBlur = nullptr;
     uint32_t* dxdy = nullptr;
     float* rowSums = nullptr;      // [n][outCap][63][4]

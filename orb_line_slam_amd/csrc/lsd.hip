@@ -24,6 +24,9 @@ constexpr double kM32PI = (3 * kPI) / 2, kM2PI = 2 * kPI;
 constexpr unsigned kNotDef = 0x40000000u, kUsed = 0x80000000u, kIso = 0x00400000u;   // bit 22: no neighbour is aligned with this pixel
 __device__ __forceinline__ int unpack_gx(uint32_t p) { return ((int)(p << 21)) >> 21; }
 __device__ __forceinline__ int unpack_gy(uint32_t p) { return ((int)(p << 10)) >> 21; }
+
+// one grown region that is large enough to be fitted: its pixels are region[start .. start + n) in growth order
+struct RegionRec { int start, n; double angle; };
 __device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0x7ffu) | (((uint32_t)gy & 0x7ffu) << 11); }
 
 __device__ __forceinline__ int refl101(int p, int n)
@@ -327,30 +330,29 @@ __device__ __forceinline__ double rlane_d(double v, int l)
 // FIFO entries are read back from an LDS ring, and a pixel whose USED bit was just stored is also entered in
 // an LDS hash table that every `used` test consults, so no memory fence is needed per step; a fence is only
 // issued when a table slot is about to be reused by a different pixel (and before region2rect).
-// 4 agents per SIMD: the agent is a long dependent chain (LDS ring -> gradient load -> atan2/sincos -> accept chain), so
-// throughput comes from interleaving waves; 126 VGPRs (a few cold spills in the KeyLine epilogue) instead of 177 lets 4
-// instead of 2 waves share a SIMD: 54 -> 36 us per image with 4096 images in flight.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
+// The agent is a long dependent chain (LDS ring -> gradient word -> angle table -> accept chain): a single wave spends ~3/4 of its time
+// waiting, so throughput comes from interleaving waves.  With region2rect moved to k_lsd_rect the agent needs 64 VGPRs, i.e. up to
+// 8 agents per SIMD (8192 per GPU) and room for other kernels beside them.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
-                                                 uint32_t* __restrict__ regionAll, olf_keyline* __restrict__ rawLines,
-                                                 int* __restrict__ rawCount, int* __restrict__ status, const float* __restrict__ angDeg,
+                                                 uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
+                                                 int* __restrict__ status, const float* __restrict__ angDeg,
                                                  const double2* __restrict__ cosSin)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
-    __shared__ double s_w[64], s_a[64], s_b[64];
-    const LineGeom& g = *gp;
+        const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     const int Ws = g.Ws, Hs = g.Hs;
     uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
     uint32_t* reg = regionAll + (size_t)img * g.Ps;
-    olf_keyline* out = rawLines + (size_t)img * g.maxDetect;
+    RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec;
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
     __builtin_amdgcn_wave_barrier();
-    int nl = 0;
+    int nreg = 0, rbase = 0;
 #ifdef OLF_TIMING
     long long t_seed = 0, t_small = 0, t_big = 0, t_rect = 0, n_small = 0, n_big = 0, it_small = 0, it_big = 0; long long t0 = __builtin_readcyclecounter();
 #endif
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             float sumdx = 0.f, sumdy = 0.f;
             bool have_sum = false;
             MARK_USED(seed, pseed);
-            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[0] = pk; }
+            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
             __builtin_amdgcn_wave_barrier();
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); t_seed += t1 - t0; t0 = t1; }
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 uint32_t pw = 0;
                 double ang = 0, cs = 0, sn = 0;
                 if (lane < 63 && e < nb && k != 4) {
-                    const uint32_t rp = (n - i > RING) ? reg[i + e] : s_ring[(i + e) & (RING - 1)];
+                    const uint32_t rp = (n - i > RING) ? reg[rbase + i + e] : s_ring[(i + e) & (RING - 1)];
                     const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                     if (xx >= 0 && yy >= 0 && xx < Ws && yy < Hs) {
                         a = yy * Ws + xx;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
                         grad[a] = pw | kUsed;
                         s_ring[idx & (RING - 1)] = (uint32_t)xy;
-                        reg[idx] = (uint32_t)xy;
+                        reg[rbase + idx] = (uint32_t)xy;
                         s_pend[slot] = a;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -477,120 +479,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; it_big += iters; } else { t_small += t1 - t0; ++n_small; it_small += iters; } t0 = t1; }
 #endif
             if (n >= g.minRegSize) {
-                __threadfence_block();   // region2rect reads the FIFO back from memory
-                // ---- region2rect: the products are formed 64 at a time (one per lane), the additions are replayed
-                // in the region's growth order through v_readlane, so every partial sum equals the reference's
-                double x = 0, y = 0, sum = 0;
-                for (int cb = 0; cb < n; cb += 64) {
-                    const int cnt = min(64, n - cb);
-                    double wt = 0, xw = 0, yw = 0;
-                    if (lane < cnt) {
-                        const uint32_t rp = reg[cb + lane];
-                        const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
-                        const uint32_t p = grad[py * Ws + px];
-                        const int gx = unpack_gx(p), gy = unpack_gy(p);
-                        wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
-                        xw = d_mul((double)px, wt); yw = d_mul((double)py, wt);
+                // a region large enough to become a segment: keep its pixel list (the log only moves forward for these) and record
+                // (start, size, final region angle); k_lsd_rect fits all rectangles of the batch in parallel afterwards
+                if (nreg < g.maxRegions) {
+                    if (lane == 0) {
+                        RegionRec rr; rr.start = rbase; rr.n = n; rr.angle = reg_angle;
+                        recs[nreg] = rr;
                     }
-                    s_w[lane] = wt; s_a[lane] = xw; s_b[lane] = yw;
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-                    for (int q = 0; q < cnt; ++q) {       // wave-uniform LDS reads (broadcast), additions in growth order
-                        x = d_add(x, s_a[q]);
-                        y = d_add(y, s_b[q]);
-                        sum = d_add(sum, s_w[q]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                x = x / sum; y = y / sum;
-                double Ixx = 0, Iyy = 0, Ixy = 0;
-                for (int cb = 0; cb < n; cb += 64) {
-                    const int cnt = min(64, n - cb);
-                    double t1 = 0, t2 = 0, t3 = 0;
-                    if (lane < cnt) {
-                        const uint32_t rp = reg[cb + lane];
-                        const int px = (int)(rp & 0xffffu), py = (int)(rp >> 16);
-                        const uint32_t p = grad[py * Ws + px];
-                        const int gx = unpack_gx(p), gy = unpack_gy(p);
-                        const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
-                        const double ex = d_sub((double)px, x), ey = d_sub((double)py, y);
-                        t1 = d_mul(d_mul(ey, ey), wt); t2 = d_mul(d_mul(ex, ex), wt); t3 = d_mul(d_mul(ex, ey), wt);
-                    }
-                    s_w[lane] = t1; s_a[lane] = t2; s_b[lane] = t3;
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-                    for (int q = 0; q < cnt; ++q) {
-                        Ixx = d_add(Ixx, s_w[q]);
-                        Iyy = d_add(Iyy, s_a[q]);
-                        Ixy = d_sub(Ixy, s_b[q]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                const double dI = d_sub(Ixx, Iyy);
-                const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
-                double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)dev_fastAtan2((float)d_sub(lambda, Ixx), (float)Ixy)
-                                                       : (double)dev_fastAtan2((float)Ixy, (float)d_sub(lambda, Iyy));
-                theta = d_mul(theta, kDegToRads);
-                {
-                    double diff = d_sub(theta, reg_angle);
-                    while (diff <= -kPI) diff = d_add(diff, kM2PI);
-                    while (diff > kPI) diff = d_sub(diff, kM2PI);
-                    if (fabs(diff) > prec) theta = d_add(theta, kPI);
-                }
-                double ddx, ddy;
-                sincos(theta, &ddy, &ddx);
-                // extent along the axis: "if (l > l_max) .. else if (l < l_min) .." from (0, 0) is max(0, max l) / min(0, min l),
-                // which does not depend on the order
-                double l_min = 0, l_max = 0;
-                for (int cb = 0; cb < n; cb += 64) {
-                    if (cb + lane < n) {
-                        const uint32_t rp = reg[cb + lane];
-                        const double rdx = d_sub((double)(int)(rp & 0xffffu), x), rdy = d_sub((double)(int)(rp >> 16), y);
-                        const double lq = d_add(d_mul(rdx, ddx), d_mul(rdy, ddy));
-                        l_max = fmax(l_max, lq); l_min = fmin(l_min, lq);
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    l_max = fmax(l_max, __hiloint2double(__shfl_xor(__double2hiint(l_max), o), __shfl_xor(__double2loint(l_max), o)));
-                    l_min = fmin(l_min, __hiloint2double(__shfl_xor(__double2hiint(l_min), o), __shfl_xor(__double2loint(l_min), o)));
-                }
-                double x1 = d_add(x, d_mul(l_min, ddx)), y1 = d_add(y, d_mul(l_min, ddy));
-                double x2 = d_add(x, d_mul(l_max, ddx)), y2 = d_add(y, d_mul(l_max, ddy));
-                x1 = d_add(x1, 0.5); y1 = d_add(y1, 0.5); x2 = d_add(x2, 0.5); y2 = d_add(y2, 0.5);
-                if (g.scale != 1) { x1 = x1 / g.scale; y1 = y1 / g.scale; x2 = x2 / g.scale; y2 = y2 / g.scale; }
-                // ---- LSDDetectorC::detectImpl: Vec4f -> KeyLine (LSDDetector_custom.cpp:270-307)
-                float e0 = (float)x1, e1 = (float)y1, e2 = (float)x2, e3 = (float)y2;
-                const int cols = g.W, rows = g.H;
-                if (e0 < 0) e0 = 0;
-                if (e0 >= cols) e0 = (float)cols - 1.0f;
-                if (e2 < 0) e2 = 0;
-                if (e2 >= cols) e2 = (float)cols - 1.0f;
-                if (e1 < 0) e1 = 0;
-                if (e1 >= rows) e1 = (float)rows - 1.0f;
-                if (e3 < 0) e3 = 0;
-                if (e3 >= rows) e3 = (float)rows - 1.0f;
-                const double dxe = (double)f_sub(e0, e2), dye = (double)f_sub(e1, e3);
-                const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
-                if (length > g.minLength) {
-                    if (nl < g.maxDetect) {
-                        if (lane == 0) {
-                            olf_keyline kl;
-                            kl.startPointX = e0; kl.startPointY = e1; kl.endPointX = e2; kl.endPointY = e3;
-                            kl.sPointInOctaveX = e0; kl.sPointInOctaveY = e1; kl.ePointInOctaveX = e2; kl.ePointInOctaveY = e3;
-                            kl.lineLength = (float)length;
-                            const int rx1 = __float2int_rn(e0), ry1 = __float2int_rn(e1), rx2 = __float2int_rn(e2), ry2 = __float2int_rn(e3);
-                            kl.numOfPixels = max(abs(rx2 - rx1), abs(ry2 - ry1)) + 1;
-                            kl.angle = (float)atan2((double)f_sub(e3, e1), (double)f_sub(e2, e0));
-                            kl.class_id = nl; kl.octave = 0;
-                            kl.size = f_mul(f_sub(e2, e0), f_sub(e3, e1));
-                            kl.response = f_div(kl.lineLength, (float)max(cols, rows));
-                            kl.pt_x = f_div(f_add(e2, e0), 2.0f); kl.pt_y = f_div(f_add(e3, e1), 2.0f);
-                            out[nl] = kl;
-                        }
-                        ++nl;
-                    } else if (lane == 0) atomicOr(status, 8);
-                }
+                    ++nreg;
+                    rbase += n;
+                } else if (lane == 0) atomicOr(status, 8);
             }
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); t_rect += t1 - t0; t0 = t1; }
@@ -605,7 +503,163 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #ifdef OLF_TIMING
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = t_seed; o[1] = t_small; o[2] = t_big; o[3] = t_rect; o[4] = n_small; o[5] = n_big; o[6] = it_small; o[7] = it_big; }
 #endif
-    if (lane == 0) rawCount[img] = nl;
+    if (lane == 0) regCount[img] = nreg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// region2rect + the Vec4f end points of LSDDetectorC::detectImpl for every logged region (cv LSD region2rect / get_theta,
+// LSDDetector_custom.cpp:270-289).  Regions are independent once grown: one thread per region, its sums run over the region's pixels in
+// growth order (exactly the reference's order).  The segment candidate (clamped end points, length, keep flag) goes to a 24-byte record;
+// k_lsd_emit then walks each image's candidates in detection order and writes the KeyLines that pass the length filter.
+struct SegCand { float e0, e1, e2, e3, length; int keep; };
+
+__global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
+                                                  const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
+                                                  const int* __restrict__ regCount, SegCand* __restrict__ candAll)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= regCount[img]) return;
+    const uint32_t* grad = gradAll + (size_t)img * g.Ps;
+    const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
+    const uint32_t* px_list = regionAll + (size_t)img * g.Ps + rr.start;
+    const int n = rr.n, Ws = g.Ws;
+    // both passes are chains of dependent loads (pixel list -> gradient word); 8 pixels are fetched per step so that the loads of a
+    // step are in flight together, the additions stay strictly in growth order
+    constexpr int U = 8;
+    double x = 0, y = 0, sum = 0;
+    for (int q0 = 0; q0 < n; q0 += U) {
+        uint32_t rp[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u < n) {
+                const int px = (int)(rp[u] & 0xffffu), py = (int)(rp[u] >> 16);
+                const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
+                const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                x = d_add(x, d_mul((double)px, wt));
+                y = d_add(y, d_mul((double)py, wt));
+                sum = d_add(sum, wt);
+            }
+        }
+    }
+    x = x / sum; y = y / sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int q0 = 0; q0 < n; q0 += U) {
+        uint32_t rp[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u < n) {
+                const int px = (int)(rp[u] & 0xffffu), py = (int)(rp[u] >> 16);
+                const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
+                const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const double ex = d_sub((double)px, x), ey = d_sub((double)py, y);
+                Ixx = d_add(Ixx, d_mul(d_mul(ey, ey), wt));
+                Iyy = d_add(Iyy, d_mul(d_mul(ex, ex), wt));
+                Ixy = d_sub(Ixy, d_mul(d_mul(ex, ey), wt));
+            }
+        }
+    }
+    const double dI = d_sub(Ixx, Iyy);
+    const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)dev_fastAtan2((float)d_sub(lambda, Ixx), (float)Ixy)
+                                           : (double)dev_fastAtan2((float)Ixy, (float)d_sub(lambda, Iyy));
+    theta = d_mul(theta, kDegToRads);
+    {
+        double diff = d_sub(theta, rr.angle);
+        while (diff <= -kPI) diff = d_add(diff, kM2PI);
+        while (diff > kPI) diff = d_sub(diff, kM2PI);
+        if (fabs(diff) > g.prec) theta = d_add(theta, kPI);
+    }
+    double ddx, ddy;
+    sincos(theta, &ddy, &ddx);
+    // extent along the axis: "if (l > l_max) .. else if (l < l_min) .." from (0, 0) is max(0, max l) / min(0, min l)
+    double l_min = 0, l_max = 0;
+    for (int q0 = 0; q0 < n; q0 += U) {
+        uint32_t rp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (q0 + u < n) {
+                const double rdx = d_sub((double)(int)(rp[u] & 0xffffu), x), rdy = d_sub((double)(int)(rp[u] >> 16), y);
+                const double lq = d_add(d_mul(rdx, ddx), d_mul(rdy, ddy));
+                l_max = fmax(l_max, lq); l_min = fmin(l_min, lq);
+            }
+        }
+    }
+    double x1 = d_add(x, d_mul(l_min, ddx)), y1 = d_add(y, d_mul(l_min, ddy));
+    double x2 = d_add(x, d_mul(l_max, ddx)), y2 = d_add(y, d_mul(l_max, ddy));
+    x1 = d_add(x1, 0.5); y1 = d_add(y1, 0.5); x2 = d_add(x2, 0.5); y2 = d_add(y2, 0.5);
+    if (g.scale != 1) { x1 = x1 / g.scale; y1 = y1 / g.scale; x2 = x2 / g.scale; y2 = y2 / g.scale; }
+    float e0 = (float)x1, e1 = (float)y1, e2 = (float)x2, e3 = (float)y2;
+    const int cols = g.W, rows = g.H;
+    if (e0 < 0) e0 = 0;
+    if (e0 >= cols) e0 = (float)cols - 1.0f;
+    if (e2 < 0) e2 = 0;
+    if (e2 >= cols) e2 = (float)cols - 1.0f;
+    if (e1 < 0) e1 = 0;
+    if (e1 >= rows) e1 = (float)rows - 1.0f;
+    if (e3 < 0) e3 = 0;
+    if (e3 >= rows) e3 = (float)rows - 1.0f;
+    const double dxe = (double)f_sub(e0, e2), dye = (double)f_sub(e1, e3);
+    const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
+    SegCand c; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.length = (float)length; c.keep = length > g.minLength;
+    candAll[(size_t)img * g.maxRegions + r] = c;
+}
+
+// LSDDetectorC::detectImpl, Vec4f -> KeyLine (LSDDetector_custom.cpp:290-307): one workgroup per image, candidates in detection order,
+// ordered compaction of the ones that pass the length filter (class_id = position in the output).
+__global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ gp, const SegCand* __restrict__ candAll, const int* __restrict__ regCount,
+                                                  olf_keyline* __restrict__ rawLines, int* __restrict__ rawCount, int* __restrict__ status)
+{
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SegCand* cand = candAll + (size_t)img * g.maxRegions;
+    olf_keyline* out = rawLines + (size_t)img * g.maxDetect;
+    const int nreg = regCount[img];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < nreg; r0 += 256) {
+        const int r = r0 + tid;
+        SegCand c; c.keep = 0;
+        if (r < nreg) c = cand[r];
+        const unsigned long long km = __ballot(c.keep != 0);
+        if (lane == 0) s_wave[wave] = __popcll(km);
+        __syncthreads();
+        int pos = s_base + __popcll(km & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) pos += s_wave[w];
+        if (c.keep) {
+            if (pos < g.maxDetect) {
+                const float e0 = c.e0, e1 = c.e1, e2 = c.e2, e3 = c.e3;
+                olf_keyline kl;
+                kl.startPointX = e0; kl.startPointY = e1; kl.endPointX = e2; kl.endPointY = e3;
+                kl.sPointInOctaveX = e0; kl.sPointInOctaveY = e1; kl.ePointInOctaveX = e2; kl.ePointInOctaveY = e3;
+                kl.lineLength = c.length;
+                const int rx1 = __float2int_rn(e0), ry1 = __float2int_rn(e1), rx2 = __float2int_rn(e2), ry2 = __float2int_rn(e3);
+                kl.numOfPixels = max(abs(rx2 - rx1), abs(ry2 - ry1)) + 1;
+                kl.angle = (float)atan2((double)f_sub(e3, e1), (double)f_sub(e2, e0));
+                kl.class_id = pos; kl.octave = 0;
+                kl.size = f_mul(f_sub(e2, e0), f_sub(e3, e1));
+                kl.response = f_div(kl.lineLength, (float)max(g.W, g.H));
+                kl.pt_x = f_div(f_add(e2, e0), 2.0f); kl.pt_y = f_div(f_add(e3, e1), 2.0f);
+                out[pos] = kl;
+            } else atomicOr(status, 8);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) rawCount[img] = min(s_base, g.maxDetect);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,7 +698,13 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, b.rawLines, b.rawCount, b.status, b.angDeg, b.cosSin);
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin);
+    // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
+    hipLaunchKernelGGL(k_lsd_rect, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
+                       reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB));
+    hipLaunchKernelGGL(k_lsd_emit, dim3(n_images), dim3(256), 0, s, b.geom, reinterpret_cast<const SegCand*>(b.keysB), b.regCount, b.rawLines,
+                       b.rawCount, b.status);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
