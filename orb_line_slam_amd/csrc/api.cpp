@@ -75,10 +75,10 @@ hipStream_t ctx_stream(olf_ctx* c) { return c->stream; }
 int ctx_scratch(olf_ctx* c, int slot, size_t bytes, void** out) { return scratch_get(c, slot, bytes, out); }
 }
 
-enum { ST_ORB_PYRAMID, ST_ORB_FAST, ST_ORB_OCTREE, ST_ORB_BLUR, ST_ORB_DESCRIBE, ST_STEREO_POINTS, ST_LSD_FRONT, ST_LSD_GROW, ST_LINE_LBD,
+enum { ST_ORB_PYRAMID, ST_ORB_FAST, ST_ORB_OCTREE, ST_ORB_BLUR, ST_ORB_DESCRIBE, ST_STEREO_POINTS, ST_LSD_FRONT, ST_LSD_GROW, ST_LSD_RECT, ST_LINE_LBD,
        ST_STEREO_LINES, ST_MATCH_BF, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"orb_pyramid", "orb_fast_cells", "orb_octree", "orb_blur", "orb_describe", "stereo_points",
-                                            "lsd_front", "lsd_grow", "line_select_lbd", "stereo_lines", "match_bf"};
+                                            "lsd_front", "lsd_grow", "lsd_rect", "line_select_lbd", "stereo_lines", "match_bf"};
 
 static hipEvent_t prof_event(olf_ctx* c)
 {
@@ -578,6 +578,7 @@ int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     { StageScope t(c, s, ST_LSD_FRONT); OLF_TRY(launch_lsd_front(c->line.geom, c->lb, d_images, c->W, n_images, s)); }
     { StageScope t(c, s, ST_LSD_GROW); OLF_TRY(launch_lsd_grow(c->line.geom, c->lb, n_images, s)); }
+    { StageScope t(c, s, ST_LSD_RECT); OLF_TRY(launch_lsd_rect(c->line.geom, c->lb, n_images, s)); }
     { StageScope t(c, s, ST_LINE_LBD); OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s)); }
     return OLF_OK;
 }

@@ -75,6 +75,7 @@ struct LineHostTables {
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s);
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
+int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images,
                            olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s);
 int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,

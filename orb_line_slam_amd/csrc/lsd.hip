@@ -700,6 +700,12 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
 {
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                        reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
+{
     // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
     hipLaunchKernelGGL(k_lsd_rect, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
                        reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB));

@@ -3,12 +3,15 @@
 // computeOrbDescriptor (:110-149) on the blurred level, the scale-up of pt (:1097-1103) and the
 // level-ascending concatenation (:1078-1106).  One 64-lane wave per key point: the 749-pixel
 // intensity-centroid disc is summed 2 rows per pass, the 256 steered-BRIEF tests are 4 ballots.
+// The kernel is bound by the texture-address / L1 pipeline (hundreds of cache-line lookups per key point when every lane gathers single
+// bytes), so the 37x37 blurred patch the rotated pattern can reach is staged in LDS with row-coalesced 32-bit loads and gathered from
+// there; the test pattern (one 32-bit word per test) and umax sit in LDS as well.
 #include "olf_internal.hpp"
 #include "device_math.hpp"
 
 namespace olf {
 
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
@@ -18,9 +21,16 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int out_cap,
                                                   int* __restrict__ status)
 {
+    constexpr int PR = 18, PW = 2 * PR + 1, PDW = 10;      // patch radius (|rotated pattern coordinate| <= round(13 * sqrt 2) = 18), 37 rows of 10 dwords
+    __shared__ uint32_t s_pat[256];
+    __shared__ int s_umax[kHalfPatch + 1];
+    __shared__ uint32_t s_patch[4][PW * PDW];
     const OrbGeom& g = *gp;
-    const int img = blockIdx.y, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wv;
+    s_pat[threadIdx.x] = reinterpret_cast<const uint32_t*>(c_pattern)[threadIdx.x];
+    if (threadIdx.x <= kHalfPatch) s_umax[threadIdx.x] = g.umax[threadIdx.x];
+    __syncthreads();
     const int* lc = lvlCount + img * g.nlevels;
     if (slot == 0 && lane == 0) {
         int tot = 0;
@@ -44,11 +54,11 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
     const uint8_t* im = pyr + (size_t)img * g.pyrBytes + L.offset;
     int m10 = 0, m01 = 0;
     const int half = lane >> 5, ul = lane & 31;
-#pragma unroll 4
+#pragma unroll
     for (int pass = 0; pass < 16; ++pass) {
         const int v = -kHalfPatch + 2 * pass + half;
         if (v <= kHalfPatch) {
-            const int d = g.umax[v < 0 ? -v : v];
+            const int d = s_umax[v < 0 ? -v : v];
             const int u = ul - 15;
             if (u >= -d && u <= d) {
                 const int val = im[(size_t)(cy + v) * L.pitch + cx + u];
@@ -68,17 +78,32 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float rad = __fmul_rn(angle, factorPI);
     const float a = glibc_cosf(rad), b = glibc_sinf(rad);
-    const uint8_t* bl = blur + (size_t)img * g.pyrBytes + L.offset + (size_t)cy * L.pitch + cx;
+    // stage rows cy-18 .. cy+18, bytes x0 .. x0+39 (x0 = (cx-18) rounded down to a dword) of the blurred level
+    const uint8_t* bl = blur + (size_t)img * g.pyrBytes + L.offset;
+    const int x0 = (cx - PR) & ~3, xs = cx - x0;          // patch column of the key point
+    uint32_t* patch = s_patch[wv];
+#pragma unroll
+    for (int k = 0; k < (PW * PDW + 63) / 64; ++k) {
+        const int idx = k * 64 + lane;
+        if (idx < PW * PDW) {
+            const int row = idx / PDW, col = idx - row * PDW;
+            const int xo = min(x0 + 4 * col, L.pitch - 4);             // the clamped dword only holds bytes no test can reach
+            patch[idx] = *reinterpret_cast<const uint32_t*>(bl + (size_t)(cy - PR + row) * L.pitch + xo);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(patch) + PR * (PDW * 4) + xs;
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int8_t* pt = &c_pattern[(j * 64 + lane) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[r0 * L.pitch + c0], t1 = bl[r1 * L.pitch + c1];
+        const uint32_t pw = s_pat[j * 64 + lane];
+        const float x0f = (float)(int8_t)(pw & 0xff), y0f = (float)(int8_t)((pw >> 8) & 0xff);
+        const float x1f = (float)(int8_t)((pw >> 16) & 0xff), y1f = (float)(int8_t)(pw >> 24);
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0f, b), __fmul_rn(y0f, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0f, a), __fmul_rn(y0f, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1f, b), __fmul_rn(y1f, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1f, a), __fmul_rn(y1f, b)));
+        const int t0 = pb[r0 * (PDW * 4) + c0], t1 = pb[r1 * (PDW * 4) + c1];
         bits[j] = __ballot(t0 < t1);
     }
     if (lane == 0) {
