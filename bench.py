@@ -192,7 +192,8 @@ def main():
         # KiB counters, per image), scaled to this launch's image count; null when no PMC summary has been committed for the kernel.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1b_pmc_hbm_traffic.json")))
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]))    # latest committed PMC summary
             kname = {"lsd_grow": "olf::k_lsd_grow", "orb_octree": "olf::k_octree", "orb_describe": "olf::k_describe"}[dom]
             if kname in pm["kernels"]:
                 traffic = int(pm["kernels"][kname]["bytes_per_image"] * 2 * B)
