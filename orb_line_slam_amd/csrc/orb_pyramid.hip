@@ -112,14 +112,16 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw);
     }
     __syncthreads();
-    __shared__ unsigned short s_list[FT_W * FT_H];
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ unsigned short s_cand[FT_W * FT_H], s_list[FT_W * FT_H];
+    __shared__ int s_nc, s_n;
+    if (threadIdx.x == 0) { s_nc = 0; s_n = 0; }
     __syncthreads();
-    const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4;
+    const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4, lane = threadIdx.x & 63;
     uint8_t* dst = score + (size_t)img * pyrBytes + L.offset;
-    // ---- phase A: corner test of the thread's 4x4 pixels (tile rows ry0 .. ry0+9, tile bytes 4q .. 4q+11; pixel p sits
-    // at byte 4q+4+p).  Corners are queued; every word of the score map is cleared.
+    // ---- phase A1: high-speed rejection on the thread's 4x4 pixels (tile rows ry0 .. ry0+9, tile bytes 4q .. 4q+11; pixel p sits at
+    // byte 4q+4+p).  A 9-arc of the 16-ring always covers two ADJACENT compass points (N/E/S/W), so a pixel can only be a corner if two
+    // adjacent compass points are both brighter than v+t or both darker than v-t.  Survivors are queued (one LDS atomic per wave and
+    // pixel slot); every word of the score map is cleared.
     uint32_t w[10][3];
 #pragma unroll
     for (int r = 0; r < 10; ++r)
@@ -133,40 +135,52 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             const int gx = x0 + 4 * q + p;
             const int c = rr + 3, b = p + 4;                       // centre row in w[], centre byte
             const int v = FB(w[c][0], w[c][1], w[c][2], b);
-            // a 9-arc of the 16-ring always contains two of the four compass points: cheap rejection for flat areas
             const int n0 = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b), n8 = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b);
             const int n4 = FB(w[c][0], w[c][1], w[c][2], b + 3), n12 = FB(w[c][0], w[c][1], w[c][2], b - 3);
             const int hiT = v + minTh, loT = v - minTh;
-            const int nb = (n0 > hiT) + (n4 > hiT) + (n8 > hiT) + (n12 > hiT), nd = (n0 < loT) + (n4 < loT) + (n8 < loT) + (n12 < loT);
-            if ((nb >= 2 || nd >= 2) && gx >= xBeg && gx < xEnd && gy < yEnd) {
-                int ring[16];
-                ring[0] = n0; ring[4] = n4; ring[8] = n8; ring[12] = n12;
-                ring[1] = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b + 1);  ring[2] = FB(w[c + 2][0], w[c + 2][1], w[c + 2][2], b + 2);
-                ring[3] = FB(w[c + 1][0], w[c + 1][1], w[c + 1][2], b + 3);  ring[5] = FB(w[c - 1][0], w[c - 1][1], w[c - 1][2], b + 3);
-                ring[6] = FB(w[c - 2][0], w[c - 2][1], w[c - 2][2], b + 2);  ring[7] = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b + 1);
-                ring[9] = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b - 1);  ring[10] = FB(w[c - 2][0], w[c - 2][1], w[c - 2][2], b - 2);
-                ring[11] = FB(w[c - 1][0], w[c - 1][1], w[c - 1][2], b - 3); ring[13] = FB(w[c + 1][0], w[c + 1][1], w[c + 1][2], b - 3);
-                ring[14] = FB(w[c + 2][0], w[c + 2][1], w[c + 2][2], b - 2); ring[15] = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b - 1);
-                uint32_t dark = 0, bright = 0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    dark |= (uint32_t)(ring[k] < loT) << k;
-                    bright |= (uint32_t)(ring[k] > hiT) << k;
-                }
-                if (run9(dark) || run9(bright)) s_list[atomicAdd(&s_n, 1)] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
+            const bool b0 = n0 > hiT, b4 = n4 > hiT, b8 = n8 > hiT, b12 = n12 > hiT;
+            const bool d0 = n0 < loT, d4 = n4 < loT, d8 = n8 < loT, d12 = n12 < loT;
+            const bool pass = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) && gx >= xBeg && gx < xEnd && gy < yEnd;
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nc, __popcll(pm));
+                base = __shfl(base, 0);
+                if (pass) s_cand[base + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
             }
         }
         const int gx0 = x0 + 4 * q;
         if (gy < yEnd && gx0 < xEnd) *reinterpret_cast<uint32_t*>(dst + (size_t)gy * L.pitch + gx0) = 0u;
     }
     __syncthreads();
-    // ---- phase B: scores of the queued corners, one corner per thread (dense lanes)
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
+    constexpr int P = FT_INW * 4;
+    // ---- phase A2: the full segment test of the survivors, one per lane (dense): 16 ring bytes from the LDS tile, brighter / darker
+    // masks, >= 9 contiguous.  Corners are queued for scoring.
+    const int nCand = s_nc;
+    for (int i = threadIdx.x; i < nCand; i += 256) {
+        const int id = s_cand[i], ty = id / FT_W, tx = id - ty * FT_W;
+        const uint8_t* c = tb + (ty + 3) * P + tx + 4;
+        const int v = c[0], hiT = v + minTh, loT = v - minTh;
+        int ring[16];
+        ring[0] = c[3 * P];   ring[1] = c[3 * P + 1];   ring[2] = c[2 * P + 2];   ring[3] = c[P + 3];
+        ring[4] = c[3];       ring[5] = c[-P + 3];      ring[6] = c[-2 * P + 2];  ring[7] = c[-3 * P + 1];
+        ring[8] = c[-3 * P];  ring[9] = c[-3 * P - 1];  ring[10] = c[-2 * P - 2]; ring[11] = c[-P - 3];
+        ring[12] = c[-3];     ring[13] = c[P - 3];      ring[14] = c[2 * P - 2];  ring[15] = c[3 * P - 1];
+        uint32_t dark = 0, bright = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            dark |= (uint32_t)(ring[k] < loT) << k;
+            bright |= (uint32_t)(ring[k] > hiT) << k;
+        }
+        if (run9(dark) || run9(bright)) s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
+    }
+    __syncthreads();
+    // ---- phase B: scores of the queued corners, one corner per thread (dense lanes)
     const int nC = s_n;
     for (int i = threadIdx.x; i < nC; i += 256) {
         const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
-        const uint8_t* c = tb + (ty + 3) * (FT_INW * 4) + tx + 4;
-        constexpr int P = FT_INW * 4;
+        const uint8_t* c = tb + (ty + 3) * P + tx + 4;
         const int v = c[0];
         int d[16], ndv[16];
         d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
