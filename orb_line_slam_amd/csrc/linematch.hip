@@ -117,23 +117,37 @@ __global__ __launch_bounds__(64) void k_lines_dist(const LinePrep* __restrict__ 
     m21[(size_t)pair * cap + i2] = who;
 }
 
-// one thread per left line: best / second best over the considered candidates, ratio + mutual test,
-// then the end-point disparities of src/Frame.cc:930-960
-__global__ __launch_bounds__(64) void k_lines_resolve(const olf_keyline* __restrict__ kls, const int* __restrict__ counts, int cap,
-                                                      const uint16_t* __restrict__ dist, const int* __restrict__ m21, olf_stereo_params P,
-                                                      int* __restrict__ m12, float* __restrict__ disp, double* __restrict__ le)
+// one wave per left line: best / second best over the considered candidates (the row of the distance matrix is read coalesced, lanes
+// stride over the right lines; first index wins a tie, the second best is the second smallest value of the multiset -- what the
+// reference's sequential scan produces), ratio + mutual test, then the end-point disparities of src/Frame.cc:930-960 on lane 0
+__global__ __launch_bounds__(256) void k_lines_resolve(const olf_keyline* __restrict__ kls, const int* __restrict__ counts, int cap,
+                                                       const uint16_t* __restrict__ dist, const int* __restrict__ m21, olf_stereo_params P,
+                                                       int* __restrict__ m12, float* __restrict__ disp, double* __restrict__ le)
 {
-    const int pair = blockIdx.y, i1 = blockIdx.x * 64 + threadIdx.x;
+    const int pair = blockIdx.y, i1 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nL = counts[2 * pair], nR = counts[2 * pair + 1];
     if (i1 >= nL) return;
     const uint16_t* row = dist + (size_t)pair * cap * cap + (size_t)i1 * cap;
-    int best_d = 0x7fffffff, best_d2 = 0x7fffffff, best_idx = -1;
-    for (int i2 = 0; i2 < nR; ++i2) {
+    unsigned key = 0xffffffffu;            // (distance << 16 | index) of the lane's best
+    int second = 0x7fffffff;               // the lane's second smallest distance
+    for (int i2 = lane; i2 < nR; i2 += 64) {
         const int d = row[i2];
         if (d == 0xffff) continue;
-        if (d < best_d) { best_d2 = best_d; best_d = d; best_idx = i2; }
-        else if (d < best_d2) best_d2 = d;
+        const unsigned k = ((unsigned)d << 16) | (unsigned)i2;
+        if (k < key) { if (key != 0xffffffffu) second = (int)(key >> 16); key = k; }      // lane indices ascend: k < key <=> d < best
+        else if (d < second) second = d;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned ok = (unsigned)__shfl_xor((int)key, o);
+        const int os = __shfl_xor(second, o);
+        const unsigned lo = min(key, ok), hi = max(key, ok);
+        const int hv = hi == 0xffffffffu ? 0x7fffffff : (int)(hi >> 16);
+        second = min(min(second, os), hv);
+        key = lo;
+    }
+    if (lane != 0) return;
+    const int best_d = key == 0xffffffffu ? 0x7fffffff : (int)(key >> 16), best_d2 = second, best_idx = key == 0xffffffffu ? -1 : (int)(key & 0xffffu);
     int match = -1;
     if ((double)best_d < d_mul((double)best_d2, P.min_ratio_12_l)) match = best_idx;
     if (match >= 0 && P.best_lr_matches && m21[(size_t)pair * cap + match] != i1) match = -1;
@@ -192,7 +206,7 @@ int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, c
     hipLaunchKernelGGL(k_lines_prep, dim3((cap + 63) / 64, 2 * n_pairs), dim3(64), 0, s, d_kls, d_counts, cap, W, H, prep);
     hipLaunchKernelGGL(k_lines_dist, dim3((cap + 63) / 64, n_pairs), dim3(64), 0, s, prep, d_desc, d_counts, cap, P.matching_s_ws, P.line_sim_th,
                        P.best_lr_matches, d_dist, d_m21);
-    hipLaunchKernelGGL(k_lines_resolve, dim3((cap + 63) / 64, n_pairs), dim3(64), 0, s, d_kls, d_counts, cap, d_dist, d_m21, P, d_m12, d_disp, d_le);
+    hipLaunchKernelGGL(k_lines_resolve, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, d_kls, d_counts, cap, d_dist, d_m21, P, d_m12, d_disp, d_le);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
