@@ -47,6 +47,7 @@ struct LineDeviceBufs {
     uint32_t* keysB = nullptr;
     int* keyCount = nullptr;       // [n] defined-pixel count
     int* maxN = nullptr;           // [n] max gx^2+gy^2 over defined pixels
+    int* chunkCnt = nullptr;       // [n][ceil(Ps / 4096)] defined pixels per gradient chunk (raster-ordered key emission)
     unsigned* segBegin = nullptr;  // [n] segment offsets for the sort
     unsigned* segEnd = nullptr;
     uint8_t* used = nullptr;

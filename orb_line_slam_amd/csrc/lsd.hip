@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void k_lsd_upsample(const uint8_t* __restrict_
 // One block covers LG_CHUNK consecutive pixels of one image (a single atomic per block).
 constexpr int LG_CHUNK = 4096;
 __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
-                                                  const LineGeom* __restrict__ gp, int* __restrict__ maxN)
+                                                  const LineGeom* __restrict__ gp, int* __restrict__ maxN, int* __restrict__ chunkCnt)
 {
-    __shared__ int s_max[4];
+    __shared__ int s_max[4], s_def[4];
     const LineGeom& g = *gp;
     const int img = blockIdx.y;
-    int n = 0;
+    int n = 0, ndef = 0;
     const uint8_t* sc = scaled + (size_t)img * g.pitchS * g.Hs;
 #pragma unroll 4
     for (int k = 0; k < LG_CHUNK / 256; ++k) {
@@ -143,37 +143,49 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
                 const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
                 const int gx = DA + BC, gy = DA - BC;
                 const int nn = gx * gx + gy * gy;
-                if (nn >= g.nThr) { packed = pack_g(gx, gy); n = max(n, nn); }
+                if (nn >= g.nThr) { packed = pack_g(gx, gy); n = max(n, nn); ++ndef; }
             }
             grad[(size_t)img * g.Ps + idx] = packed;
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_xor(n, o));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = n;
+    for (int o = 32; o > 0; o >>= 1) { n = max(n, __shfl_xor(n, o)); ndef += __shfl_xor(ndef, o); }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = n; s_def[threadIdx.x >> 6] = ndef; }
     __syncthreads();
     if (threadIdx.x == 0) {
         n = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (n > 0) atomicMax(&maxN[img * 32], n);   // counters padded to one per 128-byte line
+        chunkCnt[(size_t)img * gridDim.x + blockIdx.x] = s_def[0] + s_def[1] + s_def[2] + s_def[3];   // defined pixels of this chunk
     }
 }
 
-// ll_angle, second half: bin of every defined pixel -> sort key (one atomic per block)
+// ll_angle, second half: bin of every defined pixel -> sort key.  The keys are emitted in raster order (each wave compacts a contiguous
+// quarter of the chunk, chunk bases come from k_lsd_grad's per-chunk counts), so the pseudo-ordering only has to order the 10 bin
+// bits with a stable sort: equal bins stay in raster order, which is the reference's list order.
 __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
-                                                  const int* __restrict__ maxN, uint32_t* __restrict__ keys, int* __restrict__ keyCount,
-                                                  uint32_t* __restrict__ degbuf)
+                                                  const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
+                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf)
 {
+    constexpr int SPAN = LG_CHUNK / 4;
     __shared__ uint32_t s_keys[LG_CHUNK];
-    __shared__ int s_cnt, s_base;
+    __shared__ int s_wcnt[4], s_base;
     const LineGeom& g = *gp;
-    const int img = blockIdx.y, lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_cnt = 0;
+    const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
+    {   // keys of the chunks before this one
+        int part = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += chunkCnt[(size_t)img * gridDim.x + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0 && part) atomicAdd(&s_base, part);
+    }
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
+    int wc = 0;
 #pragma unroll 4
-    for (int k = 0; k < LG_CHUNK / 256; ++k) {
-        const int idx = blockIdx.x * LG_CHUNK + k * 256 + threadIdx.x;
+    for (int k = 0; k < SPAN / 64; ++k) {
+        const int idx = blockIdx.x * LG_CHUNK + wv * SPAN + k * 64 + lane;
         bool def = false;
         uint32_t key = 0;
         if (idx < g.Ps) {
@@ -189,16 +201,15 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ g
             }
         }
         const unsigned long long m = __ballot(def);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(&s_cnt, __popcll(m));
-        base = __shfl(base, 0);
-        if (def) s_keys[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        if (def) s_keys[wv * SPAN + wc + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        wc += __popcll(m);
     }
+    if (lane == 0) s_wcnt[wv] = wc;
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&keyCount[img * 32], s_cnt) : 0;
-    __syncthreads();
-    const int cnt = s_cnt, base = s_base;
-    for (int i = threadIdx.x; i < cnt; i += 256) keys[(size_t)img * g.Ps + base + i] = s_keys[i];
+    int base = s_base;
+    for (int v = 0; v < wv; ++v) base += s_wcnt[v];
+    for (int i = lane; i < wc; i += 64) keys[(size_t)img * g.Ps + base + i] = s_keys[wv * SPAN + i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
 }
 
 // A seed whose 8 neighbours are all undefined or not aligned with the seed's own angle can never grow: its region is
@@ -667,7 +678,7 @@ size_t lsd_sort_temp_bytes(int total_keys, int n_segments)
 {
     size_t bytes = 0;
     (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)total_keys,
-                                             (unsigned)n_segments, (unsigned*)nullptr, (unsigned*)nullptr, 0, 32, (hipStream_t)0);
+                                             (unsigned)n_segments, (unsigned*)nullptr, (unsigned*)nullptr, 22, 32, (hipStream_t)0);
     return bytes;
 }
 
@@ -685,14 +696,15 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }
-    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN);
-    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.keysA, b.keyCount, b.region);
+    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
+    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
+                       b.region);
     hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
     size_t tb = b.sortTempBytes;
     OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA, b.keysB, (unsigned)((size_t)n_images * g.Ps), (unsigned)n_images,
-                                                      b.segBegin, b.segEnd, 0, 32, s));
+                                                      b.segBegin, b.segEnd, 22, 32, s));
     return OLF_OK;
 }
 
