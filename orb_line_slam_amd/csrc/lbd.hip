@@ -128,19 +128,31 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
     for (int h = 0; h < hID; ++h) { sCorX0 = f_sub(sCorX0, dL1); sCorY0 = f_add(sCorY0, dL0); }
     float sCorX = sCorX0, sCorY = sCorY0;
     float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-    for (short wID = 0; wID < lengthOfLSP; ++wID) {
-        int tc = (int)(short)roundf(sCorX);
-        const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
-        tc = (int)(short)roundf(sCorY);
-        const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-        const uint32_t p = dxdy[yCor * realWidth + xCor];
-        const float dx = (float)(int)(int16_t)(p & 0xffffu), dy = (float)(int)(int16_t)(p >> 16);
-        const float gDL = f_add(f_mul(dx, dL0), f_mul(dy, dL1));
-        const float gDO = f_add(f_mul(dx, dO0), f_mul(dy, dO1));
-        if (gDL > 0) pgdL = f_add(pgdL, gDL); else ngdL = f_sub(ngdL, gDL);
-        if (gDO > 0) pgdO = f_add(pgdO, gDO); else ngdO = f_sub(ngdO, gDO);
-        sCorX = f_add(sCorX, dL0);
-        sCorY = f_add(sCorY, dL1);
+    // the sample coordinates are a cheap sequential float chain, the sums a sequential one on the loaded values: 4 samples are
+    // addressed and loaded per step so that their loads are in flight together (the kernel is latency bound), then accumulated in order
+    constexpr int U = 4;
+    for (int w0 = 0; w0 < lengthOfLSP; w0 += U) {
+        uint32_t p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int tc = (int)(short)roundf(sCorX);
+            const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+            tc = (int)(short)roundf(sCorY);
+            const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+            p[u] = dxdy[yCor * realWidth + xCor];           // (coordinates past the row end are clamped into the image, the value is unused)
+            sCorX = f_add(sCorX, dL0);
+            sCorY = f_add(sCorY, dL1);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (w0 + u < lengthOfLSP) {
+                const float dx = (float)(int)(int16_t)(p[u] & 0xffffu), dy = (float)(int)(int16_t)(p[u] >> 16);
+                const float gDL = f_add(f_mul(dx, dL0), f_mul(dy, dL1));
+                const float gDO = f_add(f_mul(dx, dO0), f_mul(dy, dO1));
+                if (gDL > 0) pgdL = f_add(pgdL, gDL); else ngdL = f_sub(ngdL, gDL);
+                if (gDO > 0) pgdO = f_add(pgdO, gDO); else ngdO = f_sub(ngdO, gDO);
+            }
+        }
     }
     const float cg = g.gaussCoefG[hID];
     rowSums[((size_t)img * g.outCap + li) * 63 + hID] = make_float4(f_mul(cg, pgdL), f_mul(cg, ngdL), f_mul(cg, pgdO), f_mul(cg, ngdO));
