@@ -49,13 +49,15 @@ def test_lbd_on_given_keylines(oracle):
     assert ex.compute(left, o["kls"][:0]).shape == (0, 32)
 
 
-@pytest.mark.parametrize("w,h,nf,nl,fx,bf", [(640, 480, 1000, 200, 435.2047, 47.9064), (1242, 375, 2000, 500, 718.856, 386.1448)])
-def test_stereo_frames(oracle, w, h, nf, nl, fx, bf):
+# BASELINE.json configs: C2 640x480 (1000 + 200), C3 KITTI 1242x375 (2000 + 500), C4 EuRoC 752x480, C5 1920x1080 (4000 + 1000)
+@pytest.mark.parametrize("w,h,nf,nl,fx,bf,npairs", [(640, 480, 1000, 200, 435.2047, 47.9064, 3), (1242, 375, 2000, 500, 718.856, 386.1448, 3),
+                                                    (752, 480, 1200, 300, 435.2047, 47.9064, 2), (1920, 1080, 4000, 1000, 1050.0, 126.0, 1)])
+def test_stereo_frames(oracle, w, h, nf, nl, fx, bf, npairs):
     p = oracle.full_params(nf, nl, fx, bf)
-    fe = ola.StereoFrontEnd(p, w, h, max_pairs=3)
-    imgs = synth.stereo_batch(31, 3, w, h)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=npairs)
+    imgs = synth.stereo_batch(31, npairs, w, h)
     f = fe.frames(imgs)
-    for i in range(3):
+    for i in range(npairs):
         g = f.pair(i)
         o = oracle.stereo_points(imgs[2 * i], imgs[2 * i + 1], p)
         assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"])
