@@ -169,7 +169,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     const size_t n = (size_t)max_images;
     OrbDeviceBufs& b = c->ob;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
-    A(b.pyr, n * g.pyrBytes); A(b.blur, n * g.pyrBytes); A(b.score, n * g.pyrBytes);
+    A(b.pyr, n * g.pyrBytes); A(b.blur, n * g.pyrBytes);
     A(b.cells, n * g.totalCells * g.cellCap); A(b.cellCount, n * g.totalCells);
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
@@ -180,7 +180,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (hipMemcpy(b.rx, c->orb.rx.data(), c->orb.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.ry, c->orb.ry.data(), c->orb.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.geom, &g, sizeof(OrbGeom), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(b.status, 0, 256) != hipSuccess || hipMemset(b.score, 0, n * g.pyrBytes) != hipSuccess) {
+        hipMemset(b.status, 0, 256) != hipSuccess) {
         set_error("olf_ctx_create: table upload failed");
         return fail(OLF_ERR_HIP);
     }

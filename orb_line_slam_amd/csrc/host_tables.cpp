@@ -140,6 +140,7 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
     g.pyrBytes = off;
     g.totalCells = cells;
     g.cellCap = cellCap;
+    if (cellCap > 1024) return OLF_ERR_CAPACITY;      // k_cells_sort orders a cell's candidates in a 1024-entry LDS array
     for (int l = 0; l < nlevels; ++l) {
         LevelGeom& L = g.lv[l];
         long cap = (long)L.nCols * L.nRows * cellCap;

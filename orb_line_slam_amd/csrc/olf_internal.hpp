@@ -8,7 +8,6 @@
 // HBM layout (per image, all level images packed with a 64-byte aligned pitch):
 //   pyr   : u8  levels 0..L-1   (level 0 is an aligned copy of the input)      mvImagePyramid
 //   blur  : u8  levels 0..L-1   GaussianBlur(7x7, sigma 2) of pyr               workingMat
-//   score : u8  levels 0..L-1   FAST-9/16 score (0 where score < minThFAST)
 //   cells : u32 per FAST cell a slot of cell_cap packed candidates (x:12 | y:12 | score:8, cell-local
 //           coordinates are converted to level coordinates relative to minBorder) + one count
 //   cand  : u32 per level, candidates gathered in reference order (vToDistributeKeys)
@@ -94,7 +93,6 @@ void resize_axis_coefs(int sn, int dn, double scale, bool clamp_like_x, ResizeCo
 struct OrbDeviceBufs {
     uint8_t* pyr = nullptr;       // [max_images][pyrBytes]
     uint8_t* blur = nullptr;
-    uint8_t* score = nullptr;
     uint32_t* cells = nullptr;    // [max_images][totalCells][cellCap]
     int* cellCount = nullptr;     // [max_images][totalCells]
     uint32_t* cand = nullptr;     // [max_images][candTotal]

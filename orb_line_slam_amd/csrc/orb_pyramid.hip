@@ -90,20 +90,29 @@ __device__ __forceinline__ bool run9(uint32_t m)   // >= 9 contiguous set bits i
     return (r & 0xffffu) != 0;
 }
 
-constexpr int FT_W = 128, FT_H = 32;                 // output tile; LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+34
+constexpr int FT_W = 128, FT_H = 32;                 // processed tile; LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+34
+constexpr int FT_EW = 124, FT_EH = 30;               // emitted part: columns 2 .. 125, rows 1 .. 30 (the rest is the NMS halo of the neighbours)
 constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
 
 // byte `idx` (0..11) of three consecutive little-endian words
 #define FB(w0, w1, w2, idx) ((int)((((idx) < 4 ? (w0) : (idx) < 8 ? (w1) : (w2)) >> (8 * ((idx) & 3))) & 0xffu))
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
-                                                    int pyrBytes, LevelGeom L, int minTh)
+// FAST-9/16 corners of one level, straight into the per-cell candidate lists of ComputeKeyPointsOctTree (src/ORBextractor.cc:791-831):
+// cv::FAST(cell sub-image, threshold, nonmaxSuppression = true) keeps the strict 3x3 local maxima of the corner score inside the cell's
+// interior (the sub-image minus its 3-pixel frame; everything outside counts as 0).  Tiles overlap by the 1-pixel NMS halo, so a tile
+// scores its corners into an LDS score tile, suppresses non-maxima there (neighbours in another cell do not count) and appends the
+// survivors to their cell's list.  No dense score map exists in memory; k_cells_sort orders each list and applies the dual threshold.
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, int minTh,
+                                                    uint32_t* __restrict__ cells, int* __restrict__ cellCount, int totalCells, int cellCap)
 {
     __shared__ uint32_t tile[FT_INH * FT_INW];
+    __shared__ unsigned short s_cand[FT_W * FT_H], s_list[FT_W * FT_H];
+    __shared__ uint8_t s_score[FT_H * FT_W];
+    __shared__ int s_nc, s_n;
     const int img = blockIdx.z;
-    // scores are needed on x in [minBorder+3, maxBorderX-3), y likewise; tiles start at x = 16 (4-byte aligned rows)
-    const int x0 = kMinBorder + blockIdx.x * FT_W, y0 = kMinBorder + 3 + blockIdx.y * FT_H;
-    const int xBeg = kMinBorder + 3, xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
+    // scores exist on x in [minBorder+3, maxBorderX-3), y likewise; tile origins are 4-byte aligned
+    const int x0 = kMinBorder - 4 + blockIdx.x * FT_EW, y0 = kMinBorder + 2 + blockIdx.y * FT_EH;
+    const int xBeg = kMinBorder + 3, yBeg = kMinBorder + 3, xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
     const uint8_t* src = pyr + (size_t)img * pyrBytes + L.offset;
     for (int i = threadIdx.x; i < FT_INH * FT_INW; i += 256) {
         const int r = i / FT_INW, j = i - r * FT_INW;
@@ -111,17 +120,14 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         const int xw = min(x0 - 4 + 4 * j, L.pitch - 4);          // rows are 64-byte aligned and padded to the pitch
         tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw);
     }
-    __syncthreads();
-    __shared__ unsigned short s_cand[FT_W * FT_H], s_list[FT_W * FT_H];
-    __shared__ int s_nc, s_n;
+    reinterpret_cast<uint4*>(s_score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x == 0) { s_nc = 0; s_n = 0; }
     __syncthreads();
     const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4, lane = threadIdx.x & 63;
-    uint8_t* dst = score + (size_t)img * pyrBytes + L.offset;
     // ---- phase A1: high-speed rejection on the thread's 4x4 pixels (tile rows ry0 .. ry0+9, tile bytes 4q .. 4q+11; pixel p sits at
     // byte 4q+4+p).  A 9-arc of the 16-ring always covers two ADJACENT compass points (N/E/S/W), so a pixel can only be a corner if two
     // adjacent compass points are both brighter than v+t or both darker than v-t.  Survivors are queued (one LDS atomic per wave and
-    // pixel slot); every word of the score map is cleared.
+    // pixel slot).
     uint32_t w[10][3];
 #pragma unroll
     for (int r = 0; r < 10; ++r)
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             const int hiT = v + minTh, loT = v - minTh;
             const bool b0 = n0 > hiT, b4 = n4 > hiT, b8 = n8 > hiT, b12 = n12 > hiT;
             const bool d0 = n0 < loT, d4 = n4 < loT, d8 = n8 < loT, d12 = n12 < loT;
-            const bool pass = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) && gx >= xBeg && gx < xEnd && gy < yEnd;
+            const bool pass = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) && gx >= xBeg && gx < xEnd && gy >= yBeg && gy < yEnd;
             const unsigned long long pm = __ballot(pass);
             if (pm) {
                 int base = 0;
@@ -149,8 +155,6 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
                 if (pass) s_cand[base + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
             }
         }
-        const int gx0 = x0 + 4 * q;
-        if (gy < yEnd && gx0 < xEnd) *reinterpret_cast<uint32_t*>(dst + (size_t)gy * L.pitch + gx0) = 0u;
     }
     __syncthreads();
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         if (run9(dark) || run9(bright)) s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
     }
     __syncthreads();
-    // ---- phase B: scores of the queued corners, one corner per thread (dense lanes)
+    // ---- phase B: scores of the queued corners into the LDS score tile, one corner per thread (dense lanes)
     const int nC = s_n;
     for (int i = threadIdx.x; i < nC; i += 256) {
         const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
@@ -191,78 +195,87 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
         for (int k = 0; k < 16; ++k) ndv[k] = -d[k];
         int sc = max(arc9_maxmin(d), arc9_maxmin(ndv)) - 1;
         if (sc < minTh) sc = 0;
-        dst[(size_t)(y0 + ty) * L.pitch + x0 + tx] = (uint8_t)sc;
+        s_score[id] = (uint8_t)sc;
+    }
+    __syncthreads();
+    // ---- phase C: strict 3x3 non-maximum suppression inside the cell interior, survivors appended to their cell
+    for (int i = threadIdx.x; i < nC; i += 256) {
+        const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
+        if (tx < 2 || tx >= 2 + FT_EW || ty < 1 || ty >= 1 + FT_EH) continue;           // halo: emitted by the neighbouring tile
+        const int cur = s_score[id];
+        if (cur == 0) continue;
+        const int gx = x0 + tx, gy = y0 + ty;
+        const int cj = (gx - xBeg) / L.wCell, ci = (gy - yBeg) / L.hCell;
+        const int lx = (gx - xBeg) - cj * L.wCell, ly = (gy - yBeg) - ci * L.hCell;
+        // neighbours outside the cell interior (or outside the scored area, where the tile holds 0) do not count
+        const bool xl = lx > 0, xr = lx < L.wCell - 1 && gx + 1 < xEnd, yu = ly > 0, yd = ly < L.hCell - 1 && gy + 1 < yEnd;
+        const uint8_t* sp = s_score + id;
+        int nb = 0;
+        if (yu) { nb = max(nb, (int)sp[-FT_W]); if (xl) nb = max(nb, (int)sp[-FT_W - 1]); if (xr) nb = max(nb, (int)sp[-FT_W + 1]); }
+        if (yd) { nb = max(nb, (int)sp[FT_W]); if (xl) nb = max(nb, (int)sp[FT_W - 1]); if (xr) nb = max(nb, (int)sp[FT_W + 1]); }
+        if (xl) nb = max(nb, (int)sp[-1]);
+        if (xr) nb = max(nb, (int)sp[1]);
+        if (cur > nb) {
+            const int cell = L.cellBase + ci * L.nCols + cj;
+            const int pos = atomicAdd(&cellCount[(size_t)img * totalCells + cell], 1);
+            if (pos < cellCap)      // (cannot overflow: strict local maxima are at most one per 2x2 block, cellCap is that bound)
+                cells[((size_t)img * totalCells + cell) * cellCap + pos] =
+                    ((uint32_t)(gy - kMinBorder) << 20) | ((uint32_t)(gx - kMinBorder) << 8) | (uint32_t)cur;   // (y, x, score): sort key
+        }
     }
 }
 #undef FB
 
 // ---------------------------------------------------------------------------------------------
-// Per-cell detection (src/ORBextractor.cc:791-831): cv::FAST(cell sub-image, iniThFAST, nms) and,
-// if that returns nothing, cv::FAST(..., minThFAST, nms).  With the score map this is: take the
-// strict 3x3 local maxima of the score restricted to the cell's interior (the sub-image minus its
-// 3-pixel frame; everything outside counts as 0); emit those with score >= iniTh if any exist,
-// otherwise all of them.  One wave per cell; output row-major inside the cell slot.
-__global__ __launch_bounds__(64) void k_cells(const uint8_t* __restrict__ score, const OrbGeom* __restrict__ gp,
-                                              uint32_t* __restrict__ cells, int* __restrict__ cellCount)
+// Per-cell dual threshold and ordering (src/ORBextractor.cc:799-831): if any survivor of the cell reaches iniThFAST only those are kept
+// (cv::FAST with iniThFAST returned something), otherwise all of them (the minThFAST retry); cv::FAST returns key points in row-major
+// order.  One wave per cell sorts the (y, x, score) keys in LDS and rewrites the slot as (x, y, score) entries.
+constexpr int CS_MAX = 1024;    // a cell is < 60 px wide and high (ceil(width / (width / 30))), so at most 30 x 30 strict local maxima
+__global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ gp, uint32_t* __restrict__ cells, int* __restrict__ cellCount)
 {
-    // lane = one column of the cell interior (<= 60 wide); rows stream through a 3-row register window, horizontal
-    // neighbours come from the adjacent lanes (DPP shuffles) -- no LDS.  Row y's keep / ini ballot is parked in lane y.
+    __shared__ uint32_t s_k[CS_MAX];
     const OrbGeom& g = *gp;
     const int img = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
-    int l = 0;
-    while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) ++l;
-    const LevelGeom& L = g.lv[l];
-    const int ci = (cell - L.cellBase) / L.nCols, cj = (cell - L.cellBase) - ci * L.nCols;
-    const int iniX = kMinBorder + cj * L.wCell, iniY = kMinBorder + ci * L.hCell;
     int* cnt = cellCount + (size_t)img * g.totalCells + cell;
-    if (iniY >= L.maxBorderY - 3 || iniX >= L.maxBorderX - 6) { if (lane == 0) *cnt = 0; return; }
-    const int maxX = min(iniX + L.wCell + 6, L.maxBorderX), maxY = min(iniY + L.hCell + 6, L.maxBorderY);
-    const int ix0 = iniX + 3, iy0 = iniY + 3, iw = maxX - 3 - ix0, ih = maxY - 3 - iy0;
-    if (iw <= 0 || ih <= 0) { if (lane == 0) *cnt = 0; return; }
-    const uint8_t* src = score + (size_t)img * g.pyrBytes + L.offset + (size_t)iy0 * L.pitch + ix0 + lane;
-    const bool col = lane < iw;
-    int prev = 0, cur = col ? (int)src[0] : 0, nxt;
-    unsigned long long myKeep = 0, myIni = 0;
-    for (int y = 0; y < ih; ++y) {
-        nxt = (col && y + 1 < ih) ? (int)src[(size_t)(y + 1) * L.pitch] : 0;
-        // max over the 8 neighbours; everything outside the cell interior counts as 0 (lanes >= iw hold 0, lane -1 / 64 masked)
-        const int v3 = max(prev, nxt);                       // vertical neighbours of this column
-        const int c3 = max(v3, cur);                         // column maximum incl. the centre (for the side columns)
-        int lft = __shfl_up(c3, 1), rgt = __shfl_down(c3, 1);
-        if (lane == 0) lft = 0;
-        if (lane == 63) rgt = 0;
-        const int nb = max(v3, max(lft, rgt));
-        const bool keep = cur > 0 && cur > nb;
-        const unsigned long long km = __ballot(keep), im = __ballot(keep && cur >= g.iniTh);
-        if (lane == y) { myKeep = km; myIni = im; }
-        prev = cur; cur = nxt;
-    }
-    const bool anyIni = __ballot(myIni != 0) != 0;
-    const unsigned long long chosen = anyIni ? myIni : myKeep;      // lane y: the surviving columns of row y
-    const int c = __popcll(chosen);
-    int inc = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-    }
-    const int myBase = inc - c, total = __shfl(inc, 63);
+    const int n = min(*cnt, g.cellCap);
+    if (n == 0) return;
     uint32_t* slot = cells + ((size_t)img * g.totalCells + cell) * g.cellCap;
-    unsigned long long rows = __ballot(chosen != 0);
-    while (rows) {
-        const int y = __builtin_ctzll(rows);
-        rows &= rows - 1;
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)chosen, y);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(chosen >> 32), y);
-        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-        const int base = __builtin_amdgcn_readlane(myBase, y);
-        if ((m >> lane) & 1ull) {
-            const int sc = src[(size_t)y * L.pitch];
-            slot[base + __popcll(m & ((1ull << lane) - 1ull))] =
-                ((uint32_t)(ix0 + lane - kMinBorder) << 20) | ((uint32_t)(iy0 + y - kMinBorder) << 8) | (uint32_t)sc;
-        }
+    int sortN = 64;
+    while (sortN < n) sortN <<= 1;
+    bool anyIni = false;
+    for (int i = lane; i < sortN; i += 64) {
+        const uint32_t k = i < n ? slot[i] : 0xffffffffu;
+        s_k[i] = k;
+        anyIni |= i < n && (int)(k & 0xffu) >= g.iniTh;
     }
-    if (lane == 0) *cnt = total;
+    anyIni = __ballot(anyIni) != 0;
+    __builtin_amdgcn_wave_barrier();
+    int kept = n;
+    if (anyIni) {
+        int drop = 0;
+        for (int i = lane; i < n; i += 64)
+            if ((int)(s_k[i] & 0xffu) < g.iniTh) { s_k[i] = 0xffffffffu; ++drop; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) drop += __shfl_xor(drop, o);
+        kept = n - drop;
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < sortN; t += 64) {
+                const int p = t ^ j;
+                if (p > t) {
+                    const uint32_t a = s_k[t], b = s_k[p];
+                    if (((t & k) == 0) ? a > b : a < b) { s_k[t] = b; s_k[p] = a; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    for (int i = lane; i < kept; i += 64) {
+        const uint32_t k = s_k[i];
+        slot[i] = (((k >> 8) & 0xfffu) << 20) | ((k >> 20) << 8) | (k & 0xffu);
+    }
+    if (lane == 0) *cnt = kept;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -344,14 +357,15 @@ int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* 
 
 int launch_orb_fast(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s)
 {
+    OLF_HIP_CHECK(hipMemsetAsync(b.cellCount, 0, (size_t)n_images * g.totalCells * sizeof(int), s));
     for (int l = 0; l < g.nlevels; ++l) {
         const LevelGeom& L = g.lv[l];
-        const int fw = L.maxBorderX - 3 - kMinBorder, fh = L.maxBorderY - 3 - (kMinBorder + 3);
+        const int fw = L.maxBorderX - 3 - (kMinBorder - 2), fh = L.maxBorderY - 3 - (kMinBorder + 3);   // emitted columns start at 14, rows at 19
         if (fw <= 0 || fh <= 0) continue;
-        hipLaunchKernelGGL(k_fast_score, dim3((fw + FT_W - 1) / FT_W, (fh + FT_H - 1) / FT_H, n_images), dim3(256), 0, s, b.pyr,
-                           b.score, g.pyrBytes, L, g.minTh);
+        hipLaunchKernelGGL(k_fast_score, dim3((fw + FT_EW - 1) / FT_EW, (fh + FT_EH - 1) / FT_EH, n_images), dim3(256), 0, s, b.pyr,
+                           g.pyrBytes, L, g.minTh, b.cells, b.cellCount, g.totalCells, g.cellCap);
     }
-    hipLaunchKernelGGL(k_cells, dim3(g.totalCells, n_images), dim3(64), 0, s, b.score, b.geom, b.cells, b.cellCount);
+    hipLaunchKernelGGL(k_cells_sort, dim3(g.totalCells, n_images), dim3(64), 0, s, b.geom, b.cells, b.cellCount);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
