@@ -112,6 +112,8 @@ int olf_orb_pyramid_level(olf_ctx* ctx, int image, int level, int blurred, uint8
 /* debug/test: per-level FAST candidates handed to DistributeOctTree (vToDistributeKeys,
  * src/ORBextractor.cc:821-827) as int32 triples (x,y,score) relative to minBorder. */
 int olf_orb_debug_candidates(olf_ctx* ctx, int image, int level, int32_t* xys, int cap, int32_t* count);
+/* debug: the context's 64-int device status block (overflow flags in [0]; instrumented builds put cycle counters at [16..31]). */
+int olf_debug_status(olf_ctx* ctx, int32_t* out64);
 
 /* ---- Frame::ComputeStereoMatches (src/Frame.cc:702-876) ------------------------------------- */
 /* Stereo point matching for n_pairs pairs whose ORB features (images 2p = left, 2p+1 = right) came from

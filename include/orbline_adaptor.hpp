@@ -11,6 +11,7 @@
 #pragma once
 #include <cstring>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 #include "orbline.h"
@@ -206,5 +207,44 @@ inline int matchNNR(olf_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* d
 {
     return match(ctx, desc1, n1, desc2, n2, nnr, false, matches_12);
 }
+
+// ORBVocabulary / LineVocabulary (include/ORBVocabulary.h:30-34 = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>): the tree lives on the
+// GPU; BowVec / FeatVec are the caller's DBoW2::BowVector (std::map<WordId, WordValue>) and DBoW2::FeatureVector
+// (std::map<NodeId, std::vector<unsigned>>) -- any ordered map with those value types works, entries arrive in ascending key order.
+class ORBVocabulary {
+public:
+    ORBVocabulary() : voc_(nullptr) {}
+    ~ORBVocabulary() { olf_voc_destroy(voc_); }
+    ORBVocabulary(const ORBVocabulary&) = delete;
+    ORBVocabulary& operator=(const ORBVocabulary&) = delete;
+    // bool loadFromTextFile(const std::string&), Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425
+    bool loadFromTextFile(const std::string& filename)
+    {
+        olf_voc_destroy(voc_); voc_ = nullptr;
+        return olf_voc_load_text(filename.c_str(), &voc_) == OLF_OK;
+    }
+    bool empty() const { return size() == 0; }
+    unsigned size() const { int nw = 0; return voc_ && olf_voc_info(voc_, nullptr, nullptr, nullptr, nullptr, nullptr, &nw) == OLF_OK ? (unsigned)nw : 0u; }
+    // void transform(const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup), :1127-1195
+    // (Frame::ComputeBoW, src/Frame.cc:585-597: descriptors = the rows of mDescriptors, levelsup = 4)
+    template <class BowVec, class FeatVec>
+    void transform(olf_ctx* ctx, const uint8_t* descriptors, int n, BowVec& v, FeatVec& fv, int levelsup) const
+    {
+        v.clear(); fv.clear();
+        if (!voc_ || n <= 0) return;
+        std::vector<int32_t> ids(n), nodes(n), offs(n + 1), idx(n);
+        std::vector<double> vals(n);
+        int nb = 0, nf = 0;
+        olf_detail::check(olf_bow_transform(ctx, voc_, descriptors, n, levelsup, ids.data(), vals.data(), &nb, nodes.data(), offs.data(), idx.data(), &nf),
+                          "olf_bow_transform");
+        for (int i = 0; i < nb; ++i) v.insert(v.end(), typename BowVec::value_type(ids[i], vals[i]));
+        for (int a = 0; a < nf; ++a)
+            fv.insert(fv.end(), typename FeatVec::value_type(nodes[a], typename FeatVec::mapped_type(idx.begin() + offs[a], idx.begin() + offs[a + 1])));
+    }
+    olf_voc* handle() const { return voc_; }
+private:
+    olf_voc* voc_;
+};
+typedef ORBVocabulary LineVocabulary;
 
 }  // namespace ORB_SLAM2

@@ -13,6 +13,13 @@ int main()
         std::vector<olf_keypoint> k; std::vector<uint8_t> d; std::vector<uint8_t> img(640 * 480, 7);
         try { orb(img.data(), 640, 480, k, d); return 3; } catch (const std::runtime_error& e) { std::printf("expected: %s\n", e.what()); }
     }
+    {   // the vocabulary adaptor instantiates with DBoW2's container types (std::map based)
+        ORB_SLAM2::ORBVocabulary voc;
+        std::map<unsigned, double> bow; std::map<unsigned, std::vector<unsigned>> fv;
+        if (!voc.empty() || voc.loadFromTextFile("/nonexistent/voc.txt")) return 4;
+        voc.transform(nullptr, a, 1, bow, fv, 4);            // empty vocabulary: empty vectors, no device call
+        if (!bow.empty() || !fv.empty()) return 5;
+    }
     std::printf("ADAPTOR_OK\n");
     return 0;
 }
