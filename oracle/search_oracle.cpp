@@ -3,6 +3,8 @@
 // Restates (paths relative to /root/reference), on plain arrays instead of Frame / KeyFrame / MapPoint objects:
 //   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)   src/ORBmatcher.cc:1330-1472
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)     src/ORBmatcher.cc:161-290
+//   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)        src/ORBmatcher.cc:524-657
+//   ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1620-1747 (+ MapPoint::PredictScale, src/MapPoint.cc:414-429)
 //   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:47-131 (+ RadiusByViewingCos :133-139)
 //   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
 //   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
@@ -249,6 +251,137 @@ int orc_search_local_map(const olf_keypoint* curKeys, const uint8_t* curDesc, co
     return nmatches;
 }
 }  // extern "C"
+
+// SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (relocalisation, src/Tracking.cc:1786,1801):
+// kf_* = the key frame's map point matches as SoA (valid, bad, already found, world position, descriptor, mfMaxDistance, mfMinDistance);
+// matches[i2] = key frame feature index whose map point was assigned to current feature i2.
+extern "C" int orc_search_by_projection_kf(const olf_keypoint* curKeys, const uint8_t* curDesc, int curN, uint8_t* cur_mp_valid, const float* curTcw,
+                                           const float* cam9, const float* scaleFactors, int nLevels, float logScaleFactor,
+                                           const olf_keypoint* kfKeys, int kfN, const uint8_t* kf_valid, const uint8_t* kf_bad,
+                                           const uint8_t* kf_found, const float* kf_world, const uint8_t* kf_desc, const float* kf_maxd,
+                                           const float* kf_mind, float th, int ORBdist, int checkOri, int* matches)
+{
+    using namespace orc;
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = curKeys; G.N = curN; G.c = c; G.build();
+    for (int i = 0; i < curN; ++i) matches[i] = -1;
+    int nmatches = 0;
+    float Ow[3];
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)curTcw[4 * k + r] * curTcw[4 * k + 3];
+        Ow[r] = (float)(-acc);
+    }
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < kfN; i++) {
+        if (!kf_valid[i]) continue;
+        if (kf_bad[i] || kf_found[i]) continue;
+        const float* x3Dw = kf_world + 3 * i;
+        float x3Dc[3];
+        mat3_mul_add(curTcw, x3Dw, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        const float u = c.fx * xc * invzc + c.cx, v = c.fy * yc * invzc + c.cy;
+        if (u < c.minX || u > c.maxX) continue;
+        if (v < c.minY || v > c.maxY) continue;
+        double nrm = 0;
+        for (int k = 0; k < 3; ++k) { const float po = x3Dw[k] - Ow[k]; nrm += (double)po * (double)po; }     // cv::norm(CV_32F, NORM_L2)
+        const float dist3D = (float)std::sqrt(nrm);
+        const float maxDistance = 1.2f * kf_maxd[i], minDistance = 0.8f * kf_mind[i];
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const float ratio = kf_maxd[i] / dist3D;
+        int nPredictedLevel = (int)std::ceil(std::log(ratio) / logScaleFactor);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nLevels) nPredictedLevel = nLevels - 1;
+        const float radius = th * scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices2 = G.area(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (cur_mp_valid[i2]) continue;
+            const int dist = hamming256(kf_desc + 32 * (size_t)i, curDesc + 32 * i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+        }
+        if (bestDist <= ORBdist) {
+            cur_mp_valid[bestIdx2] = 1;
+            matches[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                float rot = kfKeys[i].angle - curKeys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j : rotHist[i]) { cur_mp_valid[j] = 0; matches[j] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+// SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (loop closing): matches12[idx1] = idx2 (the feature of KF2 whose map point is taken)
+extern "C" int orc_search_by_bow_kf(const olf_keypoint* keys1, const uint8_t* desc1, int n1, const uint8_t* mp1_valid, const uint8_t* mp1_bad,
+                                    const int* nodes1, const int* offs1, const int* idx1v, int nNodes1, const olf_keypoint* keys2,
+                                    const uint8_t* desc2, int n2, const uint8_t* mp2_valid, const uint8_t* mp2_bad, const int* nodes2,
+                                    const int* offs2, const int* idx2v, int nNodes2, float nnratio, int checkOri, int* matches12)
+{
+    using namespace orc;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<bool> vbMatched2(n2, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < nNodes1 && b < nNodes2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int p = offs1[a]; p < offs1[a + 1]; ++p) {
+                const int idx1 = idx1v[p];
+                if (!mp1_valid[idx1]) continue;
+                if (mp1_bad[idx1]) continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int q = offs2[b]; q < offs2[b + 1]; ++q) {
+                    const int idx2 = idx2v[q];
+                    if (vbMatched2[idx2] || !mp2_valid[idx2]) continue;
+                    if (mp2_bad[idx2]) continue;
+                    const int dist = hamming256(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (checkOri) {
+                            float rot = keys1[idx1].angle - keys2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) { while (a < nNodes1 && nodes1[a] < nodes2[b]) ++a; }      // lower_bound on the ordered map
+        else { while (b < nNodes2 && nodes2[b] < nodes1[a]) ++b; }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
 
 // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:254-318) == MapLine::ComputeDistinctiveDescriptors (src/MapLine.cc:257-322)
 // on a batch of landmarks given as CSR lists of observing descriptors.

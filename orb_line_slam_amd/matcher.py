@@ -176,6 +176,16 @@ class FrameView:
         return out
 
 
+class KeyFrameView(FrameView):
+    """A FrameView that stands for a KeyFrame* argument (the reference overloads SearchByBoW / SearchByProjection on Frame& / KeyFrame*).
+    mp_maxd / mp_mind : (N,) float32, the map points' mfMaxDistance / mfMinDistance (MapPoint::UpdateNormalAndDepth)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.mp_maxd = np.zeros(self.N, np.float32)
+        self.mp_mind = np.zeros(self.N, np.float32)
+
+
 def _candidate_distances(descQ, lists, descT, context=None):
     """GPU Hamming distances for CSR candidate lists; returns a list of uint16 arrays (one per query)."""
     offs = np.zeros(len(lists) + 1, np.int32)
@@ -413,12 +423,165 @@ def _search_local_map(self, F, vpMapPoints, th=1.0):
     return nmatches, matches
 
 
-def _search_by_projection_dispatch(self, a, b, th=1.0, bMono=False):
-    """The reference overloads SearchByProjection on the second argument: a Frame (:1330) or a vector<MapPoint*> (:47)."""
+_libm = None
+
+
+def _logf(x):
+    """glibc logf (MapPoint::PredictScale calls std::log on a float, src/MapPoint.cc:422): numpy's float32 log is not guaranteed to be it"""
+    global _libm
+    if _libm is None:
+        import ctypes
+        _libm = ctypes.CDLL("libm.so.6")
+        _libm.logf.restype = ctypes.c_float
+        _libm.logf.argtypes = [ctypes.c_float]
+    return np.float32(_libm.logf(float(np.float32(x))))
+
+
+def _search_by_projection_kf(self, CurrentFrame, pKF, sAlreadyFound, th, ORBdist):
+    """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+    const int ORBdist), src/ORBmatcher.cc:1620-1747 (relocalisation).  pKF: KeyFrameView with mp_valid / mp_bad / mp_world / mp_desc and
+    mp_maxd / mp_mind (mfMaxDistance / mfMinDistance); sAlreadyFound: bool mask over pKF's features.  Returns (nmatches, matches) with
+    matches[i2] = pKF feature index; CurrentFrame.mp_valid is updated like mvpMapPoints."""
+    f32 = np.float32
+    HL = self.HISTO_LENGTH
+    rotHist = [[] for _ in range(HL)]
+    factor = f32(1.0) / f32(HL)
+    Rcw, tcw = CurrentFrame.mTcw[:3, :3], CurrentFrame.mTcw[:3, 3]
+    Ow = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
+    nLevels = len(CurrentFrame.mvScaleFactors)
+    logScale = _logf(CurrentFrame.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)       # mfLogScaleFactor = log(mfScaleFactor), src/Frame.cc:157
+    found = np.zeros(pKF.N, bool) if sAlreadyFound is None else np.asarray(sAlreadyFound, bool)
+    queries, lists = [], []
+    for i in range(pKF.N):
+        if not pKF.mp_valid[i] or pKF.mp_bad[i] or found[i]:
+            continue
+        x3Dw = pKF.mp_world[i]
+        x3Dc = (Rcw.astype(np.float64) @ x3Dw.astype(np.float64) + tcw.astype(np.float64)).astype(f32)
+        xc, yc = x3Dc[0], x3Dc[1]
+        invzc = f32(1.0 / np.float64(x3Dc[2])) if x3Dc[2] != 0 else f32(np.inf)
+        u = f32(f32(f32(CurrentFrame.fx * xc) * invzc) + CurrentFrame.cx)
+        v = f32(f32(f32(CurrentFrame.fy * yc) * invzc) + CurrentFrame.cy)
+        if u < CurrentFrame.mnMinX or u > CurrentFrame.mnMaxX or v < CurrentFrame.mnMinY or v > CurrentFrame.mnMaxY:
+            continue
+        PO = (x3Dw - Ow).astype(f32)
+        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
+        maxDistance, minDistance = f32(f32(1.2) * pKF.mp_maxd[i]), f32(f32(0.8) * pKF.mp_mind[i])
+        if dist3D < minDistance or dist3D > maxDistance:
+            continue
+        ratio = f32(pKF.mp_maxd[i] / dist3D)
+        nPredictedLevel = int(np.ceil(f32(_logf(ratio) / logScale)))
+        nPredictedLevel = 0 if nPredictedLevel < 0 else min(nPredictedLevel, nLevels - 1)
+        radius = f32(f32(th) * CurrentFrame.mvScaleFactors[nPredictedLevel])
+        idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1)
+        if not idx:
+            continue
+        queries.append(i); lists.append(idx)
+    dists = _candidate_distances(pKF.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, CurrentFrame.mDescriptors, self._context)
+    matches = np.full(CurrentFrame.N, -1, np.int32)
+    nmatches = 0
+    for qi, i in enumerate(queries):
+        bestDist, bestIdx2 = 256, -1
+        for i2, dist in zip(lists[qi], dists[qi]):
+            if CurrentFrame.mp_valid[i2]:
+                continue
+            if int(dist) < bestDist:
+                bestDist, bestIdx2 = int(dist), i2
+        if bestDist <= ORBdist:
+            CurrentFrame.mp_valid[bestIdx2] = True
+            matches[bestIdx2] = i
+            nmatches += 1
+            if self.mbCheckOrientation:
+                rot = f32(pKF.mvKeysUn["angle"][i] - CurrentFrame.mvKeysUn["angle"][bestIdx2])
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = _c_round(f32(rot * factor))
+                if b == HL:
+                    b = 0
+                rotHist[b].append(bestIdx2)
+    if self.mbCheckOrientation:
+        ind = ComputeThreeMaxima(rotHist)
+        for b in range(HL):
+            if b not in ind:
+                for j in rotHist[b]:
+                    CurrentFrame.mp_valid[j] = False
+                    matches[j] = -1
+                    nmatches -= 1
+    return nmatches, matches
+
+
+def _search_by_projection_dispatch(self, a, b, *args):
+    """The reference overloads SearchByProjection on the second argument: a Frame (:1330), a vector<MapPoint*> (:47) or a KeyFrame* (:1620)."""
+    if isinstance(b, KeyFrameView):
+        return _search_by_projection_kf(self, a, b, *args)
+    return _search_by_projection_dispatch2(self, a, b, *args)
+
+
+def _search_by_projection_dispatch2(self, a, b, th=1.0, bMono=False):
     if isinstance(b, MapPointView):
         return _search_local_map(self, a, b, th)
     return _search_by_projection(self, a, b, th, bMono)
 
 
 ORBmatcher.SearchByProjection = _search_by_projection_dispatch
-ORBmatcher.SearchByBoW = _search_by_bow
+def _search_by_bow_kf(self, pKF1, pKF2):
+    """int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:524-657 (loop closing).
+    Returns (nmatches, vpMatches12) with vpMatches12[idx1] = feature index idx2 of pKF2 whose map point is taken (-1 = NULL)."""
+    f32 = np.float32
+    HL = self.HISTO_LENGTH
+    rotHist = [[] for _ in range(HL)]
+    factor = f32(1.0) / f32(HL)
+    common = sorted(set(pKF1.mFeatVec) & set(pKF2.mFeatVec))
+    queries, lists = [], []
+    for node in common:
+        for idx1 in pKF1.mFeatVec[node]:
+            if not pKF1.mp_valid[idx1] or pKF1.mp_bad[idx1]:
+                continue
+            queries.append(idx1); lists.append(list(pKF2.mFeatVec[node]))
+    dists = _candidate_distances(pKF1.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF2.mDescriptors, self._context)
+    matches12 = np.full(pKF1.N, -1, np.int32)
+    vbMatched2 = np.zeros(pKF2.N, bool)
+    nmatches = 0
+    for qi, idx1 in enumerate(queries):
+        bestDist1, bestIdx2, bestDist2 = 256, -1, 256
+        for idx2, dist in zip(lists[qi], dists[qi]):
+            if vbMatched2[idx2] or not pKF2.mp_valid[idx2] or pKF2.mp_bad[idx2]:
+                continue
+            dist = int(dist)
+            if dist < bestDist1:
+                bestDist2, bestDist1, bestIdx2 = bestDist1, dist, idx2
+            elif dist < bestDist2:
+                bestDist2 = dist
+        if bestDist1 < self.TH_LOW and f32(bestDist1) < f32(self.mfNNratio) * f32(bestDist2):
+            matches12[idx1] = bestIdx2
+            vbMatched2[bestIdx2] = True
+            if self.mbCheckOrientation:
+                rot = f32(pKF1.mvKeysUn["angle"][idx1] - pKF2.mvKeysUn["angle"][bestIdx2])
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = _c_round(f32(rot * factor))
+                if b == HL:
+                    b = 0
+                rotHist[b].append(idx1)
+            nmatches += 1
+    if self.mbCheckOrientation:
+        ind = ComputeThreeMaxima(rotHist)
+        for b in range(HL):
+            if b in ind:
+                continue
+            for j in rotHist[b]:
+                matches12[j] = -1
+                nmatches -= 1
+    return nmatches, matches12
+
+
+def _search_by_bow_dispatch(self, pKF, other):
+    return _search_by_bow_kf(self, pKF, other) if isinstance(other, KeyFrameView) else _search_by_bow(self, pKF, other)
+
+
+def match_maplines(maplines_desc, frame_desc_l, nnr, context=None):
+    """int match(const std::vector<MapLine*>&, Frame&, float nnr, std::vector<int>& matches_12), src/LineMatcher.cpp:64-73: the local map
+    lines' descriptors against mDescriptors_Line with matchNNR (the code after the early return there is dead)."""
+    return matchNNR(maplines_desc, frame_desc_l, nnr, context)
+
+
+ORBmatcher.SearchByBoW = _search_by_bow_dispatch

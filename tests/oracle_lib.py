@@ -356,3 +356,34 @@ def distinctive_descriptors(observations):
     best = np.zeros(len(obs), np.int32)
     _L.orc_distinctive_descriptors(_p(desc), _p(offs), len(obs), _p(best))
     return best
+
+
+def search_by_bow_kf(kf1, kf2, nnratio, checkOri=True):
+    n1, o1, i1 = _featvec_csr(kf1.mFeatVec)
+    n2, o2, i2 = _featvec_csr(kf2.mFeatVec)
+    m = np.full(kf1.N, -1, np.int32)
+    a = np.ascontiguousarray
+    u8 = lambda x: a(x.astype(np.uint8))
+    n = _L.orc_search_by_bow_kf(_p(a(kf1.mvKeysUn)), _p(a(kf1.mDescriptors)), kf1.N, _p(u8(kf1.mp_valid)), _p(u8(kf1.mp_bad)), _p(n1), _p(o1), _p(i1),
+                                len(n1), _p(a(kf2.mvKeysUn)), _p(a(kf2.mDescriptors)), kf2.N, _p(u8(kf2.mp_valid)), _p(u8(kf2.mp_bad)), _p(n2), _p(o2),
+                                _p(i2), len(n2), C.c_float(nnratio), int(checkOri), _p(m))
+    return n, m
+
+
+def search_by_projection_kf(cur, kf, found, th, ORBdist, checkOri=True):
+    """cur: FrameView (state copied), kf: KeyFrameView -> (nmatches, matches)"""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    cv = cur.mp_valid.astype(np.uint8).copy()
+    cam = np.array([cur.fx, cur.fy, cur.cx, cur.cy, cur.mbf, cur.mnMinX, cur.mnMaxX, cur.mnMinY, cur.mnMaxY], np.float32)
+    m = np.full(cur.N, -1, np.int32)
+    a = np.ascontiguousarray
+    u8 = lambda x: a(np.asarray(x).astype(np.uint8))
+    sf = a(cur.mvScaleFactors)
+    logsf = libm.logf(float(sf[1]))
+    arrs = [a(cur.mvKeysUn), a(cur.mDescriptors), a(cur.mTcw), a(kf.mvKeysUn), u8(kf.mp_valid), u8(kf.mp_bad), u8(found), a(kf.mp_world),
+            a(kf.mp_desc), a(kf.mp_maxd), a(kf.mp_mind)]
+    n = _L.orc_search_by_projection_kf(_p(arrs[0]), _p(arrs[1]), cur.N, _p(cv), _p(arrs[2]), _p(cam), _p(sf), len(sf), C.c_float(logsf),
+                                       _p(arrs[3]), kf.N, _p(arrs[4]), _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]),
+                                       _p(arrs[10]), C.c_float(th), int(ORBdist), int(checkOri), _p(m))
+    return n, m

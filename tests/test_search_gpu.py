@@ -97,3 +97,53 @@ def test_search_local_map(oracle, th, ratio):
     n_g, m_g = ola.ORBmatcher(ratio, True).SearchByProjection(cur, mp, th)
     assert n_g == n_o and np.array_equal(m_g, m_o)
     assert n_g > 200
+
+
+def _as_kf(view):
+    kf = ola.KeyFrameView(view.mvKeysUn, view.mDescriptors, view.mvuRight, view.mvScaleFactors,
+                          bounds=(float(view.mnMinX), float(view.mnMaxX), float(view.mnMinY), float(view.mnMaxY)))
+    for a in ("mp_valid", "mp_world", "mp_desc", "mp_obs", "mp_bad", "mvbOutlier", "mFeatVec"):
+        setattr(kf, a, copy.deepcopy(getattr(view, a)))
+    return kf
+
+
+def test_search_by_bow_kf_kf(oracle):
+    """SearchByBoW(KeyFrame, KeyFrame) (loop closing): both sides carry map points; strict TH_LOW, vbMatched2"""
+    last, cur = _frames(oracle, seed=59)
+    def fv(v):
+        d = {}
+        for i in range(v.N):
+            d.setdefault(int(v.mvKeysUn["x"][i] // 90) * 7 + int(v.mvKeysUn["y"][i] // 90), []).append(i)
+        return d
+    kf1, kf2 = _as_kf(last), _as_kf(cur)
+    kf1.mFeatVec, kf2.mFeatVec = fv(kf1), fv(kf2)
+    rng = np.random.default_rng(2)
+    kf2.mp_valid = rng.random(kf2.N) > 0.2; kf2.mp_bad = rng.random(kf2.N) < 0.05; kf1.mp_bad[::31] = True
+    for ratio in (0.75, 0.9):
+        n_o, m_o = oracle.search_by_bow_kf(kf1, kf2, ratio)
+        n_g, m_g = ola.ORBmatcher(ratio, True).SearchByBoW(kf1, kf2)
+        assert n_g == n_o and np.array_equal(m_g, m_o)
+    assert n_g > 40
+    n2o, m2o = oracle.search_by_bow_kf(kf1, kf2, 0.9, checkOri=False)
+    n2g, m2g = ola.ORBmatcher(0.9, False).SearchByBoW(kf1, kf2)
+    assert n2g == n2o and np.array_equal(m2g, m2o)
+
+
+@pytest.mark.parametrize("th,ORBdist", [(10, 100), (3, 64)])
+def test_search_by_projection_keyframe(oracle, th, ORBdist):
+    """SearchByProjection(Frame, KeyFrame, sAlreadyFound, th, ORBdist) (relocalisation): predicted scale level from the viewing distance"""
+    last, cur = _frames(oracle, seed=61)
+    kf = _as_kf(last)
+    rng = np.random.default_rng(7)
+    d = np.linalg.norm(kf.mp_world, axis=1).astype(np.float32)
+    lvl = kf.mvKeysUn["octave"].astype(np.float32)
+    kf.mp_maxd = (d * np.float32(1.2) ** lvl * rng.uniform(0.9, 1.1, kf.N)).astype(np.float32)        # ~ dist * levelScaleFactor
+    kf.mp_mind = (kf.mp_maxd / np.float32(1.2) ** 7).astype(np.float32)
+    found = rng.random(kf.N) < 0.1
+    cur.mTcw = np.eye(4, dtype=np.float32); cur.mTcw[0, 3] = 0.015; cur.mTcw[2, 3] = -0.05
+    cur.mp_valid[::9] = True
+    cur_o = copy.deepcopy(cur)
+    n_o, m_o = oracle.search_by_projection_kf(cur_o, kf, found, th, ORBdist)
+    n_g, m_g = ola.ORBmatcher(0.9, True).SearchByProjection(cur, kf, found, th, ORBdist)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
+    assert n_g > 100
