@@ -204,3 +204,33 @@ def test_keyframe_record_bytes(oracle):
     assert np.array_equal(rec["mvuRight"], ur) and np.array_equal(rec["mvDepth"], dp) and np.array_equal(rec["mDescriptors"], desc)
     empty = maprecord.pack_keyframe(0, 0, 0.0, [0, 0, 0], [0, 0, 0, 1], np.zeros(0, _lib.KEYPOINT_DTYPE), [], [], np.zeros((0, 32), np.uint8))
     assert len(empty) == 60 and maprecord.unpack_keyframe(empty)[1] == 60
+
+
+def test_default_params_match_reference_config():
+    """olf_default_params against the defaults of the reference's Config::Config() (src/Config.cpp:27-110), read from the checkout when it
+    is present (build container only): every stereo-line / LSD parameter the path uses, except lsd_nfeatures (BASELINE's KITTI config)."""
+    import re
+    from orb_line_slam_amd import _lib
+    path = "/root/reference/src/Config.cpp"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout absent")
+    text = open(path, encoding="utf-8", errors="replace").read()
+    ref = {}
+    for name, val in re.findall(r"^\s*(\w+)\s*=\s*([-+0-9.eE]+|true|false)\s*;", text, re.M):
+        ref.setdefault(name, {"true": 1.0, "false": 0.0}.get(val, None) if val in ("true", "false") else float(val))
+    p = _lib.default_params()
+    got = {"min_disp": p.stereo.min_disp, "line_sim_th": p.stereo.line_sim_th, "stereo_overlap_th": p.stereo.stereo_overlap_th,
+           "line_horiz_th": p.stereo.line_horiz_th, "min_ratio_12_l": p.stereo.min_ratio_12_l, "ls_min_disp_ratio": p.stereo.ls_min_disp_ratio,
+           "best_lr_matches": p.stereo.best_lr_matches, "matching_s_ws": p.stereo.matching_s_ws, "min_line_length": p.line.min_line_length,
+           "lsd_refine": p.line.lsd_refine, "lsd_scale": p.line.lsd_scale, "lsd_sigma_scale": p.line.lsd_sigma_scale, "lsd_quant": p.line.lsd_quant,
+           "lsd_ang_th": p.line.lsd_ang_th, "lsd_log_eps": p.line.lsd_log_eps, "lsd_density_th": p.line.lsd_density_th, "lsd_n_bins": p.line.lsd_n_bins}
+    for k, v in got.items():
+        assert k in ref, k
+        assert float(v) == ref[k], (k, v, ref[k])
+    # the KITTI settings file of the PL example (BASELINE config C3): ORB extractor, camera and the LSD feature count
+    y = dict(re.findall(r"^([\w.]+)\s*:\s*([-+0-9.eE]+)\s*(?:#.*)?$", open("/root/reference/Examples/PL/PL_KITTI00-02.yaml", errors="replace").read(), re.M))
+    want = {"ORBextractor.nFeatures": p.orb.nfeatures, "ORBextractor.scaleFactor": p.orb.scale_factor, "ORBextractor.nLevels": p.orb.nlevels,
+            "ORBextractor.iniThFAST": p.orb.ini_th_fast, "ORBextractor.minThFAST": p.orb.min_th_fast, "Camera.fx": p.stereo.fx, "Camera.bf": p.stereo.bf,
+            "lsd_nfeatures": p.line.lsd_nfeatures}
+    for k, v in want.items():
+        assert np.float32(y[k]) == np.float32(v), (k, v, y[k])
