@@ -5,6 +5,8 @@
 //   ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)     src/ORBmatcher.cc:161-290
 //   ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)        src/ORBmatcher.cc:524-657
 //   ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1620-1747 (+ MapPoint::PredictScale, src/MapPoint.cc:414-429)
+//   ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo)   src/ORBmatcher.cc:659-825 (+ CheckDistEpipolarLine :142-161)
+//   ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th), the search part             src/ORBmatcher.cc:827-975
 //   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:47-131 (+ RadiusByViewingCos :133-139)
 //   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
 //   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
@@ -324,6 +326,146 @@ extern "C" int orc_search_by_projection_kf(const olf_keypoint* curKeys, const ui
                 for (int j : rotHist[i]) { cur_mp_valid[j] = 0; matches[j] = -1; nmatches--; }
     }
     return nmatches;
+}
+
+// SearchForTriangulation (LocalMapping::CreateNewMapPoints): features WITHOUT a map point, same vocabulary node, epipolar constraint.
+// (vbMatched2 is never set in the reference, so several idx1 may take the same idx2 -- reproduced.)  matches12[idx1] = idx2 or -1.
+extern "C" int orc_search_for_triangulation(const olf_keypoint* keys1, const uint8_t* desc1, int n1, const uint8_t* mp1_valid, const float* uRight1,
+                                            const int* nodes1, const int* offs1, const int* idx1v, int nNodes1, const float* Cw3,
+                                            const olf_keypoint* keys2, const uint8_t* desc2, int n2, const uint8_t* mp2_valid, const float* uRight2,
+                                            const int* nodes2, const int* offs2, const int* idx2v, int nNodes2, const float* T2w, const float* cam4,
+                                            const float* scaleFactors2, const float* levelSigma2, const float* F12, int bOnlyStereo, int checkOri,
+                                            int* matches12)
+{
+    using namespace orc;
+    float C2[3];
+    mat3_mul_add(T2w, Cw3, C2);
+    const float fx = cam4[0], fy = cam4[1], cx = cam4[2], cy = cam4[3];
+    const float invz = 1.0f / C2[2];
+    const float ex = fx * C2[0] * invz + cx, ey = fy * C2[1] * invz + cy;
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(n2, false);
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto epi_ok = [&](const olf_keypoint& kp1, const olf_keypoint& kp2) -> bool {      // CheckDistEpipolarLine, F12 row-major 3x3
+        const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+        const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+        const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+        const float num = a * kp2.x + b * kp2.y + c;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return dsqr < 3.84 * levelSigma2[kp2.octave];
+    };
+    int a = 0, b = 0;
+    while (a < nNodes1 && b < nNodes2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int p = offs1[a]; p < offs1[a + 1]; ++p) {
+                const int idx1 = idx1v[p];
+                if (mp1_valid[idx1]) continue;
+                const bool bStereo1 = uRight1[idx1] >= 0;
+                if (bOnlyStereo && !bStereo1) continue;
+                const olf_keypoint& kp1 = keys1[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int q = offs2[b]; q < offs2[b + 1]; ++q) {
+                    const int idx2 = idx2v[q];
+                    if (vbMatched2[idx2] || mp2_valid[idx2]) continue;
+                    const bool bStereo2 = uRight2[idx2] >= 0;
+                    if (bOnlyStereo && !bStereo2) continue;
+                    const int dist = hamming256(desc1 + 32 * (size_t)idx1, desc2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const olf_keypoint& kp2 = keys2[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2.x, distey = ey - kp2.y;
+                        if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+                    }
+                    if (epi_ok(kp1, kp2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    const olf_keypoint& kp2 = keys2[bestIdx2];
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            ++a; ++b;
+        } else if (nodes1[a] < nodes2[b]) { while (a < nNodes1 && nodes1[a] < nodes2[b]) ++a; }
+        else { while (b < nNodes2 && nodes2[b] < nodes1[a]) ++b; }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th), the search part: per map point the most similar key point inside the
+// projection window (bestIdx, bestDist), or -1 when a geometric gate rejects the point / no candidate passes.  The map mutation that
+// follows (Replace / AddObservation, :950-972) only depends on (bestIdx, bestDist <= TH_LOW) and on map state, and never feeds back
+// into another point's search, so the reference's loop body splits exactly at that line.
+extern "C" void orc_fuse_search(const olf_keypoint* keys, const uint8_t* desc, const float* uRight, int N, const float* Tcw, const float* Ow3,
+                                const float* cam9, const float* scaleFactors, const float* invLevelSigma2, int nLevels, float logScaleFactor,
+                                int nMP, const uint8_t* mp_skip, const float* mp_world, const float* mp_normal, const float* mp_maxd,
+                                const float* mp_mind, const uint8_t* mp_desc, float th, int* bestIdxOut, int* bestDistOut)
+{
+    using namespace orc;
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = keys; G.N = N; G.c = c; G.build();
+    for (int i = 0; i < nMP; i++) {
+        bestIdxOut[i] = -1; bestDistOut[i] = 256;
+        if (mp_skip[i]) continue;                    // !pMP, isBad(), IsInKeyFrame(pKF)
+        const float* p3Dw = mp_world + 3 * i;
+        float p3Dc[3];
+        mat3_mul_add(Tcw, p3Dw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+        if (!(u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY)) continue;
+        const float ur = u - c.mbf * invz;
+        const float maxDistance = 1.2f * mp_maxd[i], minDistance = 0.8f * mp_mind[i];
+        float PO[3]; double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { PO[k] = p3Dw[k] - Ow3[k]; nrm += (double)PO[k] * (double)PO[k]; dot += (double)PO[k] * (double)mp_normal[3 * i + k]; }
+        const float dist3D = (float)std::sqrt(nrm);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        if (dot < 0.5 * dist3D) continue;
+        const float ratio = mp_maxd[i] / dist3D;
+        int nPredictedLevel = (int)std::ceil(std::log(ratio) / logScaleFactor);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= nLevels) nPredictedLevel = nLevels - 1;
+        const float radius = th * scaleFactors[nPredictedLevel];
+        const std::vector<size_t> vIndices = G.area(u, v, radius);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            const olf_keypoint& kp = keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (uRight[idx] >= 0) {
+                const float ex = u - kp.x, ey = v - kp.y, er = ur - uRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = hamming256(mp_desc + 32 * (size_t)i, desc + 32 * idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        bestIdxOut[i] = bestIdx; bestDistOut[i] = bestDist;
+    }
 }
 
 // SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (loop closing): matches12[idx1] = idx2 (the feature of KF2 whose map point is taken)

@@ -9,11 +9,11 @@ compute object without the built HIP library or without a GPU raises.
 from ._lib import (KEYPOINT_DTYPE, KEYLINE_DTYPE, OlfError, OlfParams, default_params, device_count,
                    lib, last_error)
 from .extractor import ORBextractor, Lineextractor
-from .matcher import ORBmatcher, FrameView, KeyFrameView, MapPointView
+from .matcher import ORBmatcher, FrameView, KeyFrameView, MapPointView, MapPointGeom
 from .vocabulary import ORBVocabulary, LineVocabulary
 from . import matcher as LineMatcher
 from .frame import StereoFrontEnd, StereoFrames
 from . import synth
 
-__all__ = ["ORBextractor", "Lineextractor", "ORBmatcher", "FrameView", "KeyFrameView", "MapPointView", "ORBVocabulary", "LineVocabulary", "LineMatcher", "StereoFrontEnd", "StereoFrames", "KEYPOINT_DTYPE", "KEYLINE_DTYPE", "OlfError", "OlfParams", "default_params",
+__all__ = ["ORBextractor", "Lineextractor", "ORBmatcher", "FrameView", "KeyFrameView", "MapPointView", "MapPointGeom", "ORBVocabulary", "LineVocabulary", "LineMatcher", "StereoFrontEnd", "StereoFrames", "KEYPOINT_DTYPE", "KEYLINE_DTYPE", "OlfError", "OlfParams", "default_params",
            "device_count", "lib", "last_error", "synth"]

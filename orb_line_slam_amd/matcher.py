@@ -578,6 +578,180 @@ def _search_by_bow_dispatch(self, pKF, other):
     return _search_by_bow_kf(self, pKF, other) if isinstance(other, KeyFrameView) else _search_by_bow(self, pKF, other)
 
 
+def _epipolar_ok(kp1, kp2, F12, levelSigma2):
+    """ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:142-161 (float arithmetic, the threshold product in double)"""
+    f32 = np.float32
+    x1, y1, x2, y2 = f32(kp1["x"]), f32(kp1["y"]), f32(kp2["x"]), f32(kp2["y"])
+    a = f32(f32(f32(x1 * F12[0, 0]) + f32(y1 * F12[1, 0])) + F12[2, 0])
+    b = f32(f32(f32(x1 * F12[0, 1]) + f32(y1 * F12[1, 1])) + F12[2, 1])
+    c = f32(f32(f32(x1 * F12[0, 2]) + f32(y1 * F12[1, 2])) + F12[2, 2])
+    num = f32(f32(f32(a * x2) + f32(b * y2)) + c)
+    den = f32(f32(a * a) + f32(b * b))
+    if den == 0:
+        return False
+    dsqr = f32(f32(num * num) / den)
+    return float(dsqr) < 3.84 * float(levelSigma2[int(kp2["octave"])])
+
+
+def _search_for_triangulation(self, pKF1, pKF2, F12, bOnlyStereo, Cw=None):
+    """int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+    const bool bOnlyStereo), src/ORBmatcher.cc:659-825 (LocalMapping::CreateNewMapPoints).  Cw = pKF1->GetCameraCenter() (default: from
+    pKF1.mTcw); pKF2.mTcw gives R2w / t2w.  Returns (nmatches, vMatchedPairs) with vMatchedPairs = [(idx1, idx2), ...] in idx1 order."""
+    f32 = np.float32
+    HL = self.HISTO_LENGTH
+    F12 = np.ascontiguousarray(F12, f32).reshape(3, 3)
+    if Cw is None:
+        R1, t1 = pKF1.mTcw[:3, :3], pKF1.mTcw[:3, 3]
+        Cw = (-(R1.T.astype(np.float64) @ t1.astype(np.float64))).astype(f32)
+    R2w, t2w = pKF2.mTcw[:3, :3], pKF2.mTcw[:3, 3]
+    C2 = (R2w.astype(np.float64) @ np.asarray(Cw, f32).astype(np.float64) + t2w.astype(np.float64)).astype(f32)
+    invz = f32(f32(1.0) / C2[2])
+    ex = f32(f32(f32(pKF2.fx * C2[0]) * invz) + pKF2.cx)
+    ey = f32(f32(f32(pKF2.fy * C2[1]) * invz) + pKF2.cy)
+    sigma2 = (pKF2.mvScaleFactors * pKF2.mvScaleFactors).astype(f32)          # mvLevelSigma2, src/ORBextractor.cc:430-436
+    rotHist = [[] for _ in range(HL)]
+    factor = f32(1.0) / f32(HL)
+    common = sorted(set(pKF1.mFeatVec) & set(pKF2.mFeatVec))
+    queries, lists = [], []
+    for node in common:
+        for idx1 in pKF1.mFeatVec[node]:
+            if pKF1.mp_valid[idx1]:
+                continue
+            if bOnlyStereo and not pKF1.mvuRight[idx1] >= 0:
+                continue
+            queries.append(idx1); lists.append(list(pKF2.mFeatVec[node]))
+    dists = _candidate_distances(pKF1.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF2.mDescriptors, self._context)
+    vMatches12 = np.full(pKF1.N, -1, np.int32)
+    nmatches = 0
+    for qi, idx1 in enumerate(queries):
+        bStereo1 = bool(pKF1.mvuRight[idx1] >= 0)
+        kp1 = pKF1.mvKeysUn[idx1]
+        bestDist, bestIdx2 = self.TH_LOW, -1
+        for idx2, dist in zip(lists[qi], dists[qi]):
+            if pKF2.mp_valid[idx2]:                      # (vbMatched2 is never set in the reference)
+                continue
+            bStereo2 = bool(pKF2.mvuRight[idx2] >= 0)
+            if bOnlyStereo and not bStereo2:
+                continue
+            dist = int(dist)
+            if dist > self.TH_LOW or dist > bestDist:
+                continue
+            kp2 = pKF2.mvKeysUn[idx2]
+            if not bStereo1 and not bStereo2:
+                dx, dy = f32(ex - kp2["x"]), f32(ey - kp2["y"])
+                if f32(f32(dx * dx) + f32(dy * dy)) < f32(f32(100) * pKF2.mvScaleFactors[int(kp2["octave"])]):
+                    continue
+            if _epipolar_ok(kp1, kp2, F12, sigma2):
+                bestIdx2, bestDist = idx2, dist
+        if bestIdx2 >= 0:
+            vMatches12[idx1] = bestIdx2
+            nmatches += 1
+            if self.mbCheckOrientation:
+                rot = f32(kp1["angle"] - pKF2.mvKeysUn["angle"][bestIdx2])
+                if rot < 0.0:
+                    rot = f32(rot + f32(360.0))
+                b = _c_round(f32(rot * factor))
+                if b == HL:
+                    b = 0
+                rotHist[b].append(idx1)
+    if self.mbCheckOrientation:
+        ind = ComputeThreeMaxima(rotHist)
+        for b in range(HL):
+            if b in ind:
+                continue
+            for j in rotHist[b]:
+                vMatches12[j] = -1
+                nmatches -= 1
+    return nmatches, [(int(i), int(vMatches12[i])) for i in range(pKF1.N) if vMatches12[i] >= 0]
+
+
+class MapPointGeom:
+    """The MapPoint members read by the search part of Fuse (src/ORBmatcher.cc:827-948): skip = !pMP || isBad() || IsInKeyFrame(pKF),
+    world = GetWorldPos(), normal = GetNormal(), maxd / mind = mfMaxDistance / mfMinDistance, descriptor = GetDescriptor()."""
+
+    def __init__(self, world, normal, maxd, mind, descriptor, skip=None):
+        self.descriptor = np.ascontiguousarray(descriptor, np.uint8).reshape(-1, 32)
+        self.n = n = len(self.descriptor)
+        self.world = np.ascontiguousarray(world, np.float32).reshape(n, 3)
+        self.normal = np.ascontiguousarray(normal, np.float32).reshape(n, 3)
+        self.maxd, self.mind = np.ascontiguousarray(maxd, np.float32).reshape(n), np.ascontiguousarray(mind, np.float32).reshape(n)
+        self.skip = np.zeros(n, bool) if skip is None else np.ascontiguousarray(skip, bool).reshape(n)
+
+
+def _fuse_search(self, pKF, vpMapPoints, th=3.0, Ow=None):
+    """The search part of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:827-948:
+    per map point the most similar key point of pKF inside the projection window.  Returns (bestIdx, bestDist) arrays (-1 / 256 where a gate
+    rejects the point).  The reference's loop then fuses when bestDist <= TH_LOW (:950-972: Replace / AddObservation on the map, host
+    code); that mutation never feeds back into another point's search, so the loop body splits exactly there."""
+    f32 = np.float32
+    mp = vpMapPoints
+    Rcw, tcw = pKF.mTcw[:3, :3], pKF.mTcw[:3, 3]
+    if Ow is None:
+        Ow = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
+    Ow = np.asarray(Ow, f32)
+    nLevels = len(pKF.mvScaleFactors)
+    logScale = _logf(pKF.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
+    sigma2 = (pKF.mvScaleFactors * pKF.mvScaleFactors).astype(f32)
+    invSigma2 = (f32(1.0) / sigma2).astype(f32)                                   # mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]
+    queries, lists, meta = [], [], []
+    for i in range(mp.n):
+        if mp.skip[i]:
+            continue
+        p3Dw = mp.world[i]
+        p3Dc = (Rcw.astype(np.float64) @ p3Dw.astype(np.float64) + tcw.astype(np.float64)).astype(f32)
+        if p3Dc[2] < 0.0:
+            continue
+        invz = f32(f32(1) / p3Dc[2]) if p3Dc[2] != 0 else f32(np.inf)
+        x, y = f32(p3Dc[0] * invz), f32(p3Dc[1] * invz)
+        u, v = f32(f32(pKF.fx * x) + pKF.cx), f32(f32(pKF.fy * y) + pKF.cy)
+        if not (u >= pKF.mnMinX and u < pKF.mnMaxX and v >= pKF.mnMinY and v < pKF.mnMaxY):
+            continue
+        ur = f32(u - f32(pKF.mbf * invz))
+        maxDistance, minDistance = f32(f32(1.2) * mp.maxd[i]), f32(f32(0.8) * mp.mind[i])
+        PO = (p3Dw - Ow).astype(f32)
+        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
+        if dist3D < minDistance or dist3D > maxDistance:
+            continue
+        if float(np.sum(PO.astype(np.float64) * mp.normal[i].astype(np.float64))) < 0.5 * float(dist3D):
+            continue
+        ratio = f32(mp.maxd[i] / dist3D)
+        lvl = int(np.ceil(f32(_logf(ratio) / logScale)))
+        lvl = 0 if lvl < 0 else min(lvl, nLevels - 1)
+        radius = f32(f32(th) * pKF.mvScaleFactors[lvl])
+        idx = pKF.GetFeaturesInArea(u, v, radius)
+        if not idx:
+            continue
+        queries.append(i); lists.append(idx); meta.append((u, v, ur, lvl))
+    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF.mDescriptors, self._context)
+    bestIdx, bestDist = np.full(mp.n, -1, np.int32), np.full(mp.n, 256, np.int32)
+    kx, ky, ko = pKF.mvKeysUn["x"], pKF.mvKeysUn["y"], pKF.mvKeysUn["octave"]
+    for qi, i in enumerate(queries):
+        u, v, ur, lvl = meta[qi]
+        bd, bi = 256, -1
+        for idx, dist in zip(lists[qi], dists[qi]):
+            kpLevel = int(ko[idx])
+            if kpLevel < lvl - 1 or kpLevel > lvl:
+                continue
+            ex, ey = f32(u - kx[idx]), f32(v - ky[idx])
+            if pKF.mvuRight[idx] >= 0:
+                er = f32(ur - pKF.mvuRight[idx])
+                e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
+                if float(f32(e2 * invSigma2[kpLevel])) > 7.8:
+                    continue
+            else:
+                e2 = f32(f32(ex * ex) + f32(ey * ey))
+                if float(f32(e2 * invSigma2[kpLevel])) > 5.99:
+                    continue
+            if int(dist) < bd:
+                bd, bi = int(dist), idx
+        bestIdx[i], bestDist[i] = bi, bd
+    return bestIdx, bestDist
+
+
+ORBmatcher.SearchForTriangulation = _search_for_triangulation
+ORBmatcher.FuseSearch = _fuse_search
+
+
 def match_maplines(maplines_desc, frame_desc_l, nnr, context=None):
     """int match(const std::vector<MapLine*>&, Frame&, float nnr, std::vector<int>& matches_12), src/LineMatcher.cpp:64-73: the local map
     lines' descriptors against mDescriptors_Line with matchNNR (the code after the early return there is dead)."""

@@ -387,3 +387,34 @@ def search_by_projection_kf(cur, kf, found, th, ORBdist, checkOri=True):
                                        _p(arrs[3]), kf.N, _p(arrs[4]), _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]),
                                        _p(arrs[10]), C.c_float(th), int(ORBdist), int(checkOri), _p(m))
     return n, m
+
+
+def search_for_triangulation(kf1, kf2, F12, bOnlyStereo, Cw, checkOri=True):
+    n1, o1, i1 = _featvec_csr(kf1.mFeatVec)
+    n2, o2, i2 = _featvec_csr(kf2.mFeatVec)
+    m = np.full(kf1.N, -1, np.int32)
+    a = np.ascontiguousarray
+    u8 = lambda x: a(np.asarray(x).astype(np.uint8))
+    sf = a(kf2.mvScaleFactors); sig = a((sf * sf).astype(np.float32))
+    cam4 = np.array([kf2.fx, kf2.fy, kf2.cx, kf2.cy], np.float32)
+    arrs = [a(kf1.mvKeysUn), a(kf1.mDescriptors), u8(kf1.mp_valid), a(kf1.mvuRight), a(np.asarray(Cw, np.float32)), a(kf2.mvKeysUn), a(kf2.mDescriptors),
+            u8(kf2.mp_valid), a(kf2.mvuRight), a(kf2.mTcw), a(np.asarray(F12, np.float32))]
+    n = _L.orc_search_for_triangulation(_p(arrs[0]), _p(arrs[1]), kf1.N, _p(arrs[2]), _p(arrs[3]), _p(n1), _p(o1), _p(i1), len(n1), _p(arrs[4]),
+                                        _p(arrs[5]), _p(arrs[6]), kf2.N, _p(arrs[7]), _p(arrs[8]), _p(n2), _p(o2), _p(i2), len(n2), _p(arrs[9]),
+                                        _p(cam4), _p(sf), _p(sig), _p(arrs[10]), int(bOnlyStereo), int(checkOri), _p(m))
+    return n, [(int(i), int(m[i])) for i in range(kf1.N) if m[i] >= 0]
+
+
+def fuse_search(kf, mp, th, Ow):
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    a = np.ascontiguousarray
+    cam = np.array([kf.fx, kf.fy, kf.cx, kf.cy, kf.mbf, kf.mnMinX, kf.mnMaxX, kf.mnMinY, kf.mnMaxY], np.float32)
+    sf = a(kf.mvScaleFactors); inv = a((np.float32(1.0) / (sf * sf).astype(np.float32)).astype(np.float32))
+    bi, bd = np.zeros(mp.n, np.int32), np.zeros(mp.n, np.int32)
+    arrs = [a(kf.mvKeysUn), a(kf.mDescriptors), a(kf.mvuRight), a(kf.mTcw), a(np.asarray(Ow, np.float32)), a(mp.skip.astype(np.uint8)), a(mp.world),
+            a(mp.normal), a(mp.maxd), a(mp.mind), a(mp.descriptor)]
+    _L.orc_fuse_search(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), kf.N, _p(arrs[3]), _p(arrs[4]), _p(cam), _p(sf), _p(inv), len(sf),
+                       C.c_float(libm.logf(float(sf[1]))), mp.n, _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]), _p(arrs[10]),
+                       C.c_float(th), _p(bi), _p(bd))
+    return bi, bd

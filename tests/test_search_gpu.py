@@ -147,3 +147,54 @@ def test_search_by_projection_keyframe(oracle, th, ORBdist):
     n_g, m_g = ola.ORBmatcher(0.9, True).SearchByProjection(cur, kf, found, th, ORBdist)
     assert n_g == n_o and np.array_equal(m_g, m_o)
     assert n_g > 100
+
+
+def _fundamental_for_shift(kf, t):
+    """F12 for two identical-orientation cameras, camera 2 displaced by t: nearly horizontal epipolar lines for t ~ (tx, 0, small)"""
+    K = np.array([[kf.fx, 0, kf.cx], [0, kf.fy, kf.cy], [0, 0, 1]], np.float64)
+    tcross = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float64)
+    Kinv = np.linalg.inv(K)
+    return (Kinv.T @ tcross @ Kinv).astype(np.float32)      # used as x1^T F12 x2 by CheckDistEpipolarLine
+
+
+@pytest.mark.parametrize("bOnlyStereo", [False, True])
+def test_search_for_triangulation(oracle, bOnlyStereo):
+    last, cur = _frames(oracle, seed=67)
+    kf1, kf2 = _as_kf(last), _as_kf(cur)
+    def fv(v):
+        d = {}
+        for i in range(v.N):
+            d.setdefault(int(v.mvKeysUn["y"][i] // 40), []).append(i)
+        return d
+    kf1.mFeatVec, kf2.mFeatVec = fv(kf1), fv(kf2)
+    rng = np.random.default_rng(11)
+    kf1.mp_valid = rng.random(kf1.N) < 0.4; kf2.mp_valid = rng.random(kf2.N) < 0.4      # only features WITHOUT a map point are searched
+    kf2.mTcw = np.eye(4, dtype=np.float32); kf2.mTcw[0, 3] = -0.3; kf2.mTcw[2, 3] = 0.004      # finite epipole, far to the side
+    F12 = _fundamental_for_shift(kf1, (0.3, 0.0, -0.004))
+    Cw = np.zeros(3, np.float32)
+    n_o, p_o = oracle.search_for_triangulation(kf1, kf2, F12, bOnlyStereo, Cw)
+    n_g, p_g = ola.ORBmatcher(0.6, True).SearchForTriangulation(kf1, kf2, F12, bOnlyStereo, Cw)
+    assert n_g == n_o and p_g == p_o
+    assert n_g > 30
+    n2o, p2o = oracle.search_for_triangulation(kf1, kf2, F12, bOnlyStereo, Cw, checkOri=False)
+    n2g, p2g = ola.ORBmatcher(0.6, False).SearchForTriangulation(kf1, kf2, F12, bOnlyStereo, Cw)
+    assert n2g == n2o and p2g == p2o
+
+
+@pytest.mark.parametrize("th", [3.0, 6.0])
+def test_fuse_search(oracle, th):
+    last, cur = _frames(oracle, seed=71)
+    kf = _as_kf(cur)
+    sel = np.flatnonzero(last.mp_valid)
+    rng = np.random.default_rng(13)
+    world = last.mp_world[sel].copy(); world[:, 0] += np.float32(3 * 0.54 / 718.856) * world[:, 2]      # frame 1 = frame 0 shifted by 3 px
+    d = np.linalg.norm(world, axis=1).astype(np.float32)
+    lvl = last.mvKeysUn["octave"][sel].astype(np.float32)
+    maxd = (d * np.float32(1.2) ** lvl * rng.uniform(0.95, 1.05, len(sel))).astype(np.float32)
+    normal = (-world / d[:, None] + rng.normal(0, 0.3, world.shape)).astype(np.float32)                # some beyond the 60 degree gate
+    mp = ola.MapPointGeom(world, -normal, maxd, maxd / np.float32(1.2) ** 7, last.mDescriptors[sel], skip=rng.random(len(sel)) < 0.1)
+    Ow = np.zeros(3, np.float32)
+    bi_o, bd_o = oracle.fuse_search(kf, mp, th, Ow)
+    bi_g, bd_g = ola.ORBmatcher(0.6, True).FuseSearch(kf, mp, th, Ow)
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    assert (bi_g >= 0).sum() > 200 and ((bd_g <= 50) & (bi_g >= 0)).sum() > 100
