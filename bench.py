@@ -53,7 +53,7 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
     """The CPU oracle (oracle/liboracle_fast.so, -O3 -march=native -ffp-contract=off) timed on this box's host
     cores in the reference's shape: 4 std::threads per frame (src/Frame.cc:164-171), frames one at a time."""
     import subprocess
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True)
+    subprocess.run(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True)   # -march=native: always rebuilt on the box that runs it
     L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
     from orb_line_slam_amd import synth
     times = []
