@@ -131,11 +131,12 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
     const int img = blockIdx.y;
     int n = 0, ndef = 0;
     const uint8_t* sc = scaled + (size_t)img * g.pitchS * g.Hs;
+    int y = (blockIdx.x * LG_CHUNK + threadIdx.x) / g.Ws, x = (blockIdx.x * LG_CHUNK + threadIdx.x) - y * g.Ws;   // one division per thread
 #pragma unroll 4
-    for (int k = 0; k < LG_CHUNK / 256; ++k) {
+    for (int k = 0; k < LG_CHUNK / 256; ++k, x += 256) {
         const int idx = blockIdx.x * LG_CHUNK + k * 256 + threadIdx.x;
+        while (x >= g.Ws) { x -= g.Ws; ++y; }
         if (idx < g.Ps) {
-            const int y = idx / g.Ws, x = idx - y * g.Ws;
             uint32_t packed = kNotDef;
             if (x < g.Ws - 1 && y < g.Hs - 1) {
                 const uint8_t* r0 = sc + (size_t)y * g.pitchS + x;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // bits with a stable sort: equal bins stay in raster order, which is the reference's list order.
 __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
-                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf)
+                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf, const float* __restrict__ angDeg)
 {
     constexpr int SPAN = LG_CHUNK / 4;
     __shared__ uint32_t s_keys[LG_CHUNK];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ g
                 key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
                 def = true;
                 // level-line angle (degrees) of the defined pixel, kept for k_lsd_iso in the (not yet used) FIFO buffer
-                degbuf[(size_t)img * g.Ps + idx] = __float_as_uint(dev_fastAtan2((float)gx, (float)(-gy)));
+                degbuf[(size_t)img * g.Ps + idx] = __float_as_uint(angDeg[p & 0x3fffffu]);      // fastAtan2(gx, -gy), tabulated per context
             }
         }
         const unsigned long long m = __ballot(def);
@@ -698,7 +699,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     }
     hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
     hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
-                       b.region);
+                       b.region, b.angDeg);
     hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
