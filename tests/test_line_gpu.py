@@ -116,3 +116,24 @@ def test_line_edge_cases(oracle):
     o = oracle.line_extract(noise, p.line)
     _cmp_keylines(k, o["kls"])
     assert np.array_equal(d, o["desc"])
+
+
+@pytest.mark.parametrize("w,h", [(333, 257), (1000, 300), (401, 243), (897, 601)])
+def test_stereo_frames_odd_sizes(oracle, w, h):
+    """sizes that are multiples of nothing: tile edges, pitch padding, level geometry, cell grids with one column, tiny top levels"""
+    p = oracle.full_params(700, 150, 400.0, 40.0)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=2)
+    imgs = synth.stereo_batch(w + h, 2, w, h)
+    f = fe.frames(imgs)
+    for i in range(2):
+        g = f.pair(i)
+        o = oracle.stereo_points(imgs[2 * i], imgs[2 * i + 1], p)
+        assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"])
+        assert np.array_equal(g["mvKeysRight"], o["kpsR"]) and np.array_equal(g["mDescriptorsRight"], o["descR"])
+        assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
+        ol, orr = oracle.line_extract(imgs[2 * i], p.line), oracle.line_extract(imgs[2 * i + 1], p.line)
+        _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+        _cmp_keylines(g["mvKeysRight_Line"], orr["kls"])
+        assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
