@@ -264,12 +264,10 @@ __device__ __forceinline__ double grad_angle(int gx, int gy) { return d_mul((dou
 
 __device__ __forceinline__ bool is_aligned(double a, double theta, double prec)
 {
-    double n_theta = d_sub(theta, a);
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > kM32PI) {
-        n_theta = d_sub(n_theta, kM2PI);
-        if (n_theta < 0) n_theta = -n_theta;
-    }
+    // |x| instead of "if (x < 0) x = -x": identical for every x that reaches a comparison (only the sign of a zero could differ), and the
+    // absolute value folds into the next instruction's source modifier
+    double n_theta = fabs(d_sub(theta, a));
+    if (n_theta > kM32PI) n_theta = fabs(d_sub(n_theta, kM2PI));
     return n_theta <= prec;
 }
 
