@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
                                               size_t dstImgStride, int dstPitch, int W, int H, Taps7 taps)
 {
     __shared__ uint32_t s_in[SF_INH * SF_INW];                 // bytes x0-4 .. x0+131 of rows y0-3 .. y0+34
-    __shared__ uint32_t s_h[SF_INH * (SF_TW / 2)];             // row-pass results, two u16 per word
+    // row-pass results, column major: column x holds its SF_INH u16 values as row pairs (rows 2j, 2j+1 in dword j); the odd column
+    // stride keeps the column pass's LDS reads spread over the banks
+    constexpr int HS = (SF_INH + 1) / 2 + ((((SF_INH + 1) / 2) & 1) ? 0 : 1);
+    __shared__ uint32_t s_h[SF_TW * HS];
     const int img = blockIdx.z, x0 = blockIdx.x * SF_TW, y0 = blockIdx.y * SF_TH;
     const uint8_t* s = src + (size_t)img * srcImgStride;
     for (int i = threadIdx.x; i < SF_INH * SF_INW; i += 256) {
@@ -47,49 +50,58 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
         s_in[i] = v;
     }
     __syncthreads();
-    // ---- row pass: 4 outputs per task from bytes [4q+1, 4q+10] of the tile row (tile byte 4 == image x0)
+    // ---- row pass: 4 outputs per task from bytes [4q+1, 4q+10] of the tile row (tile byte 4 == image x0).  The taps are 8-bit
+    // fractions (OpenCV's ufixedpoint16 row filter), so a 7-tap row sum is two v_dot4_u32_u8 on byte windows cut out with v_alignbyte.
+    const uint32_t tlo = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
+    const uint32_t thi = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 8) | ((uint32_t)taps.t[6] << 16);
+    uint16_t* s_h16 = reinterpret_cast<uint16_t*>(s_h);
     for (int i = threadIdx.x; i < SF_INH * (SF_TW / 4); i += 256) {
         const int r = i / (SF_TW / 4), q = i - r * (SF_TW / 4);
         const uint32_t w0 = s_in[r * SF_INW + q], w1 = s_in[r * SF_INW + q + 1], w2 = s_in[r * SF_INW + q + 2];
-        int b[12];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xff; b[4 + k] = (w1 >> (8 * k)) & 0xff; b[8 + k] = (w2 >> (8 * k)) & 0xff; }
-        int o[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) acc += taps.t[k] * b[p + 1 + k];    // output x = x0+4q+p uses x-3 .. x+3 = tile bytes 4q+p+1 ..
-            o[p] = acc;
-        }
-        s_h[r * (SF_TW / 2) + 2 * q] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        s_h[r * (SF_TW / 2) + 2 * q + 1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        // output x = x0+4q+p uses x-3 .. x+3 = tile bytes 4q+p+1 .. 4q+p+7
+        const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1u), tlo, 0u, false), false);
+        const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2u), tlo, 0u, false), false);
+        const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3u), tlo, 0u, false), false);
+        const uint32_t o3 = __builtin_amdgcn_udot4(w2, thi, __builtin_amdgcn_udot4(w1, tlo, 0u, false), false);
+        uint16_t* col = s_h16 + (size_t)(4 * q) * (2 * HS) + r;
+        col[0] = (uint16_t)o0; col[2 * HS] = (uint16_t)o1; col[4 * HS] = (uint16_t)o2; col[6 * HS] = (uint16_t)o3;
     }
     __syncthreads();
-    // ---- column pass: each thread 4 pixels wide x 4 rows tall (10 rows of row-pass words)
+    // ---- column pass: each thread 4 pixels wide x 4 rows tall.  Rows ry0 .. ry0+9 of a column are 5 row-pair dwords D0..D4; an even
+    // output row uses the pairs as stored, an odd one the pairs shifted by one row (v_alignbyte); 7 taps = 4 v_dot2_u32_u16, the
+    // rounding constant rides in the first accumulator.
     const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4;
     const int gx = x0 + 4 * q;
     if (gx >= W) return;
-    uint32_t h0[10], h1[10];
+    const uint32_t t01 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 16), t23 = (uint32_t)taps.t[2] | ((uint32_t)taps.t[3] << 16);
+    const uint32_t t45 = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 16), t6lo = (uint32_t)taps.t[6], t6hi = (uint32_t)taps.t[6] << 16;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
+        us2 va, vb;
+        __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vb, &b, 4);
+        return __builtin_amdgcn_udot2(va, vb, c, false);
+    };
+    uint32_t res[4][4];        // [row][column]
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { h0[k] = s_h[(ry0 + k) * (SF_TW / 2) + 2 * q]; h1[k] = s_h[(ry0 + k) * (SF_TW / 2) + 2 * q + 1]; }
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t* hp = s_h + (size_t)(4 * q + c) * HS + (ry0 >> 1);
+        const uint32_t D0 = hp[0], D1 = hp[1], D2 = hp[2], D3 = hp[3], D4 = hp[4];
+        const uint32_t E0 = __builtin_amdgcn_alignbyte(D1, D0, 2u), E1 = __builtin_amdgcn_alignbyte(D2, D1, 2u);
+        const uint32_t E2 = __builtin_amdgcn_alignbyte(D3, D2, 2u), E3 = __builtin_amdgcn_alignbyte(D4, D3, 2u);
+        res[0][c] = dot2(D3, t6lo, dot2(D2, t45, dot2(D1, t23, dot2(D0, t01, 32768u))));      // rows 0..6
+        res[1][c] = dot2(D3, t6hi, dot2(E2, t45, dot2(E1, t23, dot2(E0, t01, 32768u))));      // rows 1..7
+        res[2][c] = dot2(D4, t6lo, dot2(D3, t45, dot2(D2, t23, dot2(D1, t01, 32768u))));      // rows 2..8
+        res[3][c] = dot2(D4, t6hi, dot2(E3, t45, dot2(E2, t23, dot2(E1, t01, 32768u))));      // rows 3..9
+    }
     uint8_t* d = dst + (size_t)img * dstImgStride;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int gy = y0 + ry0 + rr;
         if (gy >= H) break;
-        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int t = taps.t[k];
-            a0 += t * (int)(h0[rr + k] & 0xffff); a1 += t * (int)(h0[rr + k] >> 16);
-            a2 += t * (int)(h1[rr + k] & 0xffff); a3 += t * (int)(h1[rr + k] >> 16);
-        }
-        a0 = min((a0 + 32768) >> 16, 255); a1 = min((a1 + 32768) >> 16, 255);
-        a2 = min((a2 + 32768) >> 16, 255); a3 = min((a3 + 32768) >> 16, 255);
+        const uint32_t a0 = min(res[rr][0] >> 16, 255u), a1 = min(res[rr][1] >> 16, 255u), a2 = min(res[rr][2] >> 16, 255u), a3 = min(res[rr][3] >> 16, 255u);
         uint8_t* o = d + (size_t)gy * dstPitch + gx;
         if (gx + 3 < W && ((reinterpret_cast<uintptr_t>(o) & 3) == 0))
-            *reinterpret_cast<uint32_t*>(o) = (uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)a2 << 16) | ((uint32_t)a3 << 24);
+            *reinterpret_cast<uint32_t*>(o) = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
         else {
             o[0] = (uint8_t)a0;
             if (gx + 1 < W) o[1] = (uint8_t)a1;
