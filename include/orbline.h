@@ -114,6 +114,9 @@ int olf_orb_pyramid_level(olf_ctx* ctx, int image, int level, int blurred, uint8
 int olf_orb_debug_candidates(olf_ctx* ctx, int image, int level, int32_t* xys, int cap, int32_t* count);
 /* debug: the context's 64-int device status block (overflow flags in [0]; instrumented builds put cycle counters at [16..31]). */
 int olf_debug_status(olf_ctx* ctx, int32_t* out64);
+/* debug/test: the LSD agent's unscaled exact float division against IEEE division on blocks*256*per_thread pseudo-random operand pairs
+ * from its operand range; *mismatches = number of quotients that differ in any bit (must be 0). */
+int olf_debug_fdiv_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread, uint64_t* mismatches);
 
 /* ---- Frame::ComputeStereoMatches (src/Frame.cc:702-876) ------------------------------------- */
 /* Stereo point matching for n_pairs pairs whose ORB features (images 2p = left, 2p+1 = right) came from

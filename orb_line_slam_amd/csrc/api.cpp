@@ -351,6 +351,18 @@ int olf_debug_status(olf_ctx* c, int32_t* out64)
     return OLF_OK;
 }
 
+int olf_debug_fdiv_sweep(olf_ctx* c, uint64_t seed, int blocks, int per_thread, uint64_t* mismatches)
+{
+    if (!c || !mismatches || blocks < 1 || per_thread < 1) { set_error("olf_debug_fdiv_sweep: bad argument"); return OLF_ERR_INVALID; }
+    void* st = nullptr;
+    OLF_TRY(scratch_get(c, 1, 64, &st));
+    OLF_HIP_CHECK(hipMemsetAsync(st, 0, 8, c->stream));
+    OLF_TRY(launch_fdiv_sweep((unsigned long long)seed, blocks, per_thread, (unsigned long long*)st, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(mismatches, st, 8, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 int olf_orb_debug_candidates(olf_ctx* c, int image, int level, int32_t* xys, int cap, int32_t* count)
 {
     if (!c || !xys || !count || image < 0 || image >= c->max_images || level < 0 || level >= c->orb.geom.nlevels) return OLF_ERR_INVALID;

@@ -84,6 +84,7 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
                       const LineGeom& g, int which, int n_images, hipStream_t s);
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
+int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 size_t lsd_sort_temp_bytes(int total_keys, int n_segments);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);

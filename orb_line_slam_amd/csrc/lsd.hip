@@ -325,6 +325,69 @@ int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
     return OLF_OK;
 }
 
+// a / b for 0 <= a <= b, b in the normal range and far from overflow (the agent's sums): v_rcp_f32 refined by two Newton steps on the
+// reciprocal and two residual corrections on the quotient -- the core of the IEEE division expansion (correctly rounded for any
+// reciprocal seed within 1 ulp) without the range scaling (v_div_scale / v_div_fixup) that these operands never need.
+// tests/test_device_math_gpu.py compares it with the compiler's IEEE division on 2^30 operand pairs.
+__device__ __forceinline__ float fdiv_unscaled(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    y = __fmaf_rn(__fmaf_rn(-b, y, 1.0f), y, y);
+    float q = __fmul_rn(a, y);
+    q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
+    q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
+    return q;
+}
+
+// cv::fastAtan2 as dev_fastAtan2 (device_math.hpp), for the agent's region angle: |x| via source modifiers and the unscaled division.
+// Only the sign of a zero result can differ from dev_fastAtan2 (x or y == -0.0f), and the region angle is only ever compared.
+__device__ __forceinline__ float agent_fastAtan2(float y, float x)
+{
+    const float k = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
+    const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mn = fminf(ax, ay), mx = fmaxf(ax, ay);
+    const float c = fdiv_unscaled(mn, f_add(mx, eps));
+    const float c2 = f_mul(c, c);
+    float a = f_mul(f_add(f_mul(f_add(f_mul(f_add(f_mul(p7, c2), p5), c2), p3), c2), p1), c);
+    if (!(ax >= ay)) a = f_sub(90.f, a);
+    if (x < 0) a = f_sub(180.f, a);
+    if (y < 0) a = f_sub(360.f, a);
+    return a;
+}
+
+// debug / test: fdiv_unscaled against the compiler's IEEE division on pseudo-random operand pairs 0 <= a <= b drawn from the agent's
+// operand range (sums of up to ~10^5 unit vectors, plus tiny and equal operands); counts the bit mismatches
+__global__ __launch_bounds__(256) void k_fdiv_sweep(unsigned long long seed, int per_thread, unsigned long long* __restrict__ mismatches)
+{
+    unsigned long long st = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * 256 + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+        const unsigned long long r = st * 0x2545F4914F6CDD1Dull;
+        // exponents: b in [2^-40, 2^17), a = b * u with u in [0, 1] at several granularities (random mantissas)
+        const int eb = (int)(r & 63) - 45;                                   // -45 .. 18
+        float b = ldexpf(1.0f + (float)((r >> 8) & 0x7fffff) * 1.1920929e-7f, eb);
+        float a = ldexpf(1.0f + (float)((r >> 32) & 0x7fffff) * 1.1920929e-7f, eb - (int)((r >> 56) & 31));
+        if (((r >> 61) & 7) == 0) a = b;
+        if (((r >> 61) & 7) == 1) a = 0.f;
+        if (a > b) a = b;
+        b = __fadd_rn(b, (float)2.2204460492503131e-16);                    // the "+ eps" of fastAtan2's denominator
+        const float q0 = __fdiv_rn(a, b), q1 = fdiv_unscaled(a, b);
+        bad += __float_as_uint(q0) != __float_as_uint(q1);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fdiv_sweep, dim3(blocks), dim3(256), 0, s, seed, per_thread, d_mismatches);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
 constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
 
@@ -445,7 +508,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 unsigned long long acc = 0;
                 const int n0 = n;
                 while (cm) {
-                    const unsigned long long al = __ballot(cand && is_aligned(ang, reg_angle, prec)) & cm;
+                    const unsigned long long al = __ballot(is_aligned(ang, reg_angle, prec)) & cm;      // cm only ever holds live candidates
                     if (!al) break;
                     const int c = __builtin_ctzll(al);
                     cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
@@ -461,10 +524,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     ++n;
                     sumdx = (float)d_add((double)sumdx, cs_c);
                     sumdy = (float)d_add((double)sumdy, sn_c);
-                    reg_angle = d_mul((double)dev_fastAtan2(sumdy, sumdx), kDegToRads);
-                    const unsigned long long dup = __ballot(a == a_c);   // the same pixel seen through another FIFO entry of this batch
-                    cm &= ~dup;
-                    if (a == a_c) cand = false;
+                    reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                    cm &= ~__ballot(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
                 }
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {

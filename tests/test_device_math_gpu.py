@@ -1,0 +1,16 @@
+"""GPU checks of device arithmetic that must equal IEEE / the CPU bit for bit."""
+import ctypes as C
+import pytest
+from orb_line_slam_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_agent_division_is_ieee_exact():
+    """The LSD agent divides with v_rcp_f32 + Newton / residual steps and no range scaling (lsd.hip fdiv_unscaled): over 2^30 operand pairs
+    from its operand range (0 <= a <= b, b in [2^-45, 2^19), incl. a == b and a == 0) every quotient equals the IEEE division's."""
+    ctx = _lib.Context(_lib.default_params(), 640, 480, 1)
+    for seed in (1, 0xDEADBEEF, 20260928):
+        bad = C.c_uint64(123)
+        _lib.check(_lib.lib().olf_debug_fdiv_sweep(ctx.handle, seed, 16384, 256 // 3 + 1, C.byref(bad)), "olf_debug_fdiv_sweep")
+        assert bad.value == 0, (seed, bad.value)
