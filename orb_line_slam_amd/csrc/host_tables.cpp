@@ -176,6 +176,12 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.Ps = g.Ws * g.Hs;
     if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
     g.prec = kPI * p.lsd_ang_th / 180;
+    {   // 2*pi - prec in 64-bit-mantissa arithmetic is exact (two doubles three binades apart), then rounded up to a double
+        const long double w = (long double)(2 * kPI) - (long double)g.prec;
+        double t = (double)w;
+        if ((long double)t < w) t = std::nextafter(t, 1e300);
+        g.precWrap = t;
+    }
     const double pp = p.lsd_ang_th / 180;
     const double rho = p.lsd_quant / std::sin(g.prec);
     int n = 0;

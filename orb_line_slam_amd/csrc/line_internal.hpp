@@ -24,6 +24,7 @@ struct LineGeom {
     int nBins;
     int minRegSize;
     double prec;               // pi * ang_th / 180
+    double precWrap;           // smallest double >= 2*pi - prec (exact): n >= precWrap <=> |n - 2*pi| <= prec for n in (3*pi/2, 2*pi + prec]
     double scale;              // lsd_scale
     double minLength;          // min_line_length * min(W, H)
     int maxDetect;             // capacity of the raw key line list

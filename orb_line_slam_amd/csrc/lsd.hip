@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     uint32_t* reg = regionAll + (size_t)img * g.Ps;
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
-    const double prec = g.prec;
+    const double prec = g.prec, precWrap = g.precWrap;
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int nreg = 0, rbase = 0;
@@ -508,7 +508,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 unsigned long long acc = 0;
                 const int n0 = n;
                 while (cm) {
-                    const unsigned long long al = __ballot(is_aligned(ang, reg_angle, prec)) & cm;      // cm only ever holds live candidates
+                    // isaligned(): n = |theta - a|; if (n > 3pi/2) n = |n - 2pi|; n <= prec.  For n in (3pi/2, 2pi + prec] the subtraction is exact
+                    // (Sterbenz), so the wrapped test is n >= 2pi - prec, with that bound rounded up to a double on the host (precWrap);
+                    // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
+                    const double nth = fabs(d_sub(reg_angle, ang));
+                    const unsigned long long al = __ballot(nth <= prec || nth >= precWrap) & cm;      // cm only ever holds live candidates
                     if (!al) break;
                     const int c = __builtin_ctzll(al);
                     cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
