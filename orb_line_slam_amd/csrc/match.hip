@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
         const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
         a0 = qp[0]; a1 = qp[1];
     }
-    int b0 = 0x7fffffff, b1 = 0x7fffffff, i0 = -1;
+    // (distance << 16 | train index) keys: the minimum key is the best match with "ties keep the lower train index first" (App. A.10),
+    // and the second smallest key carries the second best distance of the multiset -- three integer min/max per candidate
+    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
     const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)set * strideT * OLF_DESC_BYTES);
     for (int t0 = 0; t0 < nt; t0 += KNN_TILE) {
         const int cnt = min(KNN_TILE, nt - t0);
@@ -253,15 +255,16 @@ __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, con
         if (threadIdx.x < 2 * cnt) s_t[threadIdx.x] = tp[2 * t0 + threadIdx.x];
         __syncthreads();
         for (int j = 0; j < cnt; ++j) {
-            const int d = ham256(a0, a1, s_t[2 * j], s_t[2 * j + 1]);
-            // ascending train index + strict '<' == "ties keep the lower train index first" (App. A.10)
-            if (d < b0) { b1 = b0; b0 = d; i0 = t0 + j; }
-            else if (d < b1) b1 = d;
+            const unsigned k = ((unsigned)ham256(a0, a1, s_t[2 * j], s_t[2 * j + 1]) << 16) | (unsigned)(t0 + j);
+            k1 = min(k1, max(k0, k));
+            k0 = min(k0, k);
         }
     }
     if (live) {
         const size_t o = (size_t)set * strideQ + iq;
-        idx0[o] = i0; dist0[o] = b0; dist1[o] = b1;
+        idx0[o] = k0 == 0xffffffffu ? -1 : (int)(k0 & 0xffffu);
+        dist0[o] = k0 == 0xffffffffu ? 0x7fffffff : (int)(k0 >> 16);
+        dist1[o] = k1 == 0xffffffffu ? 0x7fffffff : (int)(k1 >> 16);
     }
 }
 
