@@ -481,25 +481,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const int nb = min(7, n - i);
                 const int e = lane / 9, k = lane - 9 * e;
                 if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
-                bool cand = false;
-                int a = -1, xy = 0;
-                uint32_t pw = 0;
+                // one predicate, no nested regions: every lane forms an address (0 when it has nothing to look at) and loads; only the
+                // table lookups, which cost real cache traffic, are skipped for non-candidates
+                bool cand = lane < 63 && e < nb && k != 4;
+                const uint32_t rp = (n - i > RING) ? reg[rbase + i + (cand ? e : 0)] : s_ring[(i + e) & (RING - 1)];
+                const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
+                cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
+                const int a = cand ? yy * Ws + xx : 0;
+                const uint32_t pw = grad[a];
+                const int xy = xx | (yy << 16);
+                cand = cand && !(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a;
                 double ang = 0, cs = 0, sn = 0;
-                if (lane < 63 && e < nb && k != 4) {
-                    const uint32_t rp = (n - i > RING) ? reg[rbase + i + e] : s_ring[(i + e) & (RING - 1)];
-                    const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
-                    if (xx >= 0 && yy >= 0 && xx < Ws && yy < Hs) {
-                        a = yy * Ws + xx;
-                        pw = grad[a];
-                        if (!(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a) {
-                            cand = true;
-                            xy = xx | (yy << 16);
-                            const uint32_t ti = pw & 0x3fffffu;
-                            ang = d_mul((double)angDeg[ti], kDegToRads);
-                            const double2 t = cosSin[ti];
-                            cs = t.x; sn = t.y;
-                        }
-                    }
+                if (cand) {
+                    const uint32_t ti = pw & 0x3fffffu;
+                    ang = d_mul((double)angDeg[ti], kDegToRads);
+                    const double2 t = cosSin[ti];
+                    cs = t.x; sn = t.y;
                 }
                 // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
