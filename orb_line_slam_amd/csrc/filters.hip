@@ -152,12 +152,14 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     }
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_src);
-    for (int i = threadIdx.x; i < nrows * RZ_TW; i += 256) {
-        const int r = i >> 8, x = i & 255;
-        if (x < nx) {
-            const ResizeCoef c = s_rx[x];
-            const int sx = c.ofs, sx1 = min(sx + 1, sw - 1);
-            const int h = (int)sb[r * RZ_SW * 4 + sx - cx0] * c.a0 + (int)sb[r * RZ_SW * 4 + sx1 - cx0] * c.a1;
+    if ((int)threadIdx.x < nx) {
+        // thread x owns output column x of the tile for every staged source row: its two source bytes and weights are fixed
+        const int x = threadIdx.x;
+        const ResizeCoef c = s_rx[x];
+        const int o0 = (int)c.ofs - cx0, o1 = min((int)c.ofs + 1, sw - 1) - cx0;
+        const int a0 = c.a0, a1 = c.a1;
+        for (int r = 0; r < nrows; ++r) {
+            const int h = (int)sb[r * RZ_SW * 4 + o0] * a0 + (int)sb[r * RZ_SW * 4 + o1] * a1;
             s_h[r * RZ_TW + x] = (uint16_t)(h >> 4);
         }
     }
