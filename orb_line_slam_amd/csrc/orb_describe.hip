@@ -23,13 +23,25 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
 {
     constexpr int PR = 18, PW = 2 * PR + 1, PDW = 10;      // patch radius (|rotated pattern coordinate| <= round(13 * sqrt 2) = 18), 37 rows of 10 dwords
     __shared__ uint32_t s_pat[256];
-    __shared__ int s_umax[kHalfPatch + 1];
+    __shared__ uint32_t s_w0[256], s_w1[256];             // IC_Angle disc as byte weights per (row, dword) slot: 1 / (u + 16) inside, 0 outside
     __shared__ uint32_t s_patch[4][PW * PDW];
     const OrbGeom& g = *gp;
     const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int slot = blockIdx.x * 4 + wv;
     s_pat[threadIdx.x] = reinterpret_cast<const uint32_t*>(c_pattern)[threadIdx.x];
-    if (threadIdx.x <= kHalfPatch) s_umax[threadIdx.x] = g.umax[threadIdx.x];
+    {   // slot t = (row r = t / 8, dword j = t % 8) covers columns u = 4j - 16 .. 4j - 13 of row v = r - 15 (column -16 is padding)
+        const int r = threadIdx.x >> 3, j = threadIdx.x & 7, v = r - kHalfPatch;
+        uint32_t w0 = 0, w1 = 0;
+        if (r <= 2 * kHalfPatch) {
+            const int d = g.umax[v < 0 ? -v : v];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int u = 4 * j + b - 16;
+                if (u >= -d && u <= d) { w0 |= 1u << (8 * b); w1 |= (uint32_t)(u + 16) << (8 * b); }
+            }
+        }
+        s_w0[threadIdx.x] = w0; s_w1[threadIdx.x] = w1;
+    }
     __syncthreads();
     const int* lc = lvlCount + img * g.nlevels;
     if (slot == 0 && lane == 0) {
@@ -52,21 +64,24 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
 
     // ---- IC_Angle on the un-blurred level
     const uint8_t* im = pyr + (size_t)img * g.pyrBytes + L.offset;
-    int m10 = 0, m01 = 0;
-    const int half = lane >> 5, ul = lane & 31;
+    // m10 = sum u*I, m01 = sum v*I over the disc (:79-106).  The 31 rows are read as 8 (unaligned) dwords each; with the byte weights
+    // above a dword contributes v_dot4_u32_u8(I, w0) to the row sum and v_dot4_u32_u8(I, w1) to sum (u+16)*I.
+    int m10 = 0, m01 = 0, sI = 0;
+    const uint8_t* ic = im + (size_t)(cy - kHalfPatch) * L.pitch + cx - 16;
 #pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-        const int v = -kHalfPatch + 2 * pass + half;
-        if (v <= kHalfPatch) {
-            const int d = s_umax[v < 0 ? -v : v];
-            const int u = ul - 15;
-            if (u >= -d && u <= d) {
-                const int val = im[(size_t)(cy + v) * L.pitch + cx + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int slot = pass * 64 + lane;
+        if (slot < (2 * kHalfPatch + 1) * 8) {
+            const int r = slot >> 3, j = slot & 7;
+            uint32_t I;
+            __builtin_memcpy(&I, ic + (size_t)r * L.pitch + 4 * j, 4);
+            const int rs = (int)__builtin_amdgcn_udot4(I, s_w0[slot], 0u, false);
+            m10 = (int)__builtin_amdgcn_udot4(I, s_w1[slot], (uint32_t)m10, false);
+            sI += rs;
+            m01 += (r - kHalfPatch) * rs;
         }
     }
+    m10 -= 16 * sI;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         m10 += __shfl_xor(m10, o);
