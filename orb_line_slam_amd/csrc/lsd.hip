@@ -251,16 +251,26 @@ __global__ __launch_bounds__(256) void k_lsd_iso(uint32_t* __restrict__ gradAll,
     const uint32_t* deg = degbuf + (size_t)img * g.Ps;
     const int idx = (int)(keysAll[(size_t)img * g.Ps + i] & 0x3fffffu);
     const int y = idx / g.Ws, x = idx - y * g.Ws;
-    const double a0 = d_mul((double)__uint_as_float(deg[idx]), kDegToRads);
-    bool iso = true;
+    // all 16 neighbour loads (gradient word + angle) are issued before anything is tested: the kernel is latency bound, and the angle
+    // buffer is valid memory for every pixel (its value is simply unused where the pixel is undefined)
+    uint32_t nw[8], nd[8];
+    bool inb[8];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         if (k == 4) continue;
+        const int q = k < 4 ? k : k - 1;
         const int xx = x + (k % 3) - 1, yy = y + (k / 3) - 1;
-        if (xx < 0 || yy < 0 || xx >= g.Ws || yy >= g.Hs) continue;
-        const int na = yy * g.Ws + xx;
-        if (grad[na] & kNotDef) continue;
-        const double a = d_mul((double)__uint_as_float(deg[na]), kDegToRads);
+        inb[q] = xx >= 0 && yy >= 0 && xx < g.Ws && yy < g.Hs;
+        const int na = inb[q] ? yy * g.Ws + xx : idx;
+        nw[q] = grad[na];
+        nd[q] = deg[na];
+    }
+    const double a0 = d_mul((double)__uint_as_float(deg[idx]), kDegToRads);
+    bool iso = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (!inb[q] || (nw[q] & kNotDef)) continue;
+        const double a = d_mul((double)__uint_as_float(nd[q]), kDegToRads);
         double n_theta = d_sub(a0, a);
         if (n_theta < 0) n_theta = -n_theta;
         if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
