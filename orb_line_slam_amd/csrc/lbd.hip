@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
     float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
     // the sample coordinates are a cheap sequential float chain, the sums a sequential one on the loaded values: 8 samples are
     // addressed and loaded per step so that their loads are in flight together (the kernel is latency bound), then accumulated in order
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int w0 = 0; w0 < lengthOfLSP; w0 += U) {
         uint32_t p[U];
 #pragma unroll

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     const int n = rr.n, Ws = g.Ws;
     // both passes are chains of dependent loads (pixel list -> gradient word); 8 pixels are fetched per step so that the loads of a
     // step are in flight together, the additions stay strictly in growth order
-    constexpr int U = 8;
+    constexpr int U = 16;
     double x = 0, y = 0, sum = 0;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U], p[U];
