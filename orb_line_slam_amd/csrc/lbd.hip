@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
                 const float dx = (float)(int)(int16_t)(p[u] & 0xffffu), dy = (float)(int)(int16_t)(p[u] >> 16);
                 const float gDL = f_add(f_mul(dx, dL0), f_mul(dy, dL1));
                 const float gDO = f_add(f_mul(dx, dO0), f_mul(dy, dO1));
-                if (gDL > 0) pgdL = f_add(pgdL, gDL); else ngdL = f_sub(ngdL, gDL);
-                if (gDO > 0) pgdO = f_add(pgdO, gDO); else ngdO = f_sub(ngdO, gDO);
+                // "if (g > 0) p += g; else n -= g;": adding / subtracting a zero is exact, so both sums can be updated unconditionally
+                pgdL = f_add(pgdL, fmaxf(gDL, 0.f)); ngdL = f_sub(ngdL, fminf(gDL, 0.f));
+                pgdO = f_add(pgdO, fmaxf(gDO, 0.f)); ngdO = f_sub(ngdO, fminf(gDO, 0.f));
             }
         }
     }
