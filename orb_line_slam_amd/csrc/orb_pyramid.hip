@@ -240,7 +240,19 @@ __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ g
     const int n = min(*cnt, g.cellCap);
     if (n == 0) return;
     uint32_t* slot = cells + ((size_t)img * g.totalCells + cell) * g.cellCap;
-    int sortN = 64;
+    if (n <= 64) {
+        // the common case: one key per lane, rank = number of smaller keys (keys are distinct: one per pixel), no LDS, no barriers
+        uint32_t k = lane < n ? slot[lane] : 0xffffffffu;
+        const bool anyIni = __ballot(lane < n && (int)(k & 0xffu) >= g.iniTh) != 0;
+        if (anyIni && (int)(k & 0xffu) < g.iniTh) k = 0xffffffffu;
+        const int kept = __popcll(__ballot(k != 0xffffffffu));
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)k, j) < k;
+        if (k != 0xffffffffu) slot[rank] = (((k >> 8) & 0xfffu) << 20) | ((k >> 20) << 8) | (k & 0xffu);
+        if (lane == 0) *cnt = kept;
+        return;
+    }
+    int sortN = 128;
     while (sortN < n) sortN <<= 1;
     bool anyIni = false;
     for (int i = lane; i < sortN; i += 64) {
