@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
                                                       const unsigned* __restrict__ bestKey, float* __restrict__ uRight,
                                                       float* __restrict__ depth, int* __restrict__ sad)
 {
+    __shared__ uint8_t s_strip[4][11 * 21 + 1];
     const OrbGeom& g = *gp;
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -118,6 +119,13 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
             const uint8_t* IR = pyr + (size_t)(2 * pair + 1) * g.pyrBytes + L.offset;
             const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR0 = (int)scaleduR0;
             const int cL = IL[(size_t)cy * L.pitch + cxL];
+            // the 11 shifted 11x11 windows of the right image overlap in a 21x11 strip: it is staged once in LDS (4 byte loads per lane
+            // instead of 33) and every shift reads its window and its centre pixel from there
+            uint8_t* strip = s_strip[threadIdx.x >> 6];
+            for (int idx = lane; idx < 11 * 21; idx += 64) {
+                const int ry = idx / 21, rx = idx - ry * 21;
+                strip[idx] = IR[(size_t)(cy + ry - w) * L.pitch + cxR0 + rx - (w + Ls)];
+            }
             // each lane owns up to two of the 121 patch pixels
             int a[2], py[2], px[2];
 #pragma unroll
@@ -126,17 +134,17 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
                 py[k] = idx / 11 - w; px[k] = idx % 11 - w;
                 a[k] = idx < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
             }
+            __builtin_amdgcn_wave_barrier();
             int dists[11];
 #pragma unroll
             for (int inc = -Ls; inc <= Ls; ++inc) {
-                const int cxR = cxR0 + inc;
-                const int cR = IR[(size_t)cy * L.pitch + cxR];
+                const int cR = strip[w * 21 + (w + Ls) + inc];
                 int s = 0;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int idx = lane + 64 * k;
                     if (idx < 121) {
-                        const int b = (int)IR[(size_t)(cy + py[k]) * L.pitch + cxR + px[k]] - cR;
+                        const int b = (int)strip[(py[k] + w) * 21 + px[k] + (w + Ls) + inc] - cR;
                         const int df = a[k] - b;
                         s += df < 0 ? -df : df;
                     }
