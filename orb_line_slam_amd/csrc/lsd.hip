@@ -459,6 +459,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int nreg = 0, rbase = 0;
+#ifdef OLF_STATS
+    long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
+#endif
 #ifdef OLF_TIMING
     long long t_seed = 0, t_small = 0, t_big = 0, t_rect = 0, n_small = 0, n_big = 0, it_small = 0, it_big = 0; long long t0 = __builtin_readcyclecounter();
 #endif
@@ -497,8 +500,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int n = 1;
             const uint32_t pseed = grad[seed];
             double reg_angle = d_mul((double)dev_fastAtan2((float)unpack_gx(pseed), (float)(-unpack_gy(pseed))), kDegToRads);
-            float sumdx = 0.f, sumdy = 0.f;
-            bool have_sum = false;
+            // region_grow starts the sums at (cos, sin) of the seed's own angle (double argument, unlike the added pixels); done here, once per
+            // region, so that the accept chain below carries no initialisation branch
+            float sumdx, sumdy;
+            {
+                double s0, c0;
+                sincos_2pi(reg_angle, &s0, &c0);
+                sumdx = (float)c0; sumdy = (float)s0;
+            }
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
             __builtin_amdgcn_wave_barrier();
@@ -542,24 +551,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // (Sterbenz), so the wrapped test is n >= 2pi - prec, with that bound rounded up to a double on the host (precWrap);
                     // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
                     const double nth = fabs(d_sub(reg_angle, ang));
-                    const unsigned long long al = __ballot(nth <= prec || nth >= precWrap) & cm;      // cm only ever holds live candidates
+                    const bool was = nth <= prec || nth >= precWrap;
+                    const unsigned long long al = __ballot(was) & cm;      // cm only ever holds live candidates
                     if (!al) break;
-                    const int c = __builtin_ctzll(al);
-                    cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
-                    const int a_c = rlane(a, c);
-                    const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
-                    if (!have_sum) {
-                        double s0, c0;
-                        sincos_2pi(reg_angle, &s0, &c0);
-                        sumdx = (float)c0; sumdy = (float)s0;
-                        have_sum = true;
+                    if ((al & (al - 1ull)) == 0) {
+                        // a single aligned candidate: the plain sequential step
+#ifdef OLF_STATS
+                        ++st_single;
+#endif
+                        const int c = __builtin_ctzll(al);
+                        cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
+                        const int a_c = rlane(a, c);
+                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
+                        acc |= 1ull << c;
+                        ++n;
+                        sumdx = (float)d_add((double)sumdx, cs_c);
+                        sumdy = (float)d_add((double)sumdy, sn_c);
+                        reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                        cm &= ~__ballot(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
+                        continue;
                     }
-                    acc |= 1ull << c;
-                    ++n;
-                    sumdx = (float)d_add((double)sumdx, cs_c);
-                    sumdy = (float)d_add((double)sumdy, sn_c);
-                    reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
-                    cm &= ~__ballot(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
+                    // Several candidates are aligned under the current (exact) angle.  Speculate that they are accepted in lane order: the
+                    // running sums after each accept are a cheap sequential chain (lane j keeps the sums after accept j), the region angle
+                    // after each of them is then ONE fastAtan2 evaluated in parallel lanes, and every candidate is re-tested against the
+                    // angle that governs it (the one after the accepts before it).  The speculation is exact up to the first candidate
+                    // whose decision differs from the one under the initial angle; everything before it is committed -- at least the first
+                    // accept, whose governing angle is the initial, exact one -- and the rest is classified again.
+                    unsigned long long todo = al, spec = 0;
+                    float sx = sumdx, sy = sumdy, psx = 0.f, psy = 0.f;
+                    int dupStep = 64, j = 0;
+                    while (todo) {
+                        const int c = __builtin_ctzll(todo);
+                        const int a_c = rlane(a, c);
+                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
+                        sx = (float)d_add((double)sx, cs_c);
+                        sy = (float)d_add((double)sy, sn_c);
+                        if (lane == j) { psx = sx; psy = sy; }
+                        const bool tw = a == a_c;                                // c and the other FIFO entries' views of the same pixel
+                        if (tw && lane != c) dupStep = j;                        // (a lane can only ever equal one accepted pixel)
+                        todo &= ~__ballot(tw);
+                        spec |= 1ull << c;
+                        ++j;
+                    }
+                    const double th = d_mul((double)agent_fastAtan2(psy, psx), kDegToRads);       // lane j: the angle after accept j
+                    const int g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(spec >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)spec, 0u));   // speculated accepts before this lane
+                    double thg = shfl_d(th, max(g - 1, 0));
+                    if (g == 0) thg = reg_angle;
+                    const double n2 = fabs(d_sub(thg, ang));
+                    const bool re = n2 <= prec || n2 >= precWrap;
+                    const unsigned long long mis = __ballot(re != was && !(dupStep < g)) & cm;
+                    const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
+                    const unsigned long long okAcc = spec & bm;
+                    const int t = __popcll(okAcc);
+#ifdef OLF_STATS
+                    ++st_rounds; st_k += j; st_t += t; if (t == j) ++st_full; if (n >= 64) { ++st_rounds_big; st_k_big += j; st_t_big += t; }
+#endif
+                    acc |= okAcc;
+                    n += t;
+                    cm &= ~bm;                                         // everything before the first changed decision is decided
+                    cm &= ~__ballot(dupStep < t);                      // other views of the committed pixels
+                    sumdx = __int_as_float(rlane(__float_as_int(psx), t - 1));
+                    sumdy = __int_as_float(rlane(__float_as_int(psy), t - 1));
+                    reg_angle = rlane_d(th, t - 1);
                 }
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
@@ -607,6 +660,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #undef PEND_FLUSH
 #ifdef OLF_TIMING
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = t_seed; o[1] = t_small; o[2] = t_big; o[3] = t_rect; o[4] = n_small; o[5] = n_big; o[6] = it_small; o[7] = it_big; }
+#endif
+#ifdef OLF_STATS
+    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big; }
 #endif
     if (lane == 0) regCount[img] = nreg;
 }

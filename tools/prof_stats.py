@@ -10,4 +10,4 @@ k, d, c = ex.extract_batch(imgs)
 out = np.zeros(64, np.int32)
 _lib.lib().olf_debug_status(ex._ctx.handle, out.ctypes.data_as(C.c_void_p))
 t = out[16:32].view(np.int64)
-print(dict(zip(["iters", "rounds", "unc", "acc", "iters_big", "rounds_big", "unc_big", "acc_big"], t.tolist())))
+print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big"], t.tolist())))
