@@ -197,7 +197,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n); A(l.region, n * lg.Ps);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
-    A(l.angDeg, (size_t)1 << 22); A(l.cosSin, (size_t)1 << 22);
+    A(l.angDeg, (size_t)1 << 22); A(l.cosSin, (size_t)1 << 22); A(l.seedCS, (size_t)1 << 22);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
     {

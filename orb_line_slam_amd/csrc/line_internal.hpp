@@ -66,7 +66,8 @@ struct LineDeviceBufs {
     size_t sortTempBytes = 0;
     int* status = nullptr;
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
-    double2* cosSin = nullptr;     // [2^22] cos / sin of that angle as the reference evaluates them
+    double2* cosSin = nullptr;     // [2^22] cos / sin of that angle as the reference evaluates them for an added pixel (float-rounded argument)
+    float2* seedCS = nullptr;      // [2^22] (float)cos / (float)sin of the unrounded angle: the sums a region starts with
 };
 
 struct LineHostTables {

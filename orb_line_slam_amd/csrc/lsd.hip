@@ -339,7 +339,7 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 // context over the packed 22-bit (gx:11 | gy:11) field of the gradient word -- 84 MB, image independent, shared by every agent; real
 // images touch a small, L2 / Infinity-Cache resident part of it.  This takes fastAtan2 and the double sincos out of the agent's
 // per-iteration instruction stream (the agent is VALU-issue bound), at the price of one more dependent load.
-__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, double2* __restrict__ cosSin)
+__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, double2* __restrict__ cosSin, float2* __restrict__ seedCS)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int gx = unpack_gx(i), gy = unpack_gy(i);
@@ -349,11 +349,15 @@ __global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ ang
     sincos_2pi((double)(float)ang, &sn, &cs);
     angDeg[i] = deg;
     cosSin[i] = make_double2(cs, sn);
+    // region_grow starts its sums at float(cos(reg_angle)), float(sin(reg_angle)) with the seed's angle as a double
+    double s0, c0;
+    sincos_2pi(ang, &s0, &c0);
+    seedCS[i] = make_float2((float)c0, (float)s0);
 }
 
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, b.cosSin);
+    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, b.cosSin, b.seedCS);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
                                                  int* __restrict__ status, const float* __restrict__ angDeg,
-                                                 const double2* __restrict__ cosSin)
+                                                 const double2* __restrict__ cosSin, const float2* __restrict__ seedCS)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
@@ -499,15 +503,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             // ---- region_grow ------------------------------------------------------------------
             int n = 1;
             const uint32_t pseed = grad[seed];
-            double reg_angle = d_mul((double)dev_fastAtan2((float)unpack_gx(pseed), (float)(-unpack_gy(pseed))), kDegToRads);
-            // region_grow starts the sums at (cos, sin) of the seed's own angle (double argument, unlike the added pixels); done here, once per
-            // region, so that the accept chain below carries no initialisation branch
-            float sumdx, sumdy;
-            {
-                double s0, c0;
-                sincos_2pi(reg_angle, &s0, &c0);
-                sumdx = (float)c0; sumdy = (float)s0;
-            }
+            // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
+            // are per-(gx, gy) table entries, so the chain below carries no initialisation branch and a region start costs two loads
+            double reg_angle = d_mul((double)angDeg[pseed & 0x3fffffu], kDegToRads);
+            const float2 scs = seedCS[pseed & 0x3fffffu];
+            float sumdx = scs.x, sumdy = scs.y;
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
             __builtin_amdgcn_wave_barrier();
@@ -861,7 +861,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin);
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
