@@ -188,7 +188,6 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     rc = c->line.build(p->line, width, height);
     if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
     const LineGeom& lg = c->line.geom;
-    if ((double)n * lg.Ps >= 4294967295.0) { set_error("olf_ctx_create: max_images * LSD working size exceeds 2^32 keys"); return fail(OLF_ERR_CAPACITY); }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }
@@ -210,7 +209,10 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     }
 #undef A
     l.status = b.status;
-    l.sortTempBytes = lsd_sort_temp_bytes((int)std::min<size_t>(n * lg.Ps, 0xffffffffu), (int)n);
+    {
+        const size_t chunk = std::min<size_t>(n, (size_t)lsd_sort_chunk_images(lg.Ps));
+        l.sortTempBytes = lsd_sort_temp_bytes(chunk * lg.Ps, (int)chunk);
+    }
     if (hipMalloc(&l.sortTemp, std::max<size_t>(l.sortTempBytes, 256)) != hipSuccess) { set_error("hipMalloc(sort temp) failed"); return fail(OLF_ERR_HIP); }
     if (hipMemcpy(l.rx, c->line.rx.data(), c->line.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.ry, c->line.ry.data(), c->line.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||

@@ -87,7 +87,8 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
                       const LineGeom& g, int which, int n_images, hipStream_t s);
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
-size_t lsd_sort_temp_bytes(int total_keys, int n_segments);
+int lsd_sort_chunk_images(int Ps);
+size_t lsd_sort_temp_bytes(size_t total_keys, int n_segments);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);
 int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_desc,

@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void k_lsd_iso(uint32_t* __restrict__ gradAll,
     if (iso) grad[idx] |= kIso;      // neighbours only read the NOTDEF bit of this word
 }
 
-__global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, unsigned* __restrict__ b, unsigned* __restrict__ e)
+// segment offsets for the sort; the batch is sorted in chunks of `per_chunk` images (32-bit key offsets inside a chunk)
+__global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, int per_chunk, unsigned* __restrict__ b, unsigned* __restrict__ e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { b[i] = (unsigned)i * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i * 32]; }
+    if (i < n) { b[i] = (unsigned)(i % per_chunk) * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i * 32]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -424,6 +425,8 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
+
+int lsd_sort_chunk_images(int Ps);
 
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
 constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
@@ -824,7 +827,10 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t lsd_sort_temp_bytes(int total_keys, int n_segments)
+// images per sort call: the segmented sort addresses its keys with 32 bits
+int lsd_sort_chunk_images(int Ps) { return std::max(1, (int)(0xffffffffull / (unsigned long long)Ps) - 1); }
+
+size_t lsd_sort_temp_bytes(size_t total_keys, int n_segments)
 {
     size_t bytes = 0;
     (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)total_keys,
@@ -850,11 +856,15 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
                        b.region, b.angDeg);
     hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
-    hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, b.segBegin, b.segEnd);
+    const int per_chunk = lsd_sort_chunk_images(g.Ps);
+    hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, per_chunk, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
-    size_t tb = b.sortTempBytes;
-    OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA, b.keysB, (unsigned)((size_t)n_images * g.Ps), (unsigned)n_images,
-                                                      b.segBegin, b.segEnd, 22, 32, s));
+    for (int i0 = 0; i0 < n_images; i0 += per_chunk) {
+        const int cnt = std::min(per_chunk, n_images - i0);
+        size_t tb = b.sortTempBytes;
+        OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA + (size_t)i0 * g.Ps, b.keysB + (size_t)i0 * g.Ps,
+                                                          (unsigned)((size_t)cnt * g.Ps), (unsigned)cnt, b.segBegin + i0, b.segEnd + i0, 22, 32, s));
+    }
     return OLF_OK;
 }
 
