@@ -116,6 +116,14 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
 {
     Taps7 t;
     for (int i = 0; i < 7; ++i) t.t[i] = taps7[i];
+    if (t.t[3] == 256) {
+        // the identity kernel (cv::LineSegmentDetector at scale 1 skips its blur; a 256 does not fit the 8-bit tap fields of k_sep7): pitched copy
+        for (int i = 0; i < n_images; ++i)
+            OLF_HIP_CHECK(hipMemcpy2DAsync(dst + (size_t)i * dstImgStride, dstPitch, src + (size_t)i * srcImgStride, srcPitch, W, H, hipMemcpyDeviceToDevice, s));
+        return OLF_OK;
+    }
+    for (int i = 0; i < 7; ++i)
+        if (t.t[i] < 0 || t.t[i] > 255) { set_error("launch_sep7: taps must be 8-bit fractions"); return OLF_ERR_INVALID; }
     hipLaunchKernelGGL(k_sep7, dim3((W + SF_TW - 1) / SF_TW, (H + SF_TH - 1) / SF_TH, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch,
                        dst, dstImgStride, dstPitch, W, H, t);
     OLF_HIP_CHECK(hipGetLastError());

@@ -137,3 +137,33 @@ def test_stereo_frames_odd_sizes(oracle, w, h):
         assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
         m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
         assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+
+
+@pytest.mark.parametrize("orb,line", [
+    ((1500, 1.5, 4, 25, 10), dict(lsd_nfeatures=0, min_line_length=0.05, lsd_ang_th=20.0, lsd_n_bins=512)),      # keep all lines
+    ((300, 1.1, 6, 12, 5), dict(lsd_nfeatures=80, lsd_scale=1.0, lsd_quant=1.5)),                                  # no LSD rescale
+    ((800, 1.2, 8, 30, 15), dict(lsd_nfeatures=150, lsd_scale=0.8, lsd_sigma_scale=0.6, lsd_density_th=0.7)),       # OpenCV's default LSD scale
+])
+def test_stereo_frames_parameter_sets(oracle, orb, line):
+    """non-default ORBextractor / Config parameters: other pyramid geometry, thresholds, LSD scale (incl. down-scaling) and bins"""
+    w, h = 640, 480
+    p = oracle.full_params(orb[0], 0, 500.0, 60.0)
+    p.orb.nfeatures, p.orb.scale_factor, p.orb.nlevels, p.orb.ini_th_fast, p.orb.min_th_fast = orb
+    for k, v in line.items():
+        setattr(p.line, k, v)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=2)
+    imgs = synth.stereo_batch(77 + orb[0], 2, w, h)
+    f = fe.frames(imgs)
+    for i in range(2):
+        g = f.pair(i)
+        o = oracle.stereo_points(imgs[2 * i], imgs[2 * i + 1], p)
+        assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"])
+        assert np.array_equal(g["mvKeysRight"], o["kpsR"]) and np.array_equal(g["mDescriptorsRight"], o["descR"])
+        assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
+        ol, orr = oracle.line_extract(imgs[2 * i], p.line), oracle.line_extract(imgs[2 * i + 1], p.line)
+        _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+        _cmp_keylines(g["mvKeysRight_Line"], orr["kls"])
+        assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+        assert len(ol["kls"]) > 20
