@@ -167,3 +167,21 @@ def test_stereo_frames_parameter_sets(oracle, orb, line):
         m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
         assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
         assert len(ol["kls"]) > 20
+
+
+def test_context_reuse_across_batches(oracle):
+    """one context, batches of different sizes and content back to back: no state leaks from one call into the next"""
+    w, h = 640, 480
+    p = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=3)
+    fresh = lambda imgs: ola.StereoFrontEnd(p, w, h, max_pairs=len(imgs) // 2).frames(imgs)
+    flat = np.full((2, h, w), 90, np.uint8)
+    for seed, npairs in [(5, 3), (6, 1), (0, 1), (7, 2), (5, 3)]:
+        imgs = flat if seed == 0 else synth.stereo_batch(seed, npairs, w, h)
+        a, b = fe.frames(imgs), fresh(imgs)
+        for i in range(npairs):
+            ga, gb = a.pair(i), b.pair(i)
+            for k in ga:
+                assert ga[k].tobytes() == gb[k].tobytes(), (seed, i, k)
+    o = oracle.stereo_points(imgs[0], imgs[1], p)
+    assert np.array_equal(a.pair(0)["mvKeys"], o["kpsL"])
