@@ -454,8 +454,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
-    __shared__ double s_cs[64], s_sn[64];      // the iteration's candidates (cos, sin, pixel address) per lane: the accept chain reads them at
-    __shared__ int s_ca[64];                   // wave-uniform addresses (LDS broadcast) instead of five v_readlane per accept
         const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     const int Ws = g.Ws, Hs = g.Hs;
@@ -548,8 +546,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
                 // that same angle, as in the reference), the angle is updated and the rest is re-tested.
-                s_cs[lane] = cs; s_sn[lane] = sn; s_ca[lane] = a;
-                __builtin_amdgcn_wave_barrier();
                 unsigned long long cm = __ballot(cand);
                 unsigned long long acc = 0;
                 const int n0 = n;
@@ -568,8 +564,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
                         const int c = __builtin_ctzll(al);
                         cm &= ~((2ull << c) - 1ull);                 // c and everything before it is decided
-                        const int a_c = s_ca[c];
-                        const double cs_c = s_cs[c], sn_c = s_sn[c];
+                        const int a_c = rlane(a, c);
+                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
                         acc |= 1ull << c;
                         ++n;
                         sumdx = (float)d_add((double)sumdx, cs_c);
@@ -589,8 +585,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     int dupStep = 64, j = 0;
                     while (todo) {
                         const int c = __builtin_ctzll(todo);
-                        const int a_c = s_ca[c];
-                        const double cs_c = s_cs[c], sn_c = s_sn[c];
+                        const int a_c = rlane(a, c);
+                        const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
                         sx = (float)d_add((double)sx, cs_c);
                         sy = (float)d_add((double)sy, sn_c);
                         if (lane == j) { psx = sx; psy = sy; }
