@@ -1,0 +1,51 @@
+"""Error behaviour of the C ABI on a GPU box: bad arguments come back as status codes with a message, never as a crash or a silent no-op
+(the reference throws std::runtime_error / asserts in the same situations: src/Frame.cc:146, src/ORBextractor.cc:1052)."""
+import ctypes as C
+import numpy as np
+import pytest
+from orb_line_slam_amd import _lib
+from orb_line_slam_amd._lib import OLF_ERR_CAPACITY, OLF_ERR_INVALID, OLF_OK
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_bad_arguments_are_reported():
+    L = _lib.lib()
+    p = _lib.default_params()
+    h = C.c_void_p()
+    assert L.olf_ctx_create(C.byref(p), 32, 32, 1, C.byref(h)) == OLF_ERR_INVALID and L.olf_last_error()        # below the minimum size
+    assert L.olf_ctx_create(C.byref(p), 640, 480, 0, C.byref(h)) == OLF_ERR_INVALID
+    assert L.olf_ctx_create(None, 640, 480, 1, C.byref(h)) == OLF_ERR_INVALID
+    bad = _lib.default_params(); bad.orb.scale_factor = 1.0
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) != OLF_OK                                 # the pyramid needs a factor > 1
+    bad = _lib.default_params(); bad.line.lsd_scale = 0.3
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) != OLF_OK                                 # LSD blur wider than 7 taps
+    ctx = _lib.Context(p, 640, 480, 2)
+    img = np.zeros((4, 480, 640), np.uint8)
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    kps, desc, cnt = np.zeros((4, cap), _lib.KEYPOINT_DTYPE), np.zeros((4, cap, 32), np.uint8), np.zeros(4, np.int32)
+    assert L.olf_orb_extract(ctx.handle, _p(img), 3, _p(kps), _p(desc), _p(cnt)) == OLF_ERR_CAPACITY          # more images than max_images
+    assert L.olf_orb_extract(ctx.handle, None, 1, _p(kps), _p(desc), _p(cnt)) == OLF_ERR_INVALID
+    assert L.olf_orb_extract(ctx.handle, _p(img), 1, None, _p(desc), _p(cnt)) == OLF_ERR_INVALID
+    assert L.olf_orb_extract(ctx.handle, _p(img), -1, _p(kps), _p(desc), _p(cnt)) != OLF_OK
+    assert L.olf_orb_extract(ctx.handle, _p(img), 0, _p(kps), _p(desc), _p(cnt)) == OLF_OK                    # an empty batch is fine
+    kls, ldesc = np.zeros((4, lcap), _lib.KEYLINE_DTYPE), np.zeros((4, lcap, 32), np.uint8)
+    assert L.olf_line_extract(ctx.handle, _p(img), 5, _p(kls), _p(ldesc), _p(cnt)) == OLF_ERR_CAPACITY
+    assert L.olf_line_extract(ctx.handle, _p(img), 1, None, _p(ldesc), _p(cnt)) == OLF_ERR_INVALID
+    assert L.olf_stereo_points(ctx.handle, _p(img), 2, _p(kps), _p(desc), _p(cnt), None, None) != OLF_OK                  # null outputs
+    d = np.zeros((3, 32), np.uint8); m = np.zeros(3, np.int32)
+    assert L.olf_match_bf(ctx.handle, None, 3, _p(d), 3, C.c_float(0.9), 1, _p(m)) == OLF_ERR_INVALID
+    assert L.olf_match_bf(ctx.handle, _p(d), -2, _p(d), 3, C.c_float(0.9), 1, _p(m)) == OLF_ERR_INVALID
+    assert L.olf_match_bf(ctx.handle, _p(d), 0, _p(d), 3, C.c_float(0.9), 1, _p(m)) == OLF_OK
+    assert L.olf_cvt_gray(ctx.handle, _p(img), 7, 1, _p(img)) == OLF_ERR_INVALID                               # unknown conversion code
+    assert L.olf_distinctive_descriptors(ctx.handle, _p(d), _p(np.array([0, 3, 2], np.int32)), 2, _p(m)) == OLF_ERR_INVALID   # offsets decrease
+    assert L.olf_voc_load_text(b"/nonexistent", C.byref(h)) == OLF_ERR_INVALID
+    assert L.olf_voc_create(10, 0, 0, 0, 1, _p(m), _p(d), _p(d), _p(np.zeros(1)), C.byref(h)) == OLF_ERR_INVALID   # L must be >= 1
+    assert L.olf_last_error() is not None
+    # the context is still usable after all of that
+    k, dd, c = np.zeros((1, cap), _lib.KEYPOINT_DTYPE), np.zeros((1, cap, 32), np.uint8), np.zeros(1, np.int32)
+    assert L.olf_orb_extract(ctx.handle, _p(np.full((1, 480, 640), 50, np.uint8)), 1, _p(k), _p(dd), _p(c)) == OLF_OK and c[0] == 0
