@@ -1,17 +1,18 @@
 // line_internal.hpp -- device layout of the line half of the path (Lineextractor: LSD + LBD) and
 // of the stereo line matcher.  See lsd.hip / lbd.hip / linematch.hip.
 //
-// HBM layout per image (W x H input, Ws x Hs = round(1.2 W) x round(1.2 H) LSD working size):
-//   lsdBlur  : u8  H  x pitchW     GaussianBlur(7x7, sigma 0.6) of the input            (LSD step 1)
-//   scaled   : u8  Hs x pitchS     x1.2 bilinear upsample                               (LSD step 1)
-//   grad     : u32 Hs x Ws         packed (gx, gy) int16 pair; gx = -32768 marks NOTDEF (LSD ll_angle)
-//   keys     : u32 Ps (x2)         ((n_bins-1-bin) << 22 | address) of every defined pixel, sorted ascending
-//   used     : u8  Ps              region-growing `used` map
-//   region   : u32 Ps              FIFO of the region being grown (x | y << 16)
+// HBM layout per image (W x H input, Ws x Hs = round(lsd_scale W) x round(lsd_scale H) LSD working size, Ps = Ws * Hs):
+//   lsdBlur  : u8  H  x pitchW     GaussianBlur(sigma_scale) of the input                  (LSD step 1)
+//   scaled   : u8  Hs x pitchS     bilinear rescale                                        (LSD step 1)
+//   grad     : u32 Ps              gx:11 | gy:11 | ISO (bit 22) | NOTDEF (bit 30) | USED (bit 31)   (LSD ll_angle + region growing state)
+//   keysA/B  : u32 Ps each         ((n_bins-1-bin) << 22 | address) of every defined pixel, raster order / sorted; once consumed, keysA holds
+//                                  the 16-byte records of the logged regions and keysB the 24-byte segment candidates
+//   region   : u32 Ps              level-line angles (degrees) for k_lsd_iso, then the pixel log of the grown regions (x | y << 16)
 //   rawLines : olf_keyline maxDetect  key lines in detection order (after the length filter)
-//   lbdBlur  : u8  H x pitchW      GaussianBlur(5x5, sigma 1)                           (LBD)
-//   dxdy     : u32 H x W           packed Sobel (dx, dy) int16 pair                     (LBD)
-//   rowSums  : float4 nLines x 63  per support-region row: (pgdL, ngdL, pgdO, ngdO)     (LBD)
+//   lbdBlur  : u8  H x pitchW      GaussianBlur(5x5, sigma 1)                              (LBD)
+//   dxdy     : u32 H x W           packed Sobel (dx, dy) int16 pair                        (LBD)
+//   rowSums  : float4 nLines x 63  per support-region row: (pgdL, ngdL, pgdO, ngdO)        (LBD)
+// Per context (image independent): angDeg / cosSin / seedCS, 2^22 entries each (see LineDeviceBufs).
 #pragma once
 #include "olf_internal.hpp"
 

@@ -1,16 +1,17 @@
 // lsd.hip -- cv::LineSegmentDetector (OpenCV 3.4 lsd.cpp, LSD_REFINE_NONE) as called by
 // LSDDetectorC::detectImpl (reference Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:227-324), gfx950.
 //
-// Data-parallel front half (HBM-bound stencils, one pass each): sigma-0.6 blur, x1.2 bilinear upsample,
-// 2x2 gradient.  The reference keeps fp64 modgrad + angle per pixel (16 B); both are pure functions of
-// the integer gradient pair, so we store (gx, gy) as 2 x int16 (4 B/px) and recompute norm / angle on
-// demand with the reference's own expressions (bit-identical, 4x less traffic).
-// Pseudo-ordering: every defined pixel becomes a key ((n_bins-1-bin) << 22 | address); an ascending
-// segmented radix sort (rocPRIM) yields "bins high to low, raster order inside a bin".
-// Region growing is order-dependent by construction (seed order, running region angle, shared `used`
-// map), so one wave per image replays it sequentially; inside the wave the 3x3 neighbourhoods of up to
-// 7 FIFO entries are fetched and their angles / cos / sin evaluated in parallel (63 lanes), and only
-// the accept/reject chain is serial.  Parallelism comes from the batch: thousands of images in flight.
+// Data-parallel front half (one pass each): sigma-0.6 blur, x1.2 bilinear upsample, 2x2 gradient.  The reference keeps fp64 modgrad +
+// angle per pixel (16 B); both are pure functions of the integer gradient pair, so a pixel is one 32-bit word (gx:11 | gy:11 | ISO |
+// NOTDEF | USED) and everything derived from (gx, gy) -- level-line angle, its cos / sin -- comes from per-context tables indexed by
+// the packed pair (k_lsd_angle_table), bit-identical to evaluating the reference's expressions.
+// Pseudo-ordering: every defined pixel becomes a key ((n_bins-1-bin) << 22 | address), emitted in raster order; a stable segmented
+// radix sort (rocPRIM) over the 10 bin bits yields "bins high to low, raster order inside a bin".
+// Region growing is order-dependent by construction (seed order, running region angle, shared `used` map), so one wave per image
+// (k_lsd_grow, "the agent") replays it sequentially: the 3x3 neighbourhoods of up to 7 FIFO entries are examined in parallel lanes and
+// only the accept chain is serial -- run as speculative rounds that need one fastAtan2 per round instead of one per accepted pixel.
+// Regions that are large enough are logged and fitted afterwards, in parallel, by k_lsd_rect / k_lsd_emit (region2rect + KeyLine).
+// Parallelism comes from the batch: thousands of images in flight, up to 8 agents per SIMD.
 #include "line_internal.hpp"
 #include "device_math.hpp"
 #include <rocprim/rocprim.hpp>
