@@ -52,7 +52,6 @@ struct LineDeviceBufs {
     int* chunkCnt = nullptr;       // [n][ceil(Ps / 4096)] defined pixels per gradient chunk (raster-ordered key emission)
     unsigned* segBegin = nullptr;  // [n] segment offsets for the sort
     unsigned* segEnd = nullptr;
-    uint8_t* used = nullptr;
     uint32_t* region = nullptr;
     olf_keyline* rawLines = nullptr;
     int* rawCount = nullptr;

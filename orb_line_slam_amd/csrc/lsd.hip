@@ -37,51 +37,6 @@ __device__ __forceinline__ int refl101(int p, int n)
     return p;
 }
 
-// ---------------------------------------------------------------------------------------------
-// 7-tap separable Gaussian in 8-bit fixed point (App. A.3) on plain images: src [n][H][srcPitch]
-// -> dst [n][H][dstPitch].  which = 0: LSD taps, 1: LBD taps.
-constexpr int GT_W = 64, GT_H = 16;
-__global__ __launch_bounds__(256) void k_gauss7_img(const uint8_t* __restrict__ src, int srcPitch, size_t srcImgStride,
-                                                    uint8_t* __restrict__ dst, int dstPitch, size_t dstImgStride, int W, int H,
-                                                    const LineGeom* __restrict__ gp, int which)
-{
-    __shared__ uint8_t in[(GT_H + 6) * 72];
-    __shared__ uint16_t hrow[(GT_H + 6) * 64];
-    const int img = blockIdx.z;
-    const int x0 = blockIdx.x * GT_W, y0 = blockIdx.y * GT_H;
-    const uint8_t* s = src + (size_t)img * srcImgStride;
-    for (int i = threadIdx.x; i < (GT_H + 6) * (GT_W + 6); i += 256) {
-        const int ty = i / (GT_W + 6), tx = i - ty * (GT_W + 6);
-        const int gx = refl101(min(x0 - 3 + tx, W + 2), W), gy = refl101(min(y0 - 3 + ty, H + 2), H);
-        in[ty * 72 + tx] = s[(size_t)gy * srcPitch + gx];
-    }
-    __syncthreads();
-    int taps[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) taps[k] = which ? gp->lbdTaps[k] : gp->lsdTaps[k];
-    for (int i = threadIdx.x; i < (GT_H + 6) * GT_W; i += 256) {
-        const int ty = i >> 6, tx = i & 63;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += taps[k] * in[ty * 72 + tx + k];
-        hrow[i] = (uint16_t)acc;
-    }
-    __syncthreads();
-    uint8_t* d = dst + (size_t)img * dstImgStride;
-    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ly = ly0 + 4 * r;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= W || gy >= H) continue;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += taps[k] * hrow[(ly + k) * 64 + lx];
-        acc = (acc + 32768) >> 16;
-        d[(size_t)gy * dstPitch + gx] = (uint8_t)min(acc, 255);
-    }
-}
-
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
                       const LineGeom& g, int which, int n_images, hipStream_t s)
 {

@@ -302,48 +302,6 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                               const OrbGeom* __restrict__ gp, int level)
-{
-    __shared__ uint8_t in[(BT_H + 6) * 72];
-    __shared__ uint16_t hrow[(BT_H + 6) * 64];
-    const OrbGeom& g = *gp;
-    const LevelGeom& L = g.lv[level];
-    const int img = blockIdx.z;
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-    const uint8_t* src = pyr + (size_t)img * g.pyrBytes + L.offset;
-    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        const int ty = i / (BT_W + 6), tx = i - ty * (BT_W + 6);
-        const int gx = reflect101(min(x0 - 3 + tx, L.w + 2), L.w), gy = reflect101(min(y0 - 3 + ty, L.h + 2), L.h);
-        in[ty * 72 + tx] = src[(size_t)gy * L.pitch + gx];
-    }
-    __syncthreads();
-    int taps[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) taps[k] = g.blurTaps[k];
-    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
-        const int ty = i >> 6, tx = i & 63;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += taps[k] * in[ty * 72 + tx + k];
-        hrow[i] = (uint16_t)acc;
-    }
-    __syncthreads();
-    uint8_t* dst = blur + (size_t)img * g.pyrBytes + L.offset;
-    const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ly = ly0 + 4 * r;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= L.w || gy >= L.h) continue;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) acc += taps[k] * hrow[(ly + k) * 64 + lx];
-        acc = (acc + 32768) >> 16;
-        dst[(size_t)gy * L.pitch + gx] = (uint8_t)min(acc, 255);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* d_in, int n_images, hipStream_t s)
 {
