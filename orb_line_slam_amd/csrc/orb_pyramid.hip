@@ -291,18 +291,6 @@ __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ g
 }
 
 // ---------------------------------------------------------------------------------------------
-// GaussianBlur(7x7, sigma=2, BORDER_REFLECT_101) in 8-bit fixed point (App. A.3): row pass exact
-// (fits u16: 257*255), column pass (sum + 2^15) >> 16 saturated.
-constexpr int BT_W = 64, BT_H = 16;
-
-__device__ __forceinline__ int reflect101(int p, int n)
-{
-    if (p < 0) p = -p;
-    if (p >= n) p = 2 * (n - 1) - p;
-    return p;
-}
-
-// ---------------------------------------------------------------------------------------------
 int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* d_in, int n_images, hipStream_t s)
 {
     {
