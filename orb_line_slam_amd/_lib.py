@@ -63,6 +63,21 @@ class OlfError(RuntimeError):
 _lib = None
 
 
+def _torch_runtime_first():
+    """PyTorch ships its own copy of the HIP runtime.  A process that uses both this library and torch (bench.py, pipeline.py,
+    distributed.py) must bring torch's runtime up first: the other order leaves this library without a visible device.  So when torch
+    is installed it is imported and initialised before the library is loaded (set OLF_NO_TORCH=1 to skip: pure ctypes use)."""
+    import importlib.util
+    if os.environ.get("OLF_NO_TORCH") or importlib.util.find_spec("torch") is None:
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def lib():
     """The loaded C-ABI library; raises if it has not been built."""
     global _lib
@@ -70,6 +85,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_line_slam_amd/csrc` "
                               "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        _torch_runtime_first()
         L = C.CDLL(LIB_PATH)
         L.olf_last_error.restype = C.c_char_p
         L.olf_ctx_create.argtypes = [C.POINTER(OlfParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]

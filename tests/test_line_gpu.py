@@ -185,3 +185,22 @@ def test_context_reuse_across_batches(oracle):
                 assert ga[k].tobytes() == gb[k].tobytes(), (seed, i, k)
     o = oracle.stereo_points(imgs[0], imgs[1], p)
     assert np.array_equal(a.pair(0)["mvKeys"], o["kpsL"])
+
+
+def test_offline_pipeline_equals_frames(oracle):
+    """the double-buffered host pipeline (H2D / path / D2H on three streams) returns exactly what StereoFrontEnd.frames returns"""
+    from orb_line_slam_amd.pipeline import OfflinePipeline
+    w, h = 640, 480
+    p = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    pipe = OfflinePipeline(p, w, h, pairs_per_batch=3)
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=3)
+    batches = [synth.stereo_batch(100 + i, 3 if i != 3 else 1, w, h) for i in range(6)]
+    got = 0
+    for i, f in enumerate(pipe.run(batches)):
+        ref = fe.frames(batches[i])
+        for j in range(batches[i].shape[0] // 2):
+            a, b = f.pair(j), ref.pair(j)
+            for k in a:
+                assert np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes(), (i, j, k)
+        got += 1
+    assert got == len(batches)
