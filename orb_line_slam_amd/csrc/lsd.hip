@@ -424,22 +424,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     int nreg = 0, rbase = 0;
 #ifdef OLF_STATS
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
+    long long st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
+#endif
+#ifdef OLF_TIMING2
+    long long p_ring = 0, p_gather = 0, p_table = 0, p_chain = 0, p_commit = 0, p_n = 0, ps;
+#define PSTAMP(acc) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long _t = __builtin_readcyclecounter(); acc += _t - ps; ps = _t; } while (0)
+#else
+#define PSTAMP(acc)
 #endif
 #ifdef OLF_TIMING
     long long t_seed = 0, t_small = 0, t_big = 0, t_rect = 0, n_small = 0, n_big = 0, it_small = 0, it_big = 0; long long t0 = __builtin_readcyclecounter();
 #endif
 
-#define PEND_FLUSH() do { __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
+#ifdef OLF_STATS
+#define ST_FLUSH ++st_flush;
+#else
+#define ST_FLUSH
+#endif
+#define PEND_FLUSH() do { ST_FLUSH __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
 #define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
                              if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __builtin_amdgcn_wave_barrier(); } while (0)
 
+    // The seed windows are a chain of dependent loads (key -> gradient word -> table entries); the key of the next window is fetched one
+    // window ahead and the table entries of every growable seed of a window at its start, so a region start waits for neither.
+    uint32_t keyNext = lane < nkeys ? keys[lane] : 0u;
     for (int base = 0; base < nkeys; base += 64) {
         const bool valid = base + lane < nkeys;
-        const int addr = valid ? (int)(keys[base + lane] & 0x3fffffu) : 0;
+        const int addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
+        keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
         const uint32_t wseed = valid ? grad[addr] : kUsed;
         const bool isoSeed = (wseed & kIso) != 0;
         unsigned long long mask = __ballot(valid && !(wseed & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+        // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
+        // are per-(gx, gy) table entries
+        float seedDeg = 0.f;
+        float2 seedSum = make_float2(0.f, 0.f);
+        if (((mask >> lane) & 1ull) && !isoSeed) { seedDeg = angDeg[wseed & 0x3fffffu]; seedSum = seedCS[wseed & 0x3fffffu]; }
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
             {
@@ -460,13 +481,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             const int l = __builtin_ctzll(mask);
             const int seed = rlane(addr, l);
             // ---- region_grow ------------------------------------------------------------------
+#ifdef OLF_STATS
+            ++st_regions;
+#endif
             int n = 1;
-            const uint32_t pseed = grad[seed];
-            // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
-            // are per-(gx, gy) table entries, so the chain below carries no initialisation branch and a region start costs two loads
-            double reg_angle = d_mul((double)angDeg[pseed & 0x3fffffu], kDegToRads);
-            const float2 scs = seedCS[pseed & 0x3fffffu];
-            float sumdx = scs.x, sumdy = scs.y;
+            // the seed's word as loaded with the window: only its USED bit can have changed since, and the mask says it has not
+            const uint32_t pseed = (uint32_t)rlane((int)wseed, l);
+            double reg_angle = d_mul((double)__int_as_float(rlane(__float_as_int(seedDeg), l)), kDegToRads);
+            float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
             __builtin_amdgcn_wave_barrier();
@@ -481,18 +503,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
                 const int nb = min(7, n - i);
                 const int e = lane / 9, k = lane - 9 * e;
+#ifdef OLF_STATS
+                ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2;
+#endif
                 if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
                 // one predicate, no nested regions: every lane forms an address (0 when it has nothing to look at) and loads; only the
                 // table lookups, which cost real cache traffic, are skipped for non-candidates
+#ifdef OLF_TIMING2
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
+#endif
                 bool cand = lane < 63 && e < nb && k != 4;
                 const uint32_t rp = (n - i > RING) ? reg[rbase + i + (cand ? e : 0)] : s_ring[(i + e) & (RING - 1)];
                 const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                 cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
                 const int a = cand ? yy * Ws + xx : 0;
+                PSTAMP(p_ring);
                 const uint32_t pw = grad[a];
                 const int xy = xx | (yy << 16);
                 cand = cand && !(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a;
                 double ang = 0, cs = 0, sn = 0;
+                PSTAMP(p_gather);
                 if (cand) {
                     const uint32_t ti = pw & 0x3fffffu;
                     ang = d_mul((double)angDeg[ti], kDegToRads);
@@ -502,8 +532,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
                 // that same angle, as in the reference), the angle is updated and the rest is re-tested.
+                PSTAMP(p_table);
                 unsigned long long cm = __ballot(cand);
                 unsigned long long acc = 0;
+#ifdef OLF_STATS
+                st_cand += __popcll(cm);
+#endif
                 const int n0 = n;
                 while (cm) {
                     // isaligned(): n = |theta - a|; if (n > 3pi/2) n = |n - 2pi|; n <= prec.  For n in (3pi/2, 2pi + prec] the subtraction is exact
@@ -573,6 +607,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     sumdy = __int_as_float(rlane(__float_as_int(psy), t - 1));
                     reg_angle = rlane_d(th, t - 1);
                 }
+                PSTAMP(p_chain);
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
                     const bool mine = (acc >> lane) & 1ull;
@@ -591,6 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 }
                 i += nb;
                 __builtin_amdgcn_wave_barrier();
+                PSTAMP(p_commit);
             }
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; it_big += iters; } else { t_small += t1 - t0; ++n_small; it_small += iters; } t0 = t1; }
@@ -620,8 +656,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_TIMING
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = t_seed; o[1] = t_small; o[2] = t_big; o[3] = t_rect; o[4] = n_small; o[5] = n_big; o[6] = it_small; o[7] = it_big; }
 #endif
+#ifdef OLF_TIMING2
+    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = p_ring; o[1] = p_gather; o[2] = p_table; o[3] = p_chain; o[4] = p_commit; o[5] = p_n; }
+#endif
 #ifdef OLF_STATS
-    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big; }
+    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big;
+        o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; }
 #endif
     if (lane == 0) regCount[img] = nreg;
 }

@@ -9,5 +9,5 @@ ex = ola.Lineextractor(500, 0.025, max_images=n)
 k, d, c = ex.extract_batch(imgs)
 out = np.zeros(64, np.int32)
 _lib.lib().olf_debug_status(ex._ctx.handle, out.ctypes.data_as(C.c_void_p))
-t = out[16:32].view(np.int64)
-print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big"], t.tolist())))
+t = out[16:44].view(np.int64)
+print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions"], t.tolist())))
