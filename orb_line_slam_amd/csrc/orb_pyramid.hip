@@ -15,17 +15,24 @@ namespace olf {
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ in, uint8_t* __restrict__ pyr,
                                                 int W, int H, int in_pitch, int pitch0, int pyrBytes)
 {
+    // 16 pixels per thread: one (possibly unaligned) 16-byte load, one aligned 16-byte store; the level pitch is a multiple of 64, so the
+    // store may run past W into the row padding, the load may not run past the caller's row
     const int img = blockIdx.y;
-    const int quads = (W + 3) >> 2;
+    const int segs = (W + 15) >> 4;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= quads * H) return;
-    const int y = idx / quads, x = (idx - y * quads) * 4;
+    if (idx >= segs * H) return;
+    const int y = idx / segs, x = (idx - y * segs) * 16;
     const uint8_t* src = in + (size_t)img * H * in_pitch + (size_t)y * in_pitch + x;
-    uint32_t v = 0;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (x + 16 <= W) __builtin_memcpy(&v, src, 16);
+    else {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (x + k < W) v |= (uint32_t)src[k] << (8 * k);
-    *reinterpret_cast<uint32_t*>(pyr + (size_t)img * pyrBytes + (size_t)y * pitch0 + x) = v;
+        for (int k = 0; k < 16; ++k)
+            if (x + k < W) w[k >> 2] |= (uint32_t)src[k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(pyr + (size_t)img * pyrBytes + (size_t)y * pitch0 + x) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ g
 int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* d_in, int n_images, hipStream_t s)
 {
     {
-        const int quads = ((g.W + 3) >> 2) * g.H;
+        const int quads = ((g.W + 15) >> 4) * g.H;
         hipLaunchKernelGGL(k_ingest, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, d_in, b.pyr, g.W, g.H, g.in_pitch,
                            g.lv[0].pitch, g.pyrBytes);
     }
