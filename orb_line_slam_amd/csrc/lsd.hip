@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     int nreg = 0, rbase = 0;
 #ifdef OLF_STATS
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
-    long long st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
+    long long st_mem = 0, st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
 #endif
 #ifdef OLF_TIMING2
     long long p_ring = 0, p_gather = 0, p_table = 0, p_chain = 0, p_commit = 0, p_n = 0, ps;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const int nb = min(7, n - i);
                 const int e = lane / 9, k = lane - 9 * e;
 #ifdef OLF_STATS
-                ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2;
+                ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2; if (n - i > RING) ++st_mem;
 #endif
                 if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
                 // one predicate, no nested regions: every lane forms an address (0 when it has nothing to look at) and loads; only the
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
 #ifdef OLF_STATS
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big;
-        o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; }
+        o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem; }
 #endif
     if (lane == 0) regCount[img] = nreg;
 }

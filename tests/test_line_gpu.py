@@ -118,6 +118,67 @@ def test_line_edge_cases(oracle):
     assert np.array_equal(d, o["desc"])
 
 
+def _pattern(name, w, h):
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    if name == "tri_x":        # triangle wave, slope 10 grey levels / pixel: 24-pixel wide bands of one gradient direction over the full height
+        t = np.abs((x % 48) - 24) * 10
+    elif name == "tri_diag":
+        t = np.abs(((x + y) % 96) - 48) * 5
+    elif name == "rings":      # curved level lines: the region angle drifts while a region grows
+        r = np.hypot(x - w / 2, y - h / 2)
+        t = np.abs((r % 64) - 32) * 7.5
+    elif name == "checker":    # equal responses everywhere: ties in every selection
+        t = (((x // 16) + (y // 16)) % 2) * 255
+    elif name == "soft_edges": # wide smooth ramps between plateaus
+        t = 127.5 + 127.5 * np.tanh((np.abs((x % 160) - 80) - 40) / 6.0)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["tri_x", "tri_diag", "rings", "checker", "soft_edges"])
+def test_line_extract_structured_images(oracle, name):
+    """regions of thousands of pixels (the growth FIFO leaves its LDS window and is read back from memory), drifting region angles,
+    massive ties -- content the random synthetic scenes do not produce"""
+    w, h = 640, 360
+    img = _pattern(name, w, h)
+    p = oracle.full_params(1000, 300)
+    ex = ola.Lineextractor(300, 0.025)
+    k, d = ex(img)
+    o = oracle.line_extract(img, p.line)
+    _cmp_keylines(k, o["kls"])
+    assert np.array_equal(d, o["desc"])
+    if name != "checker":
+        assert len(k) > 0
+    # and through the fused stereo entry (ORB side and both stereo matchers included), the pattern shifted by 5 px as the right image
+    pq = oracle.full_params(1000, 300, 400.0, 40.0)
+    fe = ola.StereoFrontEnd(pq, w, h, max_pairs=1)
+    pair = np.stack([img, np.roll(img, -5, axis=1)])
+    g = fe.frames(pair).pair(0)
+    op = oracle.stereo_points(pair[0], pair[1], pq)
+    assert np.array_equal(g["mvKeys"], op["kpsL"]) and np.array_equal(g["mDescriptors"], op["descL"])
+    assert np.array_equal(g["mvKeysRight"], op["kpsR"]) and np.array_equal(g["mDescriptorsRight"], op["descR"])
+    assert np.array_equal(g["mvuRight"].view(np.uint32), op["uRight"].view(np.uint32))
+    ol, orr = oracle.line_extract(pair[0], pq.line), oracle.line_extract(pair[1], pq.line)
+    _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+    _cmp_keylines(g["mvKeysRight_Line"], orr["kls"])
+    m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, pq.stereo)
+    assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+
+
+def test_line_extract_wide_growth_front(oracle):
+    """a shallow ramp under a low gradient threshold, LSD working at twice the input size: one direction over 170-pixel wide bands, so the growth front holds several hundred
+    pending pixels and the FIFO window leaves the agent's 256-entry LDS ring (entries are then read back from the region log in memory)"""
+    w, h = 680, 300
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.clip(np.abs((x % 170) - 85) * 3, 0, 255).astype(np.uint8)
+    p = oracle.full_params(500, 100)
+    p.line.lsd_quant, p.line.lsd_scale = 0.3, 2.0
+    ex = ola.Lineextractor(100, 0.025, lsd_quant=0.3, lsd_scale=2.0)
+    k, d = ex(img)
+    o = oracle.line_extract(img, p.line)
+    _cmp_keylines(k, o["kls"])
+    assert np.array_equal(d, o["desc"]) and len(k) > 0
+
+
 @pytest.mark.parametrize("w,h", [(333, 257), (1000, 300), (401, 243), (897, 601)])
 def test_stereo_frames_odd_sizes(oracle, w, h):
     """sizes that are multiples of nothing: tile edges, pitch padding, level geometry, cell grids with one column, tiny top levels"""

@@ -5,9 +5,17 @@ from orb_line_slam_amd import synth, _lib
 n = 64
 imgs = synth.stereo_batch(7000, 16, 1242, 375)
 imgs = np.tile(imgs, (n // 32 + 1, 1, 1))[:n].copy()
-ex = ola.Lineextractor(500, 0.025, max_images=n)
+if len(sys.argv) > 1 and sys.argv[1] == "tri":      # 40-pixel bands of one gradient direction: regions of thousands of pixels
+    y, x = np.mgrid[0:375, 0:1242]
+    imgs[:] = np.clip(np.abs((x % 48) - 24) * 10, 0, 255).astype(np.uint8)
+kw = {}
+if len(sys.argv) > 1 and sys.argv[1] == "wide":     # 1.5 grey levels / pixel with a low gradient threshold: a growth front of several hundred pixels
+    y, x = np.mgrid[0:375, 0:1242]
+    imgs[:] = np.clip(np.abs((x % 170) - 85) * 3, 0, 255).astype(np.uint8)
+    kw = dict(lsd_quant=0.3, lsd_scale=2.0)
+ex = ola.Lineextractor(500, 0.025, max_images=n, **kw)
 k, d, c = ex.extract_batch(imgs)
 out = np.zeros(64, np.int32)
 _lib.lib().olf_debug_status(ex._ctx.handle, out.ctypes.data_as(C.c_void_p))
-t = out[16:44].view(np.int64)
-print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions"], t.tolist())))
+t = out[16:46].view(np.int64)
+print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions", "iters_fifo_from_memory"], t.tolist())))
