@@ -7,6 +7,8 @@
 //   ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1620-1747 (+ MapPoint::PredictScale, src/MapPoint.cc:414-429)
 //   ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo)   src/ORBmatcher.cc:659-825 (+ CheckDistEpipolarLine :142-161)
 //   ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th), the search part             src/ORBmatcher.cc:827-975
+//   ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint), the search part   src/ORBmatcher.cc:977-1102
+//   ORBmatcher::SearchBySim3(KF1, KF2, vpMatches12, s12, R12, t12, th)               src/ORBmatcher.cc:1104-1328
 //   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:47-131 (+ RadiusByViewingCos :133-139)
 //   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
 //   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
@@ -466,6 +468,149 @@ extern "C" void orc_fuse_search(const olf_keypoint* keys, const uint8_t* desc, c
         }
         bestIdxOut[i] = bestIdx; bestDistOut[i] = bestDist;
     }
+}
+
+// ---- Sim3 searches of the loop closer -------------------------------------------------------------------------------------------
+// cv::Mat scalar algebra used below (CV_32F): `M / s` and `s * M` are MatExpr scalings evaluated by convertTo, i.e. every element times
+// the double factor rounded to float ((float)(1.0 / s), (float)s); Mat::dot accumulates float products in double; `-A*b` is a gemm with
+// alpha = -1 (double accumulation, one rounding, as everywhere in this file).
+static void r3_mul_add(const float* R9, const float* v, const float* t3, float out[3], double alpha = 1.0)
+{
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * v[k];
+        out[r] = (float)(alpha * acc + (t3 ? (double)t3[r] : 0.0));
+    }
+}
+
+// src/ORBmatcher.cc:985-989: Scw -> Rcw, tcw, Ow
+extern "C" void orc_sim3_decompose(const float* Scw /*4x4 row-major*/, float* Rcw9, float* tcw3, float* Ow3)
+{
+    double d = 0;
+    for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) Rcw9[3 * r + k] = Scw[4 * r + k] * inv;
+        tcw3[r] = Scw[4 * r + 3] * inv;
+    }
+    float Rt[9];
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Rt[3 * r + k] = Rcw9[3 * k + r];
+    r3_mul_add(Rt, tcw3, nullptr, Ow3, -1.0);
+}
+
+static int predict_scale(float maxd, float dist, float logScaleFactor, int nLevels)     // MapPoint::PredictScale, src/MapPoint.cc:414-429
+{
+    const float ratio = maxd / dist;
+    int n = (int)std::ceil(std::log(ratio) / logScaleFactor);
+    if (n < 0) n = 0; else if (n >= nLevels) n = nLevels - 1;
+    return n;
+}
+
+// best key point of a key frame for a map point projected at (u, v): octave in [level-1, level], smallest Hamming distance, first wins
+static void best_in_area(const GridFrame& G, const uint8_t* desc, float u, float v, float radius, int level, const uint8_t* dMP, int& bestIdx, int& bestDist)
+{
+    bestIdx = -1; bestDist = INT_MAX;
+    for (size_t idx : G.area(u, v, radius)) {
+        const int kpLevel = G.keys[idx].octave;
+        if (kpLevel < level - 1 || kpLevel > level) continue;
+        const int dist = hamming256(dMP, desc + 32 * idx);
+        if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+}
+
+// The search part of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint): per point (bestIdx, bestDist) or (-1, INT_MAX) when a gate rejects it.
+// mp_skip = isBad() || spAlreadyFound.count(pMP).  What follows in the reference (:1086-1099) only reads (bestIdx, bestDist <= TH_LOW).
+extern "C" void orc_fuse_search_sim3(const olf_keypoint* keys, const uint8_t* desc, int N, const float* Scw, const float* cam9, const float* scaleFactors,
+                          int nLevels, float logScaleFactor, int nMP, const uint8_t* mp_skip, const float* mp_world, const float* mp_normal,
+                          const float* mp_maxd, const float* mp_mind, const uint8_t* mp_desc, float th, int* bestIdxOut, int* bestDistOut)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = keys; G.N = N; G.c = c; G.build();
+    float Rcw[9], tcw[3], Ow[3];
+    orc_sim3_decompose(Scw, Rcw, tcw, Ow);
+    for (int i = 0; i < nMP; i++) {
+        bestIdxOut[i] = -1; bestDistOut[i] = INT_MAX;
+        if (mp_skip[i]) continue;
+        const float* p3Dw = mp_world + 3 * i;
+        float p3Dc[3];
+        r3_mul_add(Rcw, p3Dw, tcw, p3Dc);
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = (float)(1.0 / p3Dc[2]);
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+        if (!(u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY)) continue;
+        const float maxDistance = 1.2f * mp_maxd[i], minDistance = 0.8f * mp_mind[i];
+        float PO[3]; double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { PO[k] = p3Dw[k] - Ow[k]; nrm += (double)PO[k] * (double)PO[k]; dot += (double)PO[k] * (double)mp_normal[3 * i + k]; }
+        const float dist3D = (float)std::sqrt(nrm);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        if (dot < 0.5 * dist3D) continue;
+        const int nPredictedLevel = predict_scale(mp_maxd[i], dist3D, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        best_in_area(G, desc, u, v, radius, nPredictedLevel, mp_desc + 32 * (size_t)i, bestIdxOut[i], bestDistOut[i]);
+    }
+}
+
+// SearchBySim3.  Per key frame: keys / desc / n, Tcw (4x4), and for every feature its map point (valid, bad, world, maxd, mind, descriptor);
+// already1 / already2 = vbAlreadyMatched1 / 2 (:1139-1151, derived by the caller from vpMatches12).  Outputs vnMatch1 / vnMatch2 (:1153-1154) and
+// matches12[i1] = idx2 where the two directions agree (:1312-1325; the caller stores vpMapPoints2[idx2]).  Returns nFound.
+extern "C" int orc_search_by_sim3(const olf_keypoint* keys1, const uint8_t* desc1, int n1, const float* T1w, const uint8_t* mp1_valid, const uint8_t* mp1_bad,
+                       const float* mp1_world, const float* mp1_maxd, const float* mp1_mind, const uint8_t* mp1_desc, const uint8_t* already1,
+                       const olf_keypoint* keys2, const uint8_t* desc2, int n2, const float* T2w, const uint8_t* mp2_valid, const uint8_t* mp2_bad,
+                       const float* mp2_world, const float* mp2_maxd, const float* mp2_mind, const uint8_t* mp2_desc, const uint8_t* already2,
+                       const float* cam9, const float* scaleFactors, int nLevels, float logScaleFactor, float s12, const float* R12, const float* t12,
+                       float th, int* vnMatch1, int* vnMatch2, int* matches12)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G1; G1.keys = keys1; G1.N = n1; G1.c = c; G1.build();
+    GridFrame G2; G2.keys = keys2; G2.N = n2; G2.c = c; G2.build();
+    float sR12[9], sR21[9], t21[3];
+    const float inv = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { sR12[3 * r + k] = s12 * R12[3 * r + k]; sR21[3 * r + k] = inv * R12[3 * k + r]; }
+    r3_mul_add(sR21, t12, nullptr, t21, -1.0);
+    for (int i = 0; i < n1; ++i) { vnMatch1[i] = -1; matches12[i] = -1; }
+    for (int i = 0; i < n2; ++i) vnMatch2[i] = -1;
+    for (int dir = 0; dir < 2; ++dir) {
+        // dir 0: points of KF1 into KF2 (:1157-1232); dir 1: points of KF2 into KF1 (:1235-1309)
+        const int n = dir ? n2 : n1;
+        const uint8_t *valid = dir ? mp2_valid : mp1_valid, *bad = dir ? mp2_bad : mp1_bad, *already = dir ? already2 : already1;
+        const float *world = dir ? mp2_world : mp1_world, *maxd = dir ? mp2_maxd : mp1_maxd, *mind = dir ? mp2_mind : mp1_mind;
+        const uint8_t* dMPs = dir ? mp2_desc : mp1_desc;
+        const float* Tsrc = dir ? T2w : T1w;
+        const float *sR = dir ? sR12 : sR21, *t = dir ? t12 : t21;
+        const GridFrame& G = dir ? G1 : G2;
+        const uint8_t* descT = dir ? desc1 : desc2;
+        int* out = dir ? vnMatch2 : vnMatch1;
+        for (int i = 0; i < n; ++i) {
+            if (!valid[i] || already[i]) continue;
+            if (bad[i]) continue;
+            float pa[3], pb[3];
+            mat3_mul_add(Tsrc, world + 3 * i, pa);
+            r3_mul_add(sR, pa, t, pb);
+            if (pb[2] < 0.0) continue;
+            const float invz = (float)(1.0 / pb[2]);
+            const float x = pb[0] * invz, y = pb[1] * invz;
+            const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+            if (!(u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY)) continue;
+            const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+            double nrm = 0;
+            for (int k = 0; k < 3; ++k) nrm += (double)pb[k] * (double)pb[k];
+            const float dist3D = (float)std::sqrt(nrm);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = predict_scale(maxd[i], dist3D, logScaleFactor, nLevels);
+            const float radius = th * scaleFactors[nPredictedLevel];
+            int bestIdx, bestDist;
+            best_in_area(G, descT, u, v, radius, nPredictedLevel, dMPs + 32 * (size_t)i, bestIdx, bestDist);
+            if (bestDist <= TH_HIGH) out[i] = bestIdx;
+        }
+    }
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    return nFound;
 }
 
 // SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (loop closing): matches12[idx1] = idx2 (the feature of KF2 whose map point is taken)

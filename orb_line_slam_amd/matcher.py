@@ -748,7 +748,154 @@ def _fuse_search(self, pKF, vpMapPoints, th=3.0, Ow=None):
     return bestIdx, bestDist
 
 
+def _scale(m, s):
+    """cv::Mat (CV_32F) times a scalar: MatExpr scaling, every element times the double factor rounded to float"""
+    return (np.asarray(m, np.float32) * np.float32(s)).astype(np.float32)
+
+
+def _gemv(R, v, t=None, alpha=1.0):
+    """alpha * R * v (+ t) on CV_32F operands: double accumulation, one rounding (cv::gemm)"""
+    acc = alpha * (np.asarray(R, np.float64) @ np.asarray(v, np.float64))
+    if t is not None:
+        acc = acc + np.asarray(t, np.float64)
+    return acc.astype(np.float32)
+
+
+def Sim3Decompose(Scw):
+    """Scw -> (Rcw, tcw, Ow) as at the top of ORBmatcher::Fuse(pKF, Scw, ...), src/ORBmatcher.cc:985-989"""
+    Scw = np.asarray(Scw, np.float32)
+    sRcw = Scw[:3, :3]
+    scw = np.float32(np.sqrt(np.sum(sRcw[0].astype(np.float64) ** 2)))
+    inv = np.float32(1.0 / np.float64(scw))
+    Rcw, tcw = _scale(sRcw, inv), _scale(Scw[:3, 3], inv)
+    return Rcw, tcw, _gemv(Rcw.T, tcw, alpha=-1.0)
+
+
+def _predict_scale(maxd, dist3D, logScale, nLevels):
+    """MapPoint::PredictScale, src/MapPoint.cc:414-429"""
+    lvl = int(np.ceil(np.float32(_logf(np.float32(maxd / dist3D)) / logScale)))
+    return 0 if lvl < 0 else min(lvl, nLevels - 1)
+
+
+def _project_in_image(KF, p3Dc):
+    """pinhole projection + KeyFrame::IsInImage; (u, v) or None"""
+    f32 = np.float32
+    if p3Dc[2] < 0.0:
+        return None
+    invz = f32(1.0 / np.float64(p3Dc[2])) if p3Dc[2] != 0 else f32(np.inf)
+    x, y = f32(p3Dc[0] * invz), f32(p3Dc[1] * invz)
+    u, v = f32(f32(KF.fx * x) + KF.cx), f32(f32(KF.fy * y) + KF.cy)
+    if not (u >= KF.mnMinX and u < KF.mnMaxX and v >= KF.mnMinY and v < KF.mnMaxY):
+        return None
+    return u, v
+
+
+def _best_in_lists(KF, queries, lists, levels, dists, n, empty):
+    """per query the candidate with octave in [level - 1, level] and the smallest distance (first wins)"""
+    bestIdx, bestDist = np.full(n, -1, np.int32), np.full(n, empty, np.int64)
+    ko = KF.mvKeysUn["octave"]
+    for qi, i in enumerate(queries):
+        bd, bi = empty, -1
+        for idx, dist in zip(lists[qi], dists[qi]):
+            if ko[idx] < levels[qi] - 1 or ko[idx] > levels[qi]:
+                continue
+            if int(dist) < bd:
+                bd, bi = int(dist), idx
+        bestIdx[i], bestDist[i] = bi, bd
+    return bestIdx, bestDist
+
+
+INT_MAX = 2147483647
+
+
+def _fuse_search_sim3(self, pKF, Scw, vpPoints, th):
+    """The search part of int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th,
+    vector<MapPoint*> &vpReplacePoint), src/ORBmatcher.cc:977-1102 (loop correction): per point the most similar key point of pKF inside the
+    projection window under the Sim3 pose, (bestIdx, bestDist), (-1, INT_MAX) where a gate rejects the point.  vpPoints.skip =
+    isBad() || spAlreadyFound.count(pMP).  The reference then records a replacement / adds the observation when bestDist <= TH_LOW
+    (:1086-1099, host code on the map)."""
+    f32 = np.float32
+    mp = vpPoints
+    Rcw, tcw, Ow = Sim3Decompose(Scw)
+    nLevels = len(pKF.mvScaleFactors)
+    logScale = _logf(pKF.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
+    queries, lists, levels = [], [], []
+    for i in range(mp.n):
+        if mp.skip[i]:
+            continue
+        p3Dw = mp.world[i]
+        uv = _project_in_image(pKF, _gemv(Rcw, p3Dw, tcw))
+        if uv is None:
+            continue
+        maxDistance, minDistance = f32(f32(1.2) * mp.maxd[i]), f32(f32(0.8) * mp.mind[i])
+        PO = (p3Dw - Ow).astype(f32)
+        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
+        if dist3D < minDistance or dist3D > maxDistance:
+            continue
+        if float(np.sum(PO.astype(np.float64) * mp.normal[i].astype(np.float64))) < 0.5 * float(dist3D):
+            continue
+        lvl = _predict_scale(mp.maxd[i], dist3D, logScale, nLevels)
+        idx = pKF.GetFeaturesInArea(uv[0], uv[1], f32(f32(th) * pKF.mvScaleFactors[lvl]))
+        if not idx:
+            continue
+        queries.append(i); lists.append(idx); levels.append(lvl)
+    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF.mDescriptors, self._context)
+    return _best_in_lists(pKF, queries, lists, levels, dists, mp.n, INT_MAX)
+
+
+def _search_by_sim3(self, pKF1, pKF2, vpMatches12, s12, R12, t12, th):
+    """int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+    const cv::Mat &t12, const float th), src/ORBmatcher.cc:1104-1328.  pKF1 / pKF2: KeyFrameView (mp_valid, mp_bad, mp_world, mp_desc, mp_maxd,
+    mp_mind, mTcw).  vpMatches12: int array over pKF1's features, the index in pKF2 of the feature whose map point is already matched
+    (pMP->GetIndexInKeyFrame(pKF2)), -1 for none, or -2 for "matched to a map point that pKF2 does not observe"; updated in place like the
+    reference's vector.  Returns (nFound, vnMatch1, vnMatch2)."""
+    f32 = np.float32
+    N1, N2 = pKF1.N, pKF2.N
+    m12 = np.asarray(vpMatches12)
+    already1 = m12 != -1
+    already2 = np.zeros(N2, bool)
+    already2[m12[(m12 >= 0) & (m12 < N2)]] = True
+    sR12 = _scale(R12, f32(s12))
+    sR21 = _scale(np.asarray(R12, f32).T, f32(1.0 / np.float64(f32(s12))))
+    t21 = _gemv(sR21, t12, alpha=-1.0)
+    nLevels = len(pKF1.mvScaleFactors)
+    logScale = _logf(pKF1.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
+    vn = []
+    for src, dst, already, sR, t in ((pKF1, pKF2, already1, sR21, t21), (pKF2, pKF1, already2, sR12, np.asarray(t12, f32).reshape(3))):
+        Rw, tw = src.mTcw[:3, :3], src.mTcw[:3, 3]
+        queries, lists, levels = [], [], []
+        for i in range(src.N):
+            if not src.mp_valid[i] or already[i] or src.mp_bad[i]:
+                continue
+            pb = _gemv(sR, _gemv(Rw, src.mp_world[i], tw), t)
+            uv = _project_in_image(dst, pb)
+            if uv is None:
+                continue
+            maxDistance, minDistance = f32(f32(1.2) * src.mp_maxd[i]), f32(f32(0.8) * src.mp_mind[i])
+            dist3D = f32(np.sqrt(np.sum(pb.astype(np.float64) ** 2)))
+            if dist3D < minDistance or dist3D > maxDistance:
+                continue
+            lvl = _predict_scale(src.mp_maxd[i], dist3D, logScale, nLevels)
+            idx = dst.GetFeaturesInArea(uv[0], uv[1], f32(f32(th) * dst.mvScaleFactors[lvl]))
+            if not idx:
+                continue
+            queries.append(i); lists.append(idx); levels.append(lvl)
+        dists = _candidate_distances(src.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, dst.mDescriptors, self._context)
+        bi, bd = _best_in_lists(dst, queries, lists, levels, dists, src.N, INT_MAX)
+        vn.append(np.where(bd <= self.TH_HIGH, bi, -1).astype(np.int32))
+    vnMatch1, vnMatch2 = vn
+    nFound = 0
+    for i1 in range(N1):
+        idx2 = vnMatch1[i1]
+        if idx2 >= 0 and vnMatch2[idx2] == i1:
+            vpMatches12[i1] = idx2
+            nFound += 1
+    return nFound, vnMatch1, vnMatch2
+
+
 ORBmatcher.SearchForTriangulation = _search_for_triangulation
+ORBmatcher.FuseSearchSim3 = _fuse_search_sim3
+ORBmatcher.SearchBySim3 = _search_by_sim3
 ORBmatcher.FuseSearch = _fuse_search
 
 

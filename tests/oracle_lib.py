@@ -418,3 +418,54 @@ def fuse_search(kf, mp, th, Ow):
                        C.c_float(libm.logf(float(sf[1]))), mp.n, _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]), _p(arrs[10]),
                        C.c_float(th), _p(bi), _p(bd))
     return bi, bd
+
+
+def sim3_decompose(Scw):
+    R, t, O = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    S = np.ascontiguousarray(Scw, np.float32)
+    _L.orc_sim3_decompose(_p(S), _p(R), _p(t), _p(O))
+    return R.reshape(3, 3), t, O
+
+
+def _logsf(sf):
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.logf.restype = ctypes.c_float; libm.logf.argtypes = [ctypes.c_float]
+    return C.c_float(libm.logf(float(sf[1])))
+
+
+def _cam(kf):
+    return np.array([kf.fx, kf.fy, kf.cx, kf.cy, kf.mbf, kf.mnMinX, kf.mnMaxX, kf.mnMinY, kf.mnMaxY], np.float32)
+
+
+def fuse_search_sim3(kf, Scw, mp, th):
+    a = np.ascontiguousarray
+    cam, sf = _cam(kf), a(kf.mvScaleFactors)
+    bi, bd = np.zeros(mp.n, np.int32), np.zeros(mp.n, np.int32)
+    arrs = [a(kf.mvKeysUn), a(kf.mDescriptors), a(Scw, np.float32), a(mp.skip.astype(np.uint8)), a(mp.world), a(mp.normal), a(mp.maxd), a(mp.mind),
+            a(mp.descriptor)]
+    _L.orc_fuse_search_sim3(_p(arrs[0]), _p(arrs[1]), kf.N, _p(arrs[2]), _p(cam), _p(sf), len(sf), _logsf(sf), mp.n, _p(arrs[3]), _p(arrs[4]),
+                            _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), C.c_float(th), _p(bi), _p(bd))
+    return bi, bd
+
+
+def search_by_sim3(kf1, kf2, matches12, s12, R12, t12, th):
+    """matches12: int array (-1 none, >= 0 index in kf2, -2 matched to a point kf2 does not observe); returns (nFound, vnMatch1, vnMatch2, matches12')"""
+    a = np.ascontiguousarray
+    m12 = np.asarray(matches12)
+    al1 = a((m12 != -1).astype(np.uint8))
+    al2 = np.zeros(kf2.N, np.uint8); al2[m12[(m12 >= 0) & (m12 < kf2.N)]] = 1
+    cam, sf = _cam(kf1), a(kf1.mvScaleFactors)
+
+    def pack(k):
+        return [a(k.mvKeysUn), a(k.mDescriptors), a(k.mTcw), a(k.mp_valid.astype(np.uint8)), a(k.mp_bad.astype(np.uint8)), a(k.mp_world),
+                a(k.mp_maxd), a(k.mp_mind), a(k.mp_desc)]
+    A, B = pack(kf1), pack(kf2)
+    v1, v2, out = np.zeros(kf1.N, np.int32), np.zeros(kf2.N, np.int32), np.zeros(kf1.N, np.int32)
+    R, t = a(R12, np.float32), a(t12, np.float32)
+    _L.orc_search_by_sim3.restype = C.c_int
+    n = _L.orc_search_by_sim3(_p(A[0]), _p(A[1]), kf1.N, _p(A[2]), _p(A[3]), _p(A[4]), _p(A[5]), _p(A[6]), _p(A[7]), _p(A[8]), _p(al1),
+                              _p(B[0]), _p(B[1]), kf2.N, _p(B[2]), _p(B[3]), _p(B[4]), _p(B[5]), _p(B[6]), _p(B[7]), _p(B[8]), _p(al2),
+                              _p(cam), _p(sf), len(sf), _logsf(sf), C.c_float(s12), _p(R), _p(t), C.c_float(th), _p(v1), _p(v2), _p(out))
+    res = m12.copy()
+    res[out >= 0] = out[out >= 0]
+    return n, v1, v2, res

@@ -198,3 +198,73 @@ def test_fuse_search(oracle, th):
     bi_g, bd_g = ola.ORBmatcher(0.6, True).FuseSearch(kf, mp, th, Ow)
     assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
     assert (bi_g >= 0).sum() > 200 and ((bd_g <= 50) & (bi_g >= 0)).sum() > 100
+
+
+def _rot(ax, ay, az):
+    cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]); Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return (Rz @ Ry @ Rx).astype(np.float32)
+
+
+@pytest.mark.parametrize("th,scale", [(4.0, 1.0), (10.0, 1.03)])
+def test_fuse_search_sim3(oracle, th, scale):
+    """Fuse(pKF, Scw, vpPoints, th, vpReplacePoint), the loop-correction variant: pose given as a similarity, no stereo / chi-square gate"""
+    last, cur = _frames(oracle, seed=83)
+    kf = _as_kf(cur)
+    sel = np.flatnonzero(last.mp_valid)
+    rng = np.random.default_rng(29)
+    world = last.mp_world[sel].copy(); world[:, 0] += np.float32(3 * 0.54 / 718.856) * world[:, 2]
+    d = np.linalg.norm(world, axis=1).astype(np.float32)
+    lvl = last.mvKeysUn["octave"][sel].astype(np.float32)
+    maxd = (d * np.float32(1.2) ** lvl * rng.uniform(0.95, 1.05, len(sel))).astype(np.float32)
+    normal = (world / d[:, None] + rng.normal(0, 0.3, world.shape)).astype(np.float32)
+    mp = ola.MapPointGeom(world, normal, maxd, maxd / np.float32(1.2) ** 7, last.mDescriptors[sel], skip=rng.random(len(sel)) < 0.1)
+    # world frame = camera frame moved by a small rigid motion and scaled: Scw = s [R | t]
+    R, t = _rot(0.002, -0.003, 0.001), np.array([0.01, -0.004, 0.02], np.float32)
+    Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = np.float32(scale) * R; Scw[:3, 3] = np.float32(scale) * t
+    mp.world = ((mp.world - t) @ R).astype(np.float32)                       # so that Rcw * p + tcw lands on the original points
+    Ro, to, Oo = oracle.sim3_decompose(Scw)
+    Rg, tg, Og = ola.matcher.Sim3Decompose(Scw)
+    assert np.array_equal(Ro.view(np.uint32), Rg.view(np.uint32)) and np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert np.array_equal(Oo.view(np.uint32), Og.view(np.uint32))
+    bi_o, bd_o = oracle.fuse_search_sim3(kf, Scw, mp, th)
+    bi_g, bd_g = ola.ORBmatcher(0.6, True).FuseSearchSim3(kf, Scw, mp, th)
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    assert (bi_g >= 0).sum() > 200 and ((bd_g <= 50) & (bi_g >= 0)).sum() > 100
+
+
+@pytest.mark.parametrize("th,s12", [(7.5, 1.0), (10.0, 0.98)])
+def test_search_by_sim3(oracle, th, s12):
+    """SearchBySim3 (loop closing): both key frames' map points projected into the other under the similarity, mutual agreement"""
+    last, cur = _frames(oracle, seed=97)
+    kf1, kf2 = _as_kf(last), _as_kf(cur)
+    rng = np.random.default_rng(31)
+    # KF2 = the frame shifted by 3 px; its map points are KF1's points displaced by that shift, attached to the features a projection
+    # search pairs them with (any consistent attachment would do: the test needs two key frames observing one scene)
+    _, m = oracle.search_by_projection(copy.deepcopy(cur), last, 7, False)
+    has = m >= 0
+    kf2.mp_valid = has.copy()
+    kf2.mp_world = np.zeros((kf2.N, 3), np.float32)
+    w = last.mp_world[m[has]].copy(); w[:, 0] += np.float32(3 * 0.54 / 718.856) * w[:, 2]
+    kf2.mp_world[has] = w
+    kf2.mp_desc = kf2.mDescriptors.copy()
+    for k in (kf1, kf2):
+        d = np.linalg.norm(np.where(k.mp_valid[:, None], k.mp_world, 1), axis=1).astype(np.float32)
+        lv = k.mvKeysUn["octave"].astype(np.float32)
+        k.mp_maxd = (d * np.float32(1.2) ** lv * rng.uniform(0.95, 1.05, k.N)).astype(np.float32)
+        k.mp_mind = (k.mp_maxd / np.float32(1.2) ** 7).astype(np.float32)
+        k.mp_bad = rng.random(k.N) < 0.05
+        k.mTcw = np.eye(4, dtype=np.float32)
+    kf2.mTcw[0, 3] = 0.004                                   # the two cameras see the world from slightly different poses
+    R12 = _rot(0.001, 0.002, -0.001)
+    t12 = np.array([-0.002, 0.001, 0.003], np.float32)
+    matches12 = np.full(kf1.N, -1, np.int64)                 # some features are matched already (to a feature of KF2, or to a point KF2 does not see)
+    pre = np.flatnonzero(rng.random(kf1.N) < 0.05)
+    vals = rng.integers(0, kf2.N + 20, len(pre)); vals[vals >= kf2.N] = -2
+    matches12[pre] = vals
+    n_o, v1_o, v2_o, m_o = oracle.search_by_sim3(kf1, kf2, matches12, s12, R12, t12, th)
+    mg = matches12.copy()
+    n_g, v1_g, v2_g = ola.ORBmatcher(0.75, True).SearchBySim3(kf1, kf2, mg, s12, R12, t12, th)
+    assert n_g == n_o and np.array_equal(v1_g, v1_o) and np.array_equal(v2_g, v2_o) and np.array_equal(mg, m_o)
+    assert (v1_g >= 0).sum() > 50 and (v2_g >= 0).sum() > 50
