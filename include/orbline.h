@@ -148,6 +148,48 @@ int olf_match_candidates_dev(olf_ctx* ctx, const uint8_t* d_descQ, int nQ, const
                              const int32_t* d_cand_idx, uint16_t* d_dist, void* stream);
 int olf_match_candidates(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, const int32_t* cand_offsets,
                          const int32_t* cand_idx, uint16_t* dist);
+/* ---- the per-frame ORBmatcher searches, complete (host candidate generation + GPU distances + the reference's resolution) ----
+ * Plain view of the Frame / KeyFrame members these searches read (include/Frame.h:49-260, include/KeyFrame.h).  Pointers a search
+ * does not read may be NULL.  mp_valid / mp_obs stand for `mvpMapPoints[i] != NULL` and `mvpMapPoints[i]->Observations() > 0`; the
+ * searches that assign map points to the current frame update them in place, as the reference updates mvpMapPoints. */
+typedef struct olf_frame_view {
+    const olf_keypoint* keys;     /* mvKeysUn (= mvKeys for a rectified camera, src/Frame.cc:601-605)            */
+    const uint8_t* desc;          /* mDescriptors [n][32]                                                        */
+    const float*   uright;        /* mvuRight [n] (negative = monocular point)                                   */
+    int32_t        n;             /* N                                                                           */
+    uint8_t*       mp_valid;      /* [n]                                                                         */
+    uint8_t*       mp_obs;        /* [n]                                                                         */
+    const uint8_t* mp_bad;        /* [n] pMP->isBad()                                                            */
+    const float*   mp_world;      /* [n][3] pMP->GetWorldPos()                                                   */
+    const uint8_t* mp_desc;       /* [n][32] pMP->GetDescriptor()                                                */
+    const uint8_t* outlier;       /* [n] mvbOutlier                                                              */
+    const float*   Tcw;           /* mTcw, 4x4 row-major                                                         */
+    float fx, fy, cx, cy, mbf, minX, maxX, minY, maxY;     /* calibration, mnMinX .. mnMaxY                      */
+    const float*   scale_factors; /* mvScaleFactors [n_levels]                                                   */
+    int32_t        n_levels;
+    const int32_t* fv_nodes;      /* mFeatVec (DBoW2::FeatureVector) as CSR: ascending node ids [fv_n],          */
+    const int32_t* fv_offsets;    /*   offsets [fv_n + 1],                                                       */
+    const int32_t* fv_features;   /*   feature indices                                                           */
+    int32_t        fv_n;
+} olf_frame_view;
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono), src/ORBmatcher.cc:1330-1472
+ * (Tracking::TrackWithMotionModel, every frame).  matches[i2] = index of the LastFrame feature whose map point CurrentFrame feature i2
+ * received (-1 = none); cur->mp_valid / mp_obs are updated; *nmatches = the reference's return value. */
+int olf_search_by_projection(olf_ctx* ctx, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
+                             int32_t* matches, int32_t* nmatches);
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290
+ * (Tracking::TrackReferenceKeyFrame / Relocalization).  matched[iF] = index of the key-frame feature whose map point feature iF of F
+ * received (-1 = none). */
+int olf_search_by_bow(olf_ctx* ctx, const olf_frame_view* kf, const olf_frame_view* f, float nnratio, int check_orientation, int32_t* matched,
+                      int32_t* nmatches);
+/* int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:47-131
+ * (Tracking::SearchLocalPoints, every frame).  Map point members as arrays of n_mp: mbTrackInView, isBad(), mnTrackScaleLevel,
+ * mTrackViewCos, (mTrackProjX, mTrackProjY, mTrackProjXR) interleaved, GetDescriptor(), Observations() > 0.
+ * matches[idx] = index into vpMapPoints given to feature idx of F (-1 = none); f->mp_valid / mp_obs are updated. */
+int olf_search_local_map(olf_ctx* ctx, const olf_frame_view* f, int n_mp, const uint8_t* track_in_view, const uint8_t* bad,
+                         const int32_t* track_scale_level, const float* track_view_cos, const float* track_proj3, const uint8_t* mp_desc,
+                         const uint8_t* mp_obs, float th, float nnratio, int32_t* matches, int32_t* nmatches);
+
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1795-1811) over all pairs: out[nA][nB] uint16 (host buffers) */
 int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out);
 

@@ -54,6 +54,15 @@ class FrameBuffers(C.Structure):
                                           "ldisp", "lle")]
 
 
+class FrameViewC(C.Structure):
+    """olf_frame_view (include/orbline.h): the Frame / KeyFrame members read by the per-frame ORBmatcher searches"""
+    _fields_ = ([(n, C.c_void_p) for n in ("keys", "desc", "uright")] + [("n", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("mp_valid", "mp_obs", "mp_bad", "mp_world", "mp_desc", "outlier", "Tcw")] +
+                [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "mbf", "minX", "maxX", "minY", "maxY")] +
+                [("scale_factors", C.c_void_p), ("n_levels", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("fv_nodes", "fv_offsets", "fv_features")] + [("fv_n", C.c_int32)])
+
+
 class OlfError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -116,6 +125,10 @@ def lib():
         L.olf_stereo_frames_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers), C.c_void_p]
         L.olf_stereo_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers)]
         L.olf_match_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_search_by_projection.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_by_bow.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_local_map.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.olf_match_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_cvt_gray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.olf_remap_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -225,132 +225,65 @@ def ComputeThreeMaxima(histo):
     return ind1, ind2, ind3
 
 
+def _view_c(v, keep):
+    """olf_frame_view of a FrameView / KeyFrameView; every array it points to is appended to `keep` (alive until the call returns).  The bool
+    state arrays are passed as they are (one byte per element), so the library's updates land in the view's own arrays."""
+    from ._lib import FrameViewC
+    c = FrameViewC()
+
+    def p(a, dt=None):
+        if a is None:
+            return None
+        b = np.ascontiguousarray(a if dt is None else np.asarray(a, dt))
+        keep.append(b)
+        return b.ctypes.data
+
+    def state(name):
+        a = getattr(v, name, None)
+        if a is None:
+            return None
+        if not (isinstance(a, np.ndarray) and a.dtype == np.bool_ and a.flags.c_contiguous):
+            a = np.ascontiguousarray(a, bool)
+            setattr(v, name, a)
+        keep.append(a)
+        return a.ctypes.data
+    c.keys, c.desc, c.uright, c.n = p(v.mvKeysUn), p(v.mDescriptors), p(v.mvuRight, np.float32), v.N
+    c.mp_valid, c.mp_obs, c.mp_bad, c.outlier = state("mp_valid"), state("mp_obs"), state("mp_bad"), state("mvbOutlier")
+    c.mp_world, c.mp_desc, c.Tcw = p(v.mp_world, np.float32), p(v.mp_desc, np.uint8), p(v.mTcw, np.float32)
+    c.fx, c.fy, c.cx, c.cy, c.mbf = float(v.fx), float(v.fy), float(v.cx), float(v.cy), float(v.mbf)
+    c.minX, c.maxX, c.minY, c.maxY = float(v.mnMinX), float(v.mnMaxX), float(v.mnMinY), float(v.mnMaxY)
+    c.scale_factors, c.n_levels = p(v.mvScaleFactors, np.float32), len(v.mvScaleFactors)
+    nodes = sorted(v.mFeatVec)
+    offs = np.zeros(len(nodes) + 1, np.int32)
+    offs[1:] = np.cumsum([len(v.mFeatVec[k]) for k in nodes])
+    feats = np.array([i for k in nodes for i in v.mFeatVec[k]], np.int32)
+    c.fv_nodes, c.fv_offsets, c.fv_features, c.fv_n = p(np.array(nodes, np.int32)), p(offs), p(feats), len(nodes)
+    return c
+
+
 def _search_by_projection(self, CurrentFrame, LastFrame, th, bMono):
     """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono),
-    src/ORBmatcher.cc:1330-1472.  Returns (nmatches, matches) with matches[i2] = index i of the LastFrame map point
-    assigned to CurrentFrame feature i2 (-1 = none); CurrentFrame.mp_valid / mp_obs are updated like mvpMapPoints."""
-    f32 = np.float32
-    HL = self.HISTO_LENGTH
-    rotHist = [[] for _ in range(HL)]
-    factor = f32(1.0) / f32(HL)
-    Rcw, tcw = CurrentFrame.mTcw[:3, :3], CurrentFrame.mTcw[:3, 3]
-    # cv::Mat products of CV_32F matrices accumulate in double and round once (cv::gemm's generic path)
-    twc = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
-    Rlw, tlw = LastFrame.mTcw[:3, :3], LastFrame.mTcw[:3, 3]
-    tlc = (Rlw.astype(np.float64) @ twc.astype(np.float64) + tlw.astype(np.float64)).astype(f32)
-    bForward = bool(tlc[2] > CurrentFrame.mb) and not bMono
-    bBackward = bool(-tlc[2] > CurrentFrame.mb) and not bMono
-    queries, lists, meta = [], [], []
-    for i in range(LastFrame.N):
-        if not LastFrame.mp_valid[i] or LastFrame.mvbOutlier[i]:
-            continue
-        x3Dc = (Rcw.astype(np.float64) @ LastFrame.mp_world[i].astype(np.float64) + tcw.astype(np.float64)).astype(f32)
-        xc, yc = x3Dc[0], x3Dc[1]
-        invzc = f32(1.0 / np.float64(x3Dc[2])) if x3Dc[2] != 0 else f32(np.inf)
-        if invzc < 0:
-            continue
-        u = f32(f32(f32(CurrentFrame.fx * xc) * invzc) + CurrentFrame.cx)
-        v = f32(f32(f32(CurrentFrame.fy * yc) * invzc) + CurrentFrame.cy)
-        if u < CurrentFrame.mnMinX or u > CurrentFrame.mnMaxX or v < CurrentFrame.mnMinY or v > CurrentFrame.mnMaxY:
-            continue
-        nLastOctave = int(LastFrame.mvKeys["octave"][i])
-        radius = f32(f32(th) * CurrentFrame.mvScaleFactors[nLastOctave])
-        if bForward:
-            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nLastOctave)
-        elif bBackward:
-            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, 0, nLastOctave)
-        else:
-            idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1)
-        if not idx:
-            continue
-        queries.append(i); lists.append(idx); meta.append((u, invzc, radius))
-    dists = _candidate_distances(LastFrame.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, CurrentFrame.mDescriptors,
-                                 self._context)
-    matches = np.full(CurrentFrame.N, -1, np.int32)
-    nmatches = 0
-    for qi, i in enumerate(queries):
-        u, invzc, radius = meta[qi]
-        bestDist, bestIdx2 = 256, -1
-        for i2, dist in zip(lists[qi], dists[qi]):
-            if CurrentFrame.mp_valid[i2] and CurrentFrame.mp_obs[i2]:
-                continue
-            if CurrentFrame.mvuRight[i2] > 0:
-                ur = f32(u - f32(CurrentFrame.mbf * invzc))
-                if abs(f32(ur - CurrentFrame.mvuRight[i2])) > radius:
-                    continue
-            if int(dist) < bestDist:
-                bestDist, bestIdx2 = int(dist), i2
-        if bestDist <= self.TH_HIGH:
-            CurrentFrame.mp_valid[bestIdx2] = True
-            CurrentFrame.mp_obs[bestIdx2] = LastFrame.mp_obs[i]
-            matches[bestIdx2] = i
-            nmatches += 1
-            if self.mbCheckOrientation:
-                rot = f32(LastFrame.mvKeysUn["angle"][i] - CurrentFrame.mvKeysUn["angle"][bestIdx2])
-                if rot < 0.0:
-                    rot = f32(rot + f32(360.0))
-                b = _c_round(f32(rot * factor))
-                if b == HL:
-                    b = 0
-                rotHist[b].append(bestIdx2)
-    if self.mbCheckOrientation:
-        ind = ComputeThreeMaxima(rotHist)
-        for b in range(HL):
-            if b not in ind:
-                for j in rotHist[b]:
-                    CurrentFrame.mp_valid[j] = False
-                    matches[j] = -1
-                    nmatches -= 1
-    return nmatches, matches
+    src/ORBmatcher.cc:1330-1472 -> olf_search_by_projection (host candidate lists and resolution in csrc/search_host.cpp, distances on the
+    GPU).  Returns (nmatches, matches) with matches[i2] = index i of the LastFrame map point assigned to CurrentFrame feature i2 (-1 = none);
+    CurrentFrame.mp_valid / mp_obs are updated like mvpMapPoints."""
+    keep = []
+    cur, last = _view_c(CurrentFrame, keep), _view_c(LastFrame, keep)
+    matches, n = np.full(CurrentFrame.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_projection(_ctx(self._context).handle, cur, last, float(th), int(bool(bMono)), int(bool(self.mbCheckOrientation)),
+                                         ptr(matches), ptr(n)), "olf_search_by_projection")
+    return int(n[0]), matches
 
 
 def _search_by_bow(self, pKF, F):
-    """int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290.
-    Returns (nmatches, vpMapPointMatches) with vpMapPointMatches[iF] = KF feature index whose map point was matched (-1 = none)."""
-    f32 = np.float32
-    HL = self.HISTO_LENGTH
-    rotHist = [[] for _ in range(HL)]
-    factor = f32(1.0) / f32(HL)
-    common = sorted(set(pKF.mFeatVec) & set(F.mFeatVec))       # the merge-join of the two ordered maps visits exactly these nodes
-    queries, lists = [], []
-    for node in common:
-        for realIdxKF in pKF.mFeatVec[node]:
-            if not pKF.mp_valid[realIdxKF] or pKF.mp_bad[realIdxKF]:
-                continue
-            queries.append(realIdxKF); lists.append(list(F.mFeatVec[node]))
-    dists = _candidate_distances(pKF.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, F.mDescriptors, self._context)
-    matched = np.full(F.N, -1, np.int32)
-    nmatches = 0
-    for qi, realIdxKF in enumerate(queries):
-        bestDist1, bestIdxF, bestDist2 = 256, -1, 256
-        for realIdxF, dist in zip(lists[qi], dists[qi]):
-            if matched[realIdxF] >= 0:
-                continue
-            dist = int(dist)
-            if dist < bestDist1:
-                bestDist2, bestDist1, bestIdxF = bestDist1, dist, realIdxF
-            elif dist < bestDist2:
-                bestDist2 = dist
-        if bestDist1 <= self.TH_LOW and f32(bestDist1) < f32(self.mfNNratio) * f32(bestDist2):
-            matched[bestIdxF] = realIdxKF
-            if self.mbCheckOrientation:
-                rot = f32(pKF.mvKeysUn["angle"][realIdxKF] - F.mvKeys["angle"][bestIdxF])
-                if rot < 0.0:
-                    rot = f32(rot + f32(360.0))
-                b = _c_round(f32(rot * factor))
-                if b == HL:
-                    b = 0
-                rotHist[b].append(bestIdxF)
-            nmatches += 1
-    if self.mbCheckOrientation:
-        ind = ComputeThreeMaxima(rotHist)
-        for b in range(HL):
-            if b in ind:
-                continue
-            for j in rotHist[b]:
-                matched[j] = -1
-                nmatches -= 1
-    return nmatches, matched
+    """int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290 ->
+    olf_search_by_bow.  Returns (nmatches, vpMapPointMatches) with vpMapPointMatches[iF] = KF feature index whose map point was matched
+    (-1 = none)."""
+    keep = []
+    kf, f = _view_c(pKF, keep), _view_c(F, keep)
+    matched, n = np.full(F.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_bow(_ctx(self._context).handle, kf, f, float(self.mfNNratio), int(bool(self.mbCheckOrientation)), ptr(matched),
+                                  ptr(n)), "olf_search_by_bow")
+    return int(n[0]), matched
 
 
 class MapPointView:
@@ -377,50 +310,19 @@ def RadiusByViewingCos(viewCos):
 
 def _search_local_map(self, F, vpMapPoints, th=1.0):
     """int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:47-131
-    (Tracking::SearchLocalPoints, every frame).  Returns (nmatches, matches) with matches[idx] = index into vpMapPoints assigned to feature
-    idx (-1 = none); F.mp_valid / F.mp_obs are updated like F.mvpMapPoints."""
-    f32 = np.float32
+    (Tracking::SearchLocalPoints, every frame) -> olf_search_local_map.  Returns (nmatches, matches) with matches[idx] = index into
+    vpMapPoints assigned to feature idx (-1 = none); F.mp_valid / F.mp_obs are updated like F.mvpMapPoints."""
     mp = vpMapPoints
-    bFactor = float(th) != 1.0
-    queries, lists, radii = [], [], []
-    for iMP in range(mp.n):
-        if not mp.mbTrackInView[iMP] or mp.isBad[iMP]:
-            continue
-        lvl = int(mp.mnTrackScaleLevel[iMP])
-        r = RadiusByViewingCos(mp.mTrackViewCos[iMP])
-        if bFactor:
-            r = f32(r * f32(th))
-        rs = f32(r * F.mvScaleFactors[lvl])
-        idx = F.GetFeaturesInArea(mp.mTrackProjX[iMP], mp.mTrackProjY[iMP], rs, lvl - 1, lvl)
-        if not idx:
-            continue
-        queries.append(iMP); lists.append(idx); radii.append(rs)
-    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, F.mDescriptors, self._context)
-    matches = np.full(F.N, -1, np.int32)
-    nmatches = 0
-    octave = F.mvKeysUn["octave"]
-    for qi, iMP in enumerate(queries):
-        bestDist = bestDist2 = 256
-        bestLevel = bestLevel2 = bestIdx = -1
-        for idx, dist in zip(lists[qi], dists[qi]):
-            if F.mp_valid[idx] and F.mp_obs[idx]:
-                continue
-            if F.mvuRight[idx] > 0:
-                if abs(f32(mp.mTrackProjXR[iMP] - F.mvuRight[idx])) > radii[qi]:
-                    continue
-            dist = int(dist)
-            if dist < bestDist:
-                bestDist2, bestDist, bestLevel2, bestLevel, bestIdx = bestDist, dist, bestLevel, int(octave[idx]), idx
-            elif dist < bestDist2:
-                bestLevel2, bestDist2 = int(octave[idx]), dist
-        if bestDist <= self.TH_HIGH:
-            if bestLevel == bestLevel2 and f32(bestDist) > f32(self.mfNNratio) * f32(bestDist2):
-                continue
-            F.mp_valid[bestIdx] = True
-            F.mp_obs[bestIdx] = mp.obs[iMP]
-            matches[bestIdx] = iMP
-            nmatches += 1
-    return nmatches, matches
+    keep = []
+    f = _view_c(F, keep)
+    a = np.ascontiguousarray
+    proj3 = a(np.stack([mp.mTrackProjX, mp.mTrackProjY, mp.mTrackProjXR], 1), np.float32)
+    arrs = [a(mp.mbTrackInView, np.uint8), a(mp.isBad, np.uint8), a(mp.mnTrackScaleLevel, np.int32), a(mp.mTrackViewCos, np.float32), proj3,
+            a(mp.descriptor, np.uint8), a(mp.obs, np.uint8)]
+    matches, n = np.full(F.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_local_map(_ctx(self._context).handle, f, mp.n, *(ptr(x) for x in arrs), float(th), float(self.mfNNratio), ptr(matches),
+                                     ptr(n)), "olf_search_local_map")
+    return int(n[0]), matches
 
 
 _libm = None

@@ -45,6 +45,15 @@ def test_bad_arguments_are_reported():
     assert L.olf_distinctive_descriptors(ctx.handle, _p(d), _p(np.array([0, 3, 2], np.int32)), 2, _p(m)) == OLF_ERR_INVALID   # offsets decrease
     assert L.olf_voc_load_text(b"/nonexistent", C.byref(h)) == OLF_ERR_INVALID
     assert L.olf_voc_create(10, 0, 0, 0, 1, _p(m), _p(d), _p(d), _p(np.zeros(1)), C.byref(h)) == OLF_ERR_INVALID   # L must be >= 1
+    # the per-frame searches: null views / outputs, an octave outside mvScaleFactors
+    fv = _lib.FrameViewC()
+    n1 = np.zeros(1, np.int32)
+    assert L.olf_search_by_projection(ctx.handle, None, C.byref(fv), C.c_float(7), 0, 1, _p(m), _p(n1)) == OLF_ERR_INVALID
+    assert L.olf_search_by_projection(ctx.handle, C.byref(fv), C.byref(fv), C.c_float(7), 0, 1, _p(m), _p(n1)) == OLF_ERR_INVALID   # no pose, no state
+    assert L.olf_search_by_bow(ctx.handle, C.byref(fv), C.byref(fv), C.c_float(0.7), 1, None, _p(n1)) == OLF_ERR_INVALID
+    assert L.olf_search_by_bow(ctx.handle, C.byref(fv), C.byref(fv), C.c_float(0.7), 1, _p(m), _p(n1)) == OLF_OK and n1[0] == 0      # two empty frames
+    assert L.olf_search_local_map(ctx.handle, C.byref(fv), 3, None, None, None, None, None, None, None, C.c_float(1), C.c_float(0.8), _p(m),
+                                  _p(n1)) == OLF_ERR_INVALID
     assert L.olf_last_error() is not None
     # the context is still usable after all of that
     k, dd, c = np.zeros((1, cap), _lib.KEYPOINT_DTYPE), np.zeros((1, cap, 32), np.uint8), np.zeros(1, np.int32)
