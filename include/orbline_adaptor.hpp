@@ -190,6 +190,44 @@ public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:39-41
     ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return distance(a, b); }
+
+    // The members of the reference's MapPoints read by SearchByProjection(Frame&, const vector<MapPoint*>&, th), gathered into arrays
+    struct TrackedMapPoints {
+        int n = 0;
+        const uint8_t* mbTrackInView = nullptr; const uint8_t* isBad = nullptr; const int32_t* mnTrackScaleLevel = nullptr;
+        const float* mTrackViewCos = nullptr; const float* mTrackProjXYR = nullptr;     // (mTrackProjX, mTrackProjY, mTrackProjXR) per point
+        const uint8_t* descriptor = nullptr; const uint8_t* observed = nullptr;        // GetDescriptor(), Observations() > 0
+    };
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono), src/ORBmatcher.cc:1330-1472.
+    // The frames are olf_frame_view gathers of the Frame members; matches[i2] = LastFrame feature whose map point
+    // CurrentFrame feature i2 received.
+    int SearchByProjection(olf_ctx* ctx, const olf_frame_view& CurrentFrame, const olf_frame_view& LastFrame, float th, bool bMono,
+                           std::vector<int32_t>& matches) const
+    {
+        matches.assign(CurrentFrame.n, -1);
+        int32_t n = 0;
+        olf_detail::check(olf_search_by_projection(ctx, &CurrentFrame, &LastFrame, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, matches.data(), &n),
+                          "olf_search_by_projection");
+        return n;
+    }
+    // int SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th = 3), src/ORBmatcher.cc:47-131
+    int SearchByProjection(olf_ctx* ctx, const olf_frame_view& F, const TrackedMapPoints& vpMapPoints, float th, std::vector<int32_t>& matches) const
+    {
+        matches.assign(F.n, -1);
+        int32_t n = 0;
+        const TrackedMapPoints& m = vpMapPoints;
+        olf_detail::check(olf_search_local_map(ctx, &F, m.n, m.mbTrackInView, m.isBad, m.mnTrackScaleLevel, m.mTrackViewCos, m.mTrackProjXYR,
+                                               m.descriptor, m.observed, th, mfNNratio, matches.data(), &n), "olf_search_local_map");
+        return n;
+    }
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290
+    int SearchByBoW(olf_ctx* ctx, const olf_frame_view& KF, const olf_frame_view& F, std::vector<int32_t>& vpMapPointMatches) const
+    {
+        vpMapPointMatches.assign(F.n, -1);
+        int32_t n = 0;
+        olf_detail::check(olf_search_by_bow(ctx, &KF, &F, mfNNratio, mbCheckOrientation ? 1 : 0, vpMapPointMatches.data(), &n), "olf_search_by_bow");
+        return n;
+    }
     float mfNNratio;
     bool mbCheckOrientation;
 };

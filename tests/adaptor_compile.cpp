@@ -20,6 +20,17 @@ int main()
         voc.transform(nullptr, a, 1, bow, fv, 4);            // empty vocabulary: empty vectors, no device call
         if (!bow.empty() || !fv.empty()) return 5;
     }
+    {   // the per-frame searches instantiate; with a null context the library reports the bad argument and the adaptor throws
+        ORB_SLAM2::ORBmatcher m(0.9f, true);
+        olf_frame_view f = {};
+        std::vector<int32_t> matches;
+        ORB_SLAM2::ORBmatcher::TrackedMapPoints mps;
+        int thrown = 0;
+        try { m.SearchByProjection(nullptr, f, f, 7.f, false, matches); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.SearchByProjection(nullptr, f, mps, 1.f, matches); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.SearchByBoW(nullptr, f, f, matches); } catch (const std::runtime_error&) { ++thrown; }
+        if (thrown != 3) return 6;
+    }
     std::printf("ADAPTOR_OK\n");
     return 0;
 }
