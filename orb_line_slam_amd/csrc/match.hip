@@ -232,48 +232,151 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ c
 
 // ---------------------------------------------------------------------------------------------
 // Brute-force 2-nearest-neighbour search (cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2), App. A.10):
-// per query the two smallest distances; ties keep the lower train index first.  One wave per query.
+// per query the two smallest distances; ties keep the lower train index first.
 // Sets are batched: set s has nQ[s] queries at q + s*strideQ*32 and nT[s] train rows at t + s*strideT*32.
-// One THREAD per query: the query's 256 bits live in 8 registers, the train descriptors stream through LDS in tiles
-// and are read at a wave-uniform address (broadcast), so the inner loop is 8 x (xor, popcount, add) + the top-2 update.
-constexpr int KNN_TILE = 128;   // train descriptors per LDS tile (4 KB)
+//
+// All-pairs Hamming is a GEMM: hamming(a, b) = |a| + |b| - 2 a.b over the 256 bits taken as 0/1 vectors, so the distance tile comes out
+// of the matrix cores (v_mfma_i32_32x32x32_i8, exact in int32): the train rows are the A operand with bytes {0, 1}, the queries the B
+// operand with bytes {0, -2}, and the accumulator starts at |a| + |b|.  A workgroup owns 256 queries (4 waves x two 32-query column
+// blocks, their expanded bits held in registers for the whole kernel) and walks the train set in tiles of 32 rows, expanded to bytes
+// once per workgroup into LDS (double buffered).  In the C/D layout a lane holds 16 train rows of ONE query (col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)), so the running top-2 is per lane: (distance << 16 | train index) keys, three integer
+// ops per candidate, and one exchange between the two lane halves at the end.  The k index of an A / B byte only has to be the
+// same function of (lane >> 5, byte) on both sides -- any such assignment sums the same 256 products.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int KM_ROWS = 32;          // train rows per tile
+constexpr int KM_STRIDE = 272;       // bytes per expanded row in LDS: 256 + 16 (16-byte reads of 16 consecutive rows touch every bank once)
+constexpr int KM_PAD_DIST = 0x4000;  // |a| of a row past the end of the train set: never among real candidates, recognised at the end
+
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }   // bits 0..3 -> bytes 0..3
+
+// SHIFT = 12 (train sets of up to 4096 rows, every case on the path): A bytes {0, 64}, B bytes {0, -128}, so a common bit contributes
+// -2 * 4096 and an accumulator that starts at ((|a| + |b|) << 12) + train index ends as the finished (distance << 12 | index) key --
+// no instruction builds it.  SHIFT = 16 (up to 65535 rows): bytes {0, 1} / {0, -2}, the accumulator is the distance and the key is one
+// shift-add.
+template <int SHIFT>
+__device__ __forceinline__ void knn2_body(uint8_t (*s_a)[KM_ROWS * KM_STRIDE], int (*s_pa)[KM_ROWS], const int set, const int nq, const int nt,
+                                          const uint8_t* __restrict__ q, int strideQ, const uint8_t* __restrict__ t, int strideT,
+                                          int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ dist1)
+{
+    constexpr bool FUSED = SHIFT == 12;
+    constexpr uint32_t A_BYTE = FUSED ? 0x40u : 0x01u, B_BYTE = FUSED ? 0x80u : 0xfeu;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 5, col = lane & 31;
+
+    // B operand: the wave's 2 x 32 queries, 8 k-chunks of 32 bits; this lane carries bits [32 c + 16 g, +16) of query `col`
+    v4i bq[2][8];
+    int pb[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int iq = blockIdx.x * 256 + wv * 64 + cb * 32 + col;
+        uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+        if (iq < nq) {
+            const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
+            d0 = qp[0]; d1 = qp[1];
+        }
+        const uint32_t d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        int p = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            p += __popc(d[c]);
+            const uint32_t h = (d[c] >> (16 * g)) & 0xffffu;
+            v4i f;
+            f.x = (int)(spread4(h & 15u) * B_BYTE); f.y = (int)(spread4((h >> 4) & 15u) * B_BYTE);
+            f.z = (int)(spread4((h >> 8) & 15u) * B_BYTE); f.w = (int)(spread4(h >> 12) * B_BYTE);
+            bq[cb][c] = f;
+        }
+        pb[cb] = FUSED ? p << 12 : p;
+    }
+
+    // A operand staging: thread (row r = tid / 8, word w = tid % 8) expands 32 bits of train row t0 + r into 32 bytes
+    const int sr = threadIdx.x >> 3, sw = threadIdx.x & 7;
+    const uint32_t* tp = reinterpret_cast<const uint32_t*>(t + (size_t)set * strideT * OLF_DESC_BYTES);
+    auto stage = [&](int buf, int t0) {
+        const bool in = t0 + sr < nt;
+        const uint32_t w = in ? tp[(size_t)(t0 + sr) * 8 + sw] : 0u;
+        uint4 lo, hi;
+        lo.x = spread4(w & 15u) * A_BYTE; lo.y = spread4((w >> 4) & 15u) * A_BYTE; lo.z = spread4((w >> 8) & 15u) * A_BYTE;
+        lo.w = spread4((w >> 12) & 15u) * A_BYTE;
+        hi.x = spread4((w >> 16) & 15u) * A_BYTE; hi.y = spread4((w >> 20) & 15u) * A_BYTE; hi.z = spread4((w >> 24) & 15u) * A_BYTE;
+        hi.w = spread4(w >> 28) * A_BYTE;
+        uint4* dst = reinterpret_cast<uint4*>(&s_a[buf][sr * KM_STRIDE + sw * 32]);
+        dst[0] = lo; dst[1] = hi;
+        int p = __popc(w);                                   // |a| of the row: sum over its 8 words (8 adjacent lanes)
+        p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4);
+        if (!in) p = KM_PAD_DIST;
+        if (sw == 0) s_pa[buf][sr] = FUSED ? (p << 12) + t0 + sr : p;
+    };
+
+    unsigned k0[2] = {0xffffffffu, 0xffffffffu}, k1[2] = {0xffffffffu, 0xffffffffu};
+    if (nt > 0) stage(0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = 0; t0 < nt; t0 += KM_ROWS) {
+        if (t0 + KM_ROWS < nt) stage(buf ^ 1, t0 + KM_ROWS);
+        // accumulators start at |a| + |b| (FUSED: shifted, plus the row's index)
+        v16i acc0, acc1;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int4 pa = *reinterpret_cast<const int4*>(&s_pa[buf][8 * q4 + 4 * g]);
+            acc0[4 * q4 + 0] = pa.x + pb[0]; acc0[4 * q4 + 1] = pa.y + pb[0]; acc0[4 * q4 + 2] = pa.z + pb[0]; acc0[4 * q4 + 3] = pa.w + pb[0];
+            acc1[4 * q4 + 0] = pa.x + pb[1]; acc1[4 * q4 + 1] = pa.y + pb[1]; acc1[4 * q4 + 2] = pa.z + pb[1]; acc1[4 * q4 + 3] = pa.w + pb[1];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v4i a = *reinterpret_cast<const v4i*>(&s_a[buf][col * KM_STRIDE + c * 32 + g * 16]);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][c], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][c], acc1, 0, 0, 0);
+        }
+        const unsigned rowbase = (unsigned)(t0 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned ka, kb;
+            if (FUSED) { ka = (unsigned)acc0[r]; kb = (unsigned)acc1[r]; }
+            else {
+                const unsigned idx = rowbase + (unsigned)((r & 3) + 8 * (r >> 2));
+                ka = ((unsigned)acc0[r] << 16) + idx; kb = ((unsigned)acc1[r] << 16) + idx;
+            }
+            k1[0] = min(k1[0], max(k0[0], ka)); k0[0] = min(k0[0], ka);
+            k1[1] = min(k1[1], max(k0[1], kb)); k0[1] = min(k0[1], kb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        // the other half of the rows of this query lives in lane ^ 32
+        const unsigned o0 = (unsigned)__shfl_xor((int)k0[cb], 32), o1 = (unsigned)__shfl_xor((int)k1[cb], 32);
+        unsigned m0 = min(k0[cb], o0), m1 = min(max(k0[cb], o0), min(k1[cb], o1));
+        if (m0 >= ((unsigned)KM_PAD_DIST << SHIFT)) m0 = 0xffffffffu;          // padding rows are not candidates
+        if (m1 >= ((unsigned)KM_PAD_DIST << SHIFT)) m1 = 0xffffffffu;
+        const int iq = blockIdx.x * 256 + wv * 64 + cb * 32 + col;
+        if (g == 0 && iq < nq) {
+            const size_t o = (size_t)set * strideQ + iq;
+            idx0[o] = m0 == 0xffffffffu ? -1 : (int)(m0 & ((1u << SHIFT) - 1u));
+            dist0[o] = m0 == 0xffffffffu ? 0x7fffffff : (int)(m0 >> SHIFT);
+            dist1[o] = m1 == 0xffffffffu ? 0x7fffffff : (int)(m1 >> SHIFT);
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_knn2(const uint8_t* __restrict__ q, const int* __restrict__ nQ, int strideQ, int qSetStep,
                                               const uint8_t* __restrict__ t, const int* __restrict__ nT, int strideT, int tSetStep,
                                               int* __restrict__ idx0, int* __restrict__ dist0, int* __restrict__ dist1)
 {
-    __shared__ uint4 s_t[KNN_TILE * 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][KM_ROWS * KM_STRIDE];
+    __shared__ __attribute__((aligned(16))) int s_pa[2][KM_ROWS];
     const int set = blockIdx.y;
-    const int iq = blockIdx.x * 256 + threadIdx.x;
     const int nq = nQ[set * qSetStep], nt = nT[set * tSetStep];
     if (blockIdx.x * 256 >= nq) return;                      // whole block beyond the query set
-    const bool live = iq < nq;
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-    if (live) {
-        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)set * strideQ + iq) * OLF_DESC_BYTES);
-        a0 = qp[0]; a1 = qp[1];
-    }
-    // (distance << 16 | train index) keys: the minimum key is the best match with "ties keep the lower train index first" (App. A.10),
-    // and the second smallest key carries the second best distance of the multiset -- three integer min/max per candidate
-    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
-    const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)set * strideT * OLF_DESC_BYTES);
-    for (int t0 = 0; t0 < nt; t0 += KNN_TILE) {
-        const int cnt = min(KNN_TILE, nt - t0);
-        __syncthreads();
-        if (threadIdx.x < 2 * cnt) s_t[threadIdx.x] = tp[2 * t0 + threadIdx.x];
-        __syncthreads();
-        for (int j = 0; j < cnt; ++j) {
-            const unsigned k = ((unsigned)ham256(a0, a1, s_t[2 * j], s_t[2 * j + 1]) << 16) | (unsigned)(t0 + j);
-            k1 = min(k1, max(k0, k));
-            k0 = min(k0, k);
-        }
-    }
-    if (live) {
-        const size_t o = (size_t)set * strideQ + iq;
-        idx0[o] = k0 == 0xffffffffu ? -1 : (int)(k0 & 0xffffu);
-        dist0[o] = k0 == 0xffffffffu ? 0x7fffffff : (int)(k0 >> 16);
-        dist1[o] = k1 == 0xffffffffu ? 0x7fffffff : (int)(k1 >> 16);
-    }
+    if (nt <= 4096) knn2_body<12>(s_a, s_pa, set, nq, nt, q, strideQ, t, strideT, idx0, dist0, dist1);
+    else knn2_body<16>(s_a, s_pa, set, nq, nt, q, strideQ, t, strideT, idx0, dist0, dist1);
+}
+
+static void launch_knn2_kernel(dim3 grid, hipStream_t s, const uint8_t* q, const int* nQ, int strideQ, int qStep, const uint8_t* t, const int* nT,
+                               int strideT, int tStep, int* idx0, int* dist0, int* dist1)
+{
+    hipLaunchKernelGGL(k_knn2, grid, dim3(256), 0, s, q, nQ, strideQ, qStep, t, nT, strideT, tStep, idx0, dist0, dist1);
 }
 
 // ratio test of matchNNR (src/LineMatcher.cpp:54-59) + mutual check of match() (:121-127)
@@ -398,11 +501,12 @@ int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, 
 int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, const uint8_t* dB, const int* nB, int strideB, int bStep,
                     int n_sets, float nnr, int best_lr, int* ws /* 3*(strideA+strideB)*n_sets ints */, int* m12, hipStream_t s)
 {
+    if (strideA > 65535 || strideB > 65535) { set_error("match: more than 65535 descriptors per set"); return OLF_ERR_CAPACITY; }   // 16-bit index in the keys
     int* idxAB = ws; int* d0AB = idxAB + (size_t)n_sets * strideA; int* d1AB = d0AB + (size_t)n_sets * strideA;
     int* idxBA = d1AB + (size_t)n_sets * strideA; int* d0BA = idxBA + (size_t)n_sets * strideB; int* d1BA = d0BA + (size_t)n_sets * strideB;
-    hipLaunchKernelGGL(k_knn2, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, dA, nA, strideA, aStep, dB, nB, strideB, bStep, idxAB, d0AB, d1AB);
+    launch_knn2_kernel(dim3((strideA + 255) / 256, n_sets), s, dA, nA, strideA, aStep, dB, nB, strideB, bStep, idxAB, d0AB, d1AB);
     if (best_lr)
-        hipLaunchKernelGGL(k_knn2, dim3((strideB + 255) / 256, n_sets), dim3(256), 0, s, dB, nB, strideB, bStep, dA, nA, strideA, aStep, idxBA, d0BA, d1BA);
+        launch_knn2_kernel(dim3((strideB + 255) / 256, n_sets), s, dB, nB, strideB, bStep, dA, nA, strideA, aStep, idxBA, d0BA, d1BA);
     hipLaunchKernelGGL(k_ratio_mutual, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, nA, strideA, aStep, nB, strideB, bStep, idxAB, d0AB,
                        d1AB, idxBA, d0BA, d1BA, nnr, best_lr, m12);
     OLF_HIP_CHECK(hipGetLastError());
@@ -412,7 +516,8 @@ int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, co
 int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
                 int* dist0, int* dist1, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_knn2, dim3((strideA + 255) / 256, n_sets), dim3(256), 0, s, dA, nA, strideA, 1, dB, nB, strideB, 1, idx0, dist0, dist1);
+    if (strideB > 65535) { set_error("knn2: more than 65535 train descriptors per set"); return OLF_ERR_CAPACITY; }
+    launch_knn2_kernel(dim3((strideA + 255) / 256, n_sets), s, dA, nA, strideA, 1, dB, nB, strideB, 1, idx0, dist0, dist1);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
