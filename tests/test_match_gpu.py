@@ -16,7 +16,7 @@ def _rand_desc(rng, n, dup=0):
     return d
 
 
-@pytest.mark.parametrize("n1,n2", [(500, 500), (1, 7), (200, 2), (37, 1), (5, 0), (2000, 1999)])
+@pytest.mark.parametrize("n1,n2", [(500, 500), (1, 7), (200, 2), (37, 1), (5, 0), (2000, 1999), (300, 4096), (257, 4097), (700, 6001), (33, 31), (65, 33)])
 def test_knn2_and_match(oracle, n1, n2):
     rng = np.random.default_rng(n1 * 1000 + n2)
     d1, d2 = _rand_desc(rng, n1, dup=n1 // 10), _rand_desc(rng, n2, dup=n2 // 10)
