@@ -161,7 +161,11 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     olf_ctx* c = new olf_ctx();
     c->params = *p; c->W = width; c->H = height; c->max_images = max_images;
     int rc = c->orb.build(p->orb, width, height);
-    if (rc != OLF_OK) { set_error("olf_ctx_create: image size / ORB parameters not supported"); delete c; return rc; }
+    if (rc != OLF_OK) {
+        set_error(rc == OLF_ERR_CAPACITY ? "olf_ctx_create: more than 2040 key points on one pyramid level (nfeatures too large for this scale factor / level count)"
+                                         : "olf_ctx_create: image size / ORB parameters not supported (every pyramid level needs at least 62 x 62 pixels and a landscape cell grid)");
+        delete c; return rc;
+    }
     auto fail = [&](int code) { olf_ctx_destroy(c); return code; };
     if (hipGetDevice(&c->device) != hipSuccess) return fail(OLF_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(OLF_ERR_HIP); }

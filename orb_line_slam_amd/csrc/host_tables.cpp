@@ -100,7 +100,7 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
     for (int i = 0; i < 7; ++i) g.blurTaps[i] = taps[i];
 
     rx.clear(); ry.clear();
-    int off = 0, cells = 0, cand = 0, kps = 0, cellCap = 1, maxQuota = 1;
+    int off = 0, cells = 0, cand = 0, kps = 0, cellCap = 1, maxQuota = 1, maxKp = 1;
     for (int l = 0; l < nlevels; ++l) {
         LevelGeom& L = g.lv[l];
         L.w = cv_round_f((float)W * inv_sf[l]);
@@ -125,7 +125,10 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
         L.hX = width / L.nIni;
         L.scale = sf[l]; L.inv_scale = inv_sf[l];
         L.patch_size = (int)(31 * sf[l]);
-        L.kpBase = kps; L.kpCap = L.quota + 8; kps += L.kpCap;
+        // DistributeOctTree returns at most quota + 3 nodes once its size checks run, but the first sweep splits all nIni root nodes
+        // unconditionally (src/ORBextractor.cc:556-640): a small quota can come back as 4 * nIni key points
+        L.kpBase = kps; L.kpCap = std::max(L.quota + 8, 4 * L.nIni + 4); kps += L.kpCap;
+        maxKp = std::max(maxKp, L.kpCap);
         if (l > 0) {
             const LevelGeom& P = g.lv[l - 1];
             L.resizeTabX = (int)rx.size(); L.resizeTabY = (int)ry.size();
@@ -152,9 +155,11 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
     g.kpTotal = kps;
     g.outCap = kps;
     int mn = 64;
-    while (mn < maxQuota + 8) mn <<= 1;
+    while (mn < maxKp) mn <<= 1;
     g.maxNodes = mn;
-    if (mn > 4096) return OLF_ERR_INVALID;
+    // k_octree keeps a level's node list in LDS (orb_octree.hip, octree_lds_bytes: 66 bytes per node + 16 KB): 2048 nodes fit the 160 KB,
+    // i.e. at most 2040 key points on one level
+    if (mn > 2048) return OLF_ERR_CAPACITY;
     return OLF_OK;
 }
 
@@ -191,7 +196,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     const double LOG_NT = 5 * (std::log10(double(g.Ws)) + std::log10(double(g.Hs))) / 2 + std::log10(11.0);
     g.minRegSize = int(-LOG_NT / std::log10(pp));
     g.minLength = p.min_line_length * std::min(W, H);
-    g.maxDetect = 4096;
+    g.maxDetect = std::min(8192, std::max(4096, g.Ps / 256));       // raw segments kept per image before the top-N (k_line_select sorts them in LDS)
     // 16-byte region records alias the unsorted key buffer, 24-byte segment candidates the sorted one (4 bytes per pixel each)
     g.maxRegions = std::min(g.Ps / std::max(g.minRegSize, 1) + 1, g.Ps / 6 - 1);
     g.rectGrid = g.maxRegions;
