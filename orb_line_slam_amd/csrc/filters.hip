@@ -31,21 +31,28 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
     __shared__ uint32_t s_h[SF_TW * HS];
     const int img = blockIdx.z, x0 = blockIdx.x * SF_TW, y0 = blockIdx.y * SF_TH;
     const uint8_t* s = src + (size_t)img * srcImgStride;
+    // interior tile of a 4-byte aligned image: every staged word is one aligned load, no reflection (the common case by far)
+    const bool plain = x0 >= 4 && x0 + SF_TW + 4 <= W && y0 >= 3 && y0 + SF_TH + 3 <= H && ((srcPitch | (int)srcImgStride) & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+    const uint8_t* tile = s + (ptrdiff_t)(y0 - 3) * srcPitch + (x0 - 4);
     for (int i = threadIdx.x; i < SF_INH * SF_INW; i += 256) {
         const int r = i / SF_INW, j = i - r * SF_INW;
-        const int gy = sf_reflect(min(y0 - 3 + r, H + 2), H);
-        const int xw = x0 - 4 + 4 * j;
-        const uint8_t* row = s + (size_t)gy * srcPitch;
         uint32_t v;
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(row + xw);
-        const int sh = (int)(addr & 3) * 8;
-        if (xw >= 0 && (sh ? xw + 7 < W : xw + 3 < W)) {          // the second aligned word must stay inside the row
-            const uint32_t* p4 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
-            v = sh ? __funnelshift_r(p4[0], p4[1], sh) : p4[0];
-        } else {
-            v = 0;
+        if (plain) v = *reinterpret_cast<const uint32_t*>(tile + (size_t)r * srcPitch + 4 * j);
+        else {
+            const int gy = sf_reflect(min(y0 - 3 + r, H + 2), H);
+            const int xw = x0 - 4 + 4 * j;
+            const uint8_t* row = s + (size_t)gy * srcPitch;
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(row + xw);
+            const int sh = (int)(addr & 3) * 8;
+            if (xw >= 0 && (sh ? xw + 7 < W : xw + 3 < W)) {          // the second aligned word must stay inside the row
+                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
+                v = sh ? __funnelshift_r(p4[0], p4[1], sh) : p4[0];
+            } else {
+                v = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v |= (uint32_t)row[sf_reflect(min(xw + b, W + 2), W)] << (8 * b);
+                for (int b = 0; b < 4; ++b) v |= (uint32_t)row[sf_reflect(min(xw + b, W + 2), W)] << (8 * b);
+            }
         }
         s_in[i] = v;
     }
