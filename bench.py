@@ -173,6 +173,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    ctx.synchronize()                        # outside the timed region: raises if any step overflowed a fixed-capacity device buffer
     prof = ctx.profile_read()
     ctx.profile(False)
     if dist is not None:

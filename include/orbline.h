@@ -34,7 +34,13 @@ int olf_default_params(olf_params* p);
 /* context: replaces constructing ORBextractor x2 + Lineextractor x2 (src/Tracking.cc:131-142) */
 int  olf_ctx_create(const olf_params* p, int width, int height, int max_images, olf_ctx** out);
 void olf_ctx_destroy(olf_ctx* ctx);
+/* Capacity overflows (more corners / key points / segments than a fixed-size device buffer holds) are never silent: the blocking
+ * host-pointer entry points return OLF_ERR_CAPACITY themselves; for the asynchronous *_dev entry points the flag is collected by
+ * olf_ctx_synchronize (waits for the context's two streams, then reports and clears it) or, without waiting for anything,
+ * by olf_ctx_poll_status (call it once the caller's own stream has passed the work in question).  The reference has no such limits
+ * (std::vector growth); a refused frame is the equivalent of its std::bad_alloc. */
 int  olf_ctx_synchronize(olf_ctx* ctx);
+int  olf_ctx_poll_status(olf_ctx* ctx);
 
 /* Stage timing with HIP events recorded on the stream each stage is launched on (the reference's only
  * instrumentation is std::chrono around TrackStereo, Examples/PL/PL_stereo_kitti.cc:80-97).  Accumulates

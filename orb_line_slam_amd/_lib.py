@@ -101,6 +101,7 @@ def lib():
         L.olf_ctx_destroy.argtypes = [C.c_void_p]
         L.olf_ctx_destroy.restype = None
         L.olf_ctx_synchronize.argtypes = [C.c_void_p]
+        L.olf_ctx_poll_status.argtypes = [C.c_void_p]
         L.olf_orb_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         L.olf_orb_level_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_orb_capacity.argtypes = [C.c_void_p]
@@ -218,4 +219,9 @@ class Context:
         return {lib().olf_profile_stage_name(i).decode(): (float(ms[i]), int(calls[i])) for i in range(n)}
 
     def synchronize(self):
+        """wait for the context's streams; raises OlfError if a *_dev call issued since the last check overflowed a device buffer"""
         check(lib().olf_ctx_synchronize(self.handle), "olf_ctx_synchronize")
+
+    def poll_status(self):
+        """the same check without waiting for any stream (the caller has synchronised its own)"""
+        check(lib().olf_ctx_poll_status(self.handle), "olf_ctx_poll_status")

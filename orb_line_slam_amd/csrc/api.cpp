@@ -226,12 +226,20 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     return OLF_OK;
 }
 
+static int check_status(olf_ctx* c);
+
 int olf_ctx_synchronize(olf_ctx* c)
 {
     if (!c) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream2));
-    return OLF_OK;
+    return check_status(c);
+}
+
+int olf_ctx_poll_status(olf_ctx* c)
+{
+    if (!c) return OLF_ERR_INVALID;
+    return check_status(c);
 }
 
 // ---- stage profiling: HIP events on the launching streams -------------------------------------

@@ -318,11 +318,9 @@ size_t octree_lds_bytes(int M)
 int launch_orb_octree(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s)
 {
     const size_t lds = octree_lds_bytes(g.maxNodes);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (function, device) pair: set it on whichever device this launch goes to
+    if (lds > 64 * 1024)
         OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(k_octree, dim3(g.nlevels, n_images), dim3(256), lds, s, b.geom, b.cells, b.cellCount, b.cand, b.candNode,
                        b.candCount, b.lvlKp, b.lvlCount, b.status);
     OLF_HIP_CHECK(hipGetLastError());

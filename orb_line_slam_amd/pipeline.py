@@ -101,8 +101,10 @@ class OfflinePipeline:
                     slot["out_done"].record(self.s_out)
                 if prev is not None:
                     prev["out_done"].synchronize()
+                    self.ctx.poll_status()                                 # a batch that overflowed a device buffer is an error, not a short result
                     yield self._frames(prev)
                 prev = slot
             if prev is not None:
                 prev["out_done"].synchronize()
+                self.ctx.poll_status()
                 yield self._frames(prev)

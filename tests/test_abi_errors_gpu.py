@@ -62,3 +62,26 @@ def test_bad_arguments_are_reported():
     # the context is still usable after all of that
     k, dd, c = np.zeros((1, cap), _lib.KEYPOINT_DTYPE), np.zeros((1, cap, 32), np.uint8), np.zeros(1, np.int32)
     assert L.olf_orb_extract(ctx.handle, _p(np.full((1, 480, 640), 50, np.uint8)), 1, _p(k), _p(dd), _p(c)) == OLF_OK and c[0] == 0
+
+
+def test_async_overflow_is_reported():
+    """a *_dev call that overflows a device buffer (pure noise: more raw segments than the per-image capacity) does not fail by itself --
+    it is asynchronous -- but the next olf_ctx_synchronize / olf_ctx_poll_status reports it, once"""
+    import torch
+    L = _lib.lib()
+    p = _lib.default_params()
+    p.line.lsd_scale, p.line.min_line_length, p.line.lsd_quant, p.line.lsd_nfeatures = 2.0, 0.0, 1.0, 100
+    w, h = 620, 470
+    ctx = _lib.Context(p, w, h, 1)
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy(rng.integers(0, 256, (1, h, w), dtype=np.uint8)).cuda()
+    lcap = ctx.line_capacity
+    kls = torch.zeros(lcap * _lib.KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    desc = torch.zeros(lcap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = L.olf_line_extract_dev(ctx.handle, C.c_void_p(img.data_ptr()), 1, C.c_void_p(kls.data_ptr()), C.c_void_p(desc.data_ptr()),
+                                C.c_void_p(cnt.data_ptr()), None)
+    assert rc == OLF_OK
+    assert L.olf_ctx_synchronize(ctx.handle) == OLF_ERR_CAPACITY and b"overflow" in L.olf_last_error()
+    assert L.olf_ctx_synchronize(ctx.handle) == OLF_OK                       # reported once, then cleared
+    assert L.olf_ctx_poll_status(ctx.handle) == OLF_OK
