@@ -173,6 +173,8 @@ typedef struct olf_frame_view {
     float fx, fy, cx, cy, mbf, minX, maxX, minY, maxY;     /* calibration, mnMinX .. mnMaxY                      */
     const float*   scale_factors; /* mvScaleFactors [n_levels]                                                   */
     int32_t        n_levels;
+    const float*   mp_maxd;       /* [n] pMP->mfMaxDistance (key-frame searches that predict a scale level)      */
+    const float*   mp_mind;       /* [n] pMP->mfMinDistance                                                      */
     const int32_t* fv_nodes;      /* mFeatVec (DBoW2::FeatureVector) as CSR: ascending node ids [fv_n],          */
     const int32_t* fv_offsets;    /*   offsets [fv_n + 1],                                                       */
     const int32_t* fv_features;   /*   feature indices                                                           */
@@ -195,6 +197,39 @@ int olf_search_by_bow(olf_ctx* ctx, const olf_frame_view* kf, const olf_frame_vi
 int olf_search_local_map(olf_ctx* ctx, const olf_frame_view* f, int n_mp, const uint8_t* track_in_view, const uint8_t* bad,
                          const int32_t* track_scale_level, const float* track_view_cos, const float* track_proj3, const uint8_t* mp_desc,
                          const uint8_t* mp_obs, float th, float nnratio, int32_t* matches, int32_t* nmatches);
+
+/* ---- the LocalMapping / LoopClosing / relocalisation searches, same split (host candidates, GPU distances, host resolution) ----
+ * int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+ * const int ORBdist), src/ORBmatcher.cc:1620-1747.  already_found[i] = sAlreadyFound.count(pKF's i-th map point) (may be NULL);
+ * matches[i2] = key-frame feature whose map point CurrentFrame feature i2 received; cur->mp_valid is updated. */
+int olf_search_by_projection_kf(olf_ctx* ctx, const olf_frame_view* cur, const olf_frame_view* kf, const uint8_t* already_found, float th,
+                                int orb_dist, int check_orientation, int32_t* matches, int32_t* nmatches);
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:524-657.
+ * matches12[idx1] = feature of pKF2 whose map point is taken (-1 = NULL). */
+int olf_search_by_bow_kf(olf_ctx* ctx, const olf_frame_view* kf1, const olf_frame_view* kf2, float nnratio, int check_orientation,
+                         int32_t* matches12, int32_t* nmatches);
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+ * const bool bOnlyStereo), src/ORBmatcher.cc:659-825.  F12 3x3 row-major; Cw = pKF1->GetCameraCenter() (NULL: derived from kf1->Tcw).
+ * matches12[idx1] = idx2 (-1 = none): vMatchedPairs is the list of (idx1, matches12[idx1]) in idx1 order. */
+int olf_search_for_triangulation(olf_ctx* ctx, const olf_frame_view* kf1, const olf_frame_view* kf2, const float* F12, const float* Cw,
+                                 int only_stereo, int check_orientation, int32_t* matches12, int32_t* nmatches);
+/* The search part of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:827-948:
+ * per map point (skip = !pMP || isBad() || IsInKeyFrame(pKF); world, normal, mfMaxDistance, mfMinDistance, descriptor) the most similar key
+ * point inside the projection window: best_idx / best_dist (-1 / 256 where a gate rejects the point).  Ow = pKF->GetCameraCenter()
+ * (NULL: derived from kf->Tcw).  The reference then fuses when best_dist <= TH_LOW (:950-972, map mutation, host code). */
+int olf_fuse_search(olf_ctx* ctx, const olf_frame_view* kf, int n_mp, const uint8_t* skip, const float* world, const float* normal,
+                    const float* maxd, const float* mind, const uint8_t* desc, float th, const float* Ow, int32_t* best_idx, int32_t* best_dist);
+/* The search part of int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*>
+ * &vpReplacePoint), src/ORBmatcher.cc:977-1102 (Scw 4x4 row-major; skip = isBad() || spAlreadyFound.count(pMP)); best_dist is INT_MAX
+ * where nothing was found. */
+int olf_fuse_search_sim3(olf_ctx* ctx, const olf_frame_view* kf, const float* Scw, int n_mp, const uint8_t* skip, const float* world,
+                         const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th, int32_t* best_idx,
+                         int32_t* best_dist);
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
+ * const cv::Mat &t12, const float th), src/ORBmatcher.cc:1104-1328.  matches12[i1]: in -- -1 = NULL, >= 0 = pMP->GetIndexInKeyFrame(pKF2),
+ * -2 = a map point pKF2 does not observe; out -- additionally the agreed matches.  vn_match1 / vn_match2 = vnMatch1 / vnMatch2. */
+int olf_search_by_sim3(olf_ctx* ctx, const olf_frame_view* kf1, const olf_frame_view* kf2, int32_t* matches12, float s12, const float* R12,
+                       const float* t12, float th, int32_t* vn_match1, int32_t* vn_match2, int32_t* nfound);
 
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1795-1811) over all pairs: out[nA][nB] uint16 (host buffers) */
 int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t* descB, int nB, uint16_t* out);

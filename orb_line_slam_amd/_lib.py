@@ -60,7 +60,7 @@ class FrameViewC(C.Structure):
                 [(n, C.c_void_p) for n in ("mp_valid", "mp_obs", "mp_bad", "mp_world", "mp_desc", "outlier", "Tcw")] +
                 [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "mbf", "minX", "maxX", "minY", "maxY")] +
                 [("scale_factors", C.c_void_p), ("n_levels", C.c_int32)] +
-                [(n, C.c_void_p) for n in ("fv_nodes", "fv_offsets", "fv_features")] + [("fv_n", C.c_int32)])
+                [(n, C.c_void_p) for n in ("mp_maxd", "mp_mind", "fv_nodes", "fv_offsets", "fv_features")] + [("fv_n", C.c_int32)])
 
 
 class OlfError(RuntimeError):
@@ -128,6 +128,13 @@ def lib():
         L.olf_match_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_by_projection.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.olf_search_by_bow.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        V = C.POINTER(FrameViewC)
+        L.olf_search_by_projection_kf.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_by_bow_kf.argtypes = [C.c_void_p, V, V, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_for_triangulation.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_fuse_search.argtypes = [C.c_void_p, V, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.olf_fuse_search_sim3.argtypes = [C.c_void_p, V, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
+        L.olf_search_by_sim3.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_local_map.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.olf_match_candidates_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 #include "../../include/orbline.h"
 #include "olf_internal.hpp"
@@ -327,6 +328,453 @@ int olf_search_local_map(olf_ctx* c, const olf_frame_view* f, int n_mp, const ui
         }
     }
     *nmatches = n;
+    return OLF_OK;
+}
+
+}  // extern "C"
+
+// ---- LocalMapping / LoopClosing / relocalisation searches ------------------------------------------------------------------------
+
+namespace {
+// merge of two DBoW2 feature vectors: calls f(a, b) for every node present in both (:537-543, :683-689)
+template <class F>
+void for_common_nodes(const olf_frame_view& A, const olf_frame_view& B, F&& f)
+{
+    int a = 0, b = 0;
+    while (a < A.fv_n && b < B.fv_n) {
+        if (A.fv_nodes[a] == B.fv_nodes[b]) { f(a, b); ++a; ++b; }
+        else if (A.fv_nodes[a] < B.fv_nodes[b]) ++a;
+        else ++b;
+    }
+}
+
+bool bad_fv(const olf_frame_view* v) { return v->fv_n < 0 || (v->fv_n && (!v->fv_nodes || !v->fv_offsets || !v->fv_features)); }
+
+void camera_centre(const float* Tcw, float* Ow)                 // -Rcw.t() * tcw
+{
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)Tcw[4 * k + r] * (double)Tcw[4 * k + 3];
+        Ow[r] = (float)(-acc);
+    }
+}
+
+void r3_apply(const float* R9, const float* v, const float* t3, float* out, double alpha = 1.0)     // alpha * R * v (+ t), cv::gemm
+{
+    for (int r = 0; r < 3; ++r) {
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * (double)v[k];
+        out[r] = (float)(alpha * acc + (t3 ? (double)t3[r] : 0.0));
+    }
+}
+
+int predict_scale(float maxd, float dist, float logScaleFactor, int nLevels)       // MapPoint::PredictScale, src/MapPoint.cc:414-429
+{
+    const float ratio = maxd / dist;
+    int n = (int)std::ceil(std::log(ratio) / logScaleFactor);
+    if (n < 0) n = 0; else if (n >= nLevels) n = nLevels - 1;
+    return n;
+}
+
+float log_scale_factor(const olf_frame_view& f) { return f.n_levels > 1 ? std::log(f.scale_factors[1]) : 1.0f; }    // mfLogScaleFactor
+
+// pinhole projection + IsInImage (half-open, KeyFrame::IsInImage)
+bool project_in_image(const olf_frame_view& K, const float* p3Dc, float& u, float& v, float& invz)
+{
+    if (p3Dc[2] < 0.0f) return false;
+    invz = (float)(1.0 / p3Dc[2]);
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    u = K.fx * x + K.cx; v = K.fy * y + K.cy;
+    return u >= K.minX && u < K.maxX && v >= K.minY && v < K.maxY;
+}
+}  // namespace
+
+extern "C" {
+
+int olf_search_by_projection_kf(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* kf, const uint8_t* already_found, float th,
+                                int orb_dist, int check_orientation, int32_t* matches, int32_t* nmatches)
+{
+    if (!c || bad_view(cur, true) || bad_view(kf, false) || !matches || !nmatches || !cur->scale_factors || !cur->mp_valid ||
+        (kf->n && (!kf->mp_valid || !kf->mp_bad || !kf->mp_world || !kf->mp_desc || !kf->mp_maxd || !kf->mp_mind))) {
+        set_error("olf_search_by_projection_kf: bad argument"); return OLF_ERR_INVALID;
+    }
+    for (int i = 0; i < cur->n; ++i) matches[i] = -1;
+    *nmatches = 0;
+    float Ow[3];
+    camera_centre(cur->Tcw, Ow);
+    const float logSF = log_scale_factor(*cur);
+    const Grid grid(*cur);
+    Batch q;
+    for (int i = 0; i < kf->n; ++i) {
+        if (!kf->mp_valid[i]) continue;
+        if (kf->mp_bad[i] || (already_found && already_found[i])) continue;
+        const float* x3Dw = kf->mp_world + 3 * (size_t)i;
+        float x3Dc[3];
+        rot_apply(cur->Tcw, x3Dw, 1.0f, x3Dc);
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        const float u = cur->fx * xc * invzc + cur->cx, v = cur->fy * yc * invzc + cur->cy;
+        if (u < cur->minX || u > cur->maxX) continue;
+        if (v < cur->minY || v > cur->maxY) continue;
+        // Compute predicted scale level
+        double nrm = 0;
+        for (int k = 0; k < 3; ++k) { const float po = x3Dw[k] - Ow[k]; nrm += (double)po * (double)po; }
+        const float dist3D = (float)std::sqrt(nrm);
+        const float maxDistance = 1.2f * kf->mp_maxd[i], minDistance = 0.8f * kf->mp_mind[i];
+        // Depth must be inside the scale pyramid of the image
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = predict_scale(kf->mp_maxd[i], dist3D, logSF, cur->n_levels);
+        // Search in a window
+        const float radius = th * cur->scale_factors[nPredictedLevel];
+        if (!grid.area(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, q.cand)) continue;
+        q.add(i, kf->mp_desc + 32 * (size_t)i);
+    }
+    OLF_TRY(q.run(c, cur->desc, cur->n));
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int n = 0;
+    for (size_t k = 0; k < q.owner.size(); ++k) {
+        const int i = q.owner[k];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+            const int i2 = q.cand[p];
+            if (cur->mp_valid[i2]) continue;
+            const int dist = q.dist[p];
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) {
+            cur->mp_valid[bestIdx2] = 1;
+            matches[bestIdx2] = i;
+            n++;
+            if (check_orientation) rotHist[rot_bin(kf->keys[i].angle, cur->keys[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        three_maxima(rotHist, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int j : rotHist[b]) { cur->mp_valid[j] = 0; matches[j] = -1; n--; }
+        }
+    }
+    *nmatches = n;
+    return OLF_OK;
+}
+
+int olf_search_by_bow_kf(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_view* kf2, float nnratio, int check_orientation,
+                         int32_t* matches12, int32_t* nmatches)
+{
+    if (!c || bad_view(kf1, false) || bad_view(kf2, false) || !matches12 || !nmatches || bad_fv(kf1) || bad_fv(kf2) ||
+        (kf1->n && (!kf1->mp_valid || !kf1->mp_bad)) || (kf2->n && (!kf2->mp_valid || !kf2->mp_bad))) {
+        set_error("olf_search_by_bow_kf: bad argument"); return OLF_ERR_INVALID;
+    }
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    *nmatches = 0;
+    Batch q;
+    bool oob = false;
+    for_common_nodes(*kf1, *kf2, [&](int a, int b) {
+        for (int p = kf1->fv_offsets[a]; p < kf1->fv_offsets[a + 1]; ++p) {
+            const int idx1 = kf1->fv_features[p];
+            if (idx1 < 0 || idx1 >= kf1->n) { oob = true; continue; }
+            if (!kf1->mp_valid[idx1]) continue;
+            if (kf1->mp_bad[idx1]) continue;
+            q.cand.insert(q.cand.end(), kf2->fv_features + kf2->fv_offsets[b], kf2->fv_features + kf2->fv_offsets[b + 1]);
+            q.add(idx1, kf1->desc + 32 * (size_t)idx1);
+        }
+    });
+    for (int idx2 : q.cand) if (idx2 < 0 || idx2 >= kf2->n) oob = true;
+    if (oob) { set_error("olf_search_by_bow_kf: feature index outside its key frame"); return OLF_ERR_INVALID; }
+    OLF_TRY(q.run(c, kf2->desc, kf2->n));
+    std::vector<uint8_t> vbMatched2((size_t)std::max(kf2->n, 0), 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int n = 0;
+    for (size_t k = 0; k < q.owner.size(); ++k) {
+        const int idx1 = q.owner[k];
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+            const int idx2 = q.cand[p];
+            if (vbMatched2[idx2] || !kf2->mp_valid[idx2]) continue;
+            if (kf2->mp_bad[idx2]) continue;
+            const int dist = q.dist[p];
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < TH_LOW) {
+            if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                matches12[idx1] = bestIdx2;
+                vbMatched2[bestIdx2] = 1;
+                if (check_orientation) rotHist[rot_bin(kf1->keys[idx1].angle, kf2->keys[bestIdx2].angle)].push_back(idx1);
+                n++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        three_maxima(rotHist, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int j : rotHist[b]) { matches12[j] = -1; n--; }
+        }
+    }
+    *nmatches = n;
+    return OLF_OK;
+}
+
+int olf_search_for_triangulation(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_view* kf2, const float* F12, const float* Cw,
+                                 int only_stereo, int check_orientation, int32_t* matches12, int32_t* nmatches)
+{
+    if (!c || bad_view(kf1, !Cw) || bad_view(kf2, true) || !F12 || !matches12 || !nmatches || bad_fv(kf1) || bad_fv(kf2) || !kf2->scale_factors ||
+        (kf1->n && (!kf1->mp_valid || !kf1->uright)) || (kf2->n && (!kf2->mp_valid || !kf2->uright))) {
+        set_error("olf_search_for_triangulation: bad argument"); return OLF_ERR_INVALID;
+    }
+    for (int i = 0; i < kf1->n; ++i) matches12[i] = -1;
+    *nmatches = 0;
+    // Compute epipole in second image (:666-676)
+    float cw[3], C2[3];
+    if (Cw) std::memcpy(cw, Cw, sizeof(cw)); else camera_centre(kf1->Tcw, cw);
+    rot_apply(kf2->Tcw, cw, 1.0f, C2);
+    const float invz = 1.0f / C2[2];
+    const float ex = kf2->fx * C2[0] * invz + kf2->cx, ey = kf2->fy * C2[1] * invz + kf2->cy;
+    Batch q;
+    bool oob = false;
+    for_common_nodes(*kf1, *kf2, [&](int a, int b) {
+        for (int p = kf1->fv_offsets[a]; p < kf1->fv_offsets[a + 1]; ++p) {
+            const int idx1 = kf1->fv_features[p];
+            if (idx1 < 0 || idx1 >= kf1->n) { oob = true; continue; }
+            // If there is already a MapPoint skip
+            if (kf1->mp_valid[idx1]) continue;
+            const bool bStereo1 = kf1->uright[idx1] >= 0;
+            if (only_stereo) if (!bStereo1) continue;
+            q.cand.insert(q.cand.end(), kf2->fv_features + kf2->fv_offsets[b], kf2->fv_features + kf2->fv_offsets[b + 1]);
+            q.add(idx1, kf1->desc + 32 * (size_t)idx1);
+        }
+    });
+    for (int idx2 : q.cand) if (idx2 < 0 || idx2 >= kf2->n) oob = true;
+    if (oob) { set_error("olf_search_for_triangulation: feature index outside its key frame"); return OLF_ERR_INVALID; }
+    OLF_TRY(q.run(c, kf2->desc, kf2->n));
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int n = 0;
+    for (size_t k = 0; k < q.owner.size(); ++k) {
+        const int idx1 = q.owner[k];
+        const bool bStereo1 = kf1->uright[idx1] >= 0;
+        const olf_keypoint& kp1 = kf1->keys[idx1];
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+            const int idx2 = q.cand[p];
+            // If we have already matched or there is a MapPoint skip (vbMatched2 is never set in the reference)
+            if (kf2->mp_valid[idx2]) continue;
+            const bool bStereo2 = kf2->uright[idx2] >= 0;
+            if (only_stereo) if (!bStereo2) continue;
+            const int dist = q.dist[p];
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const olf_keypoint& kp2 = kf2->keys[idx2];
+            if (kp2.octave < 0 || kp2.octave >= kf2->n_levels) { set_error("olf_search_for_triangulation: octave outside mvScaleFactors"); return OLF_ERR_INVALID; }
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ex - kp2.x, distey = ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * kf2->scale_factors[kp2.octave]) continue;
+            }
+            // CheckDistEpipolarLine (:142-161), mvLevelSigma2[l] = mvScaleFactor[l]^2
+            const float ea = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+            const float eb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+            const float ec = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+            const float num = ea * kp2.x + eb * kp2.y + ec;
+            const float den = ea * ea + eb * eb;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            const float sigma2 = kf2->scale_factors[kp2.octave] * kf2->scale_factors[kp2.octave];
+            if (dsqr < 3.84 * sigma2) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            matches12[idx1] = bestIdx2;
+            n++;
+            if (check_orientation) rotHist[rot_bin(kp1.angle, kf2->keys[bestIdx2].angle)].push_back(idx1);
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        three_maxima(rotHist, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int j : rotHist[b]) { matches12[j] = -1; n--; }
+        }
+    }
+    *nmatches = n;
+    return OLF_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// per map point: gates, window, candidates.  Rcw9 / tcw3 / Ow3: camera pose; stereo_gate: the chi-square test of the plain Fuse.
+int fuse_core(olf_ctx* c, const char* who, const olf_frame_view* kf, const float* Rcw9, const float* tcw3, const float* Ow3, int n_mp,
+              const uint8_t* skip, const float* world, const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th,
+              bool stereo_gate, int none_dist, int32_t* best_idx, int32_t* best_dist)
+{
+    const float logSF = log_scale_factor(*kf);
+    const Grid grid(*kf);
+    Batch q;
+    struct Meta { float u, v, ur; int level; };
+    std::vector<Meta> meta;
+    for (int i = 0; i < n_mp; ++i) {
+        best_idx[i] = -1; best_dist[i] = none_dist;
+        if (skip && skip[i]) continue;
+        const float* p3Dw = world + 3 * (size_t)i;
+        float p3Dc[3], u, v, invz;
+        r3_apply(Rcw9, p3Dw, tcw3, p3Dc);
+        if (!project_in_image(*kf, p3Dc, u, v, invz)) continue;
+        const float ur = u - kf->mbf * invz;
+        const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+        float PO[3]; double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { PO[k] = p3Dw[k] - Ow3[k]; nrm += (double)PO[k] * (double)PO[k]; dot += (double)PO[k] * (double)normal[3 * (size_t)i + k]; }
+        const float dist3D = (float)std::sqrt(nrm);
+        // Depth must be inside the scale pyramid of the image
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        // Viewing angle must be less than 60 deg
+        if (dot < 0.5 * dist3D) continue;
+        const int nPredictedLevel = predict_scale(maxd[i], dist3D, logSF, kf->n_levels);
+        const float radius = th * kf->scale_factors[nPredictedLevel];
+        if (!grid.area(u, v, radius, -1, -1, q.cand)) continue;
+        q.add(i, desc + 32 * (size_t)i);
+        meta.push_back({u, v, ur, nPredictedLevel});
+    }
+    const int rc = q.run(c, kf->desc, kf->n);
+    if (rc != OLF_OK) return rc;
+    for (size_t k = 0; k < q.owner.size(); ++k) {
+        const Meta& m = meta[k];
+        int bestDist = none_dist, bestIdx = -1;
+        for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+            const int idx = q.cand[p];
+            const olf_keypoint& kp = kf->keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < m.level - 1 || kpLevel > m.level) continue;
+            if (stereo_gate) {
+                if (kpLevel < 0 || kpLevel >= kf->n_levels) { set_error(std::string(who) + ": octave outside mvScaleFactors"); return OLF_ERR_INVALID; }
+                const float sigma2 = kf->scale_factors[kpLevel] * kf->scale_factors[kpLevel];
+                const float invSigma2 = 1.0f / sigma2;                        // mvInvLevelSigma2, src/ORBextractor.cc:434-436
+                const float ex = m.u - kp.x, ey = m.v - kp.y;
+                if (kf->uright[idx] >= 0) {
+                    // Check reprojection error in stereo
+                    const float er = m.ur - kf->uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invSigma2 > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invSigma2 > 5.99) continue;
+                }
+            }
+            const int dist = q.dist[p];
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[q.owner[k]] = bestIdx; best_dist[q.owner[k]] = bestDist;
+    }
+    return OLF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int olf_fuse_search(olf_ctx* c, const olf_frame_view* kf, int n_mp, const uint8_t* skip, const float* world, const float* normal,
+                    const float* maxd, const float* mind, const uint8_t* desc, float th, const float* Ow, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c || bad_view(kf, true) || n_mp < 0 || !best_idx || !best_dist || !kf->scale_factors || (kf->n && !kf->uright) ||
+        (n_mp && (!world || !normal || !maxd || !mind || !desc))) { set_error("olf_fuse_search: bad argument"); return OLF_ERR_INVALID; }
+    float R[9], t[3], ow[3];
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) R[3 * r + k] = kf->Tcw[4 * r + k]; t[r] = kf->Tcw[4 * r + 3]; }
+    if (Ow) std::memcpy(ow, Ow, sizeof(ow)); else camera_centre(kf->Tcw, ow);
+    return fuse_core(c, "olf_fuse_search", kf, R, t, ow, n_mp, skip, world, normal, maxd, mind, desc, th, true, 256, best_idx, best_dist);
+}
+
+int olf_fuse_search_sim3(olf_ctx* c, const olf_frame_view* kf, const float* Scw, int n_mp, const uint8_t* skip, const float* world,
+                         const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th, int32_t* best_idx,
+                         int32_t* best_dist)
+{
+    if (!c || bad_view(kf, false) || !Scw || n_mp < 0 || !best_idx || !best_dist || !kf->scale_factors ||
+        (n_mp && (!world || !normal || !maxd || !mind || !desc))) { set_error("olf_fuse_search_sim3: bad argument"); return OLF_ERR_INVALID; }
+    // Decompose Scw (:985-989): scw = sqrt(row0 . row0); Rcw = sRcw / scw, tcw = Scw.col(3) / scw (a cv::Mat divided by a scalar is a
+    // scaling by the double 1/scw rounded to float); Ow = -Rcw.t() * tcw
+    double d = 0;
+    for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    float R[9], Rt[9], t[3], ow[3];
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) { R[3 * r + k] = Scw[4 * r + k] * inv; Rt[3 * k + r] = R[3 * r + k]; } t[r] = Scw[4 * r + 3] * inv; }
+    r3_apply(Rt, t, nullptr, ow, -1.0);
+    return fuse_core(c, "olf_fuse_search_sim3", kf, R, t, ow, n_mp, skip, world, normal, maxd, mind, desc, th, false, 2147483647, best_idx,
+                     best_dist);
+}
+
+int olf_search_by_sim3(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_view* kf2, int32_t* matches12, float s12, const float* R12,
+                       const float* t12, float th, int32_t* vn_match1, int32_t* vn_match2, int32_t* nfound)
+{
+    auto incomplete = [](const olf_frame_view* k) {
+        return k->n && (!k->mp_valid || !k->mp_bad || !k->mp_world || !k->mp_desc || !k->mp_maxd || !k->mp_mind);
+    };
+    if (!c || bad_view(kf1, true) || bad_view(kf2, true) || !matches12 || !R12 || !t12 || !vn_match1 || !vn_match2 || !nfound ||
+        !kf1->scale_factors || !kf2->scale_factors || incomplete(kf1) || incomplete(kf2)) {
+        set_error("olf_search_by_sim3: bad argument"); return OLF_ERR_INVALID;
+    }
+    const int N1 = kf1->n, N2 = kf2->n;
+    // Transformation between cameras (:1123-1125)
+    float sR12[9], sR21[9], t21[3];
+    const float inv = (float)(1.0 / (double)s12);
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { sR12[3 * r + k] = s12 * R12[3 * r + k]; sR21[3 * r + k] = inv * R12[3 * k + r]; }
+    r3_apply(sR21, t12, nullptr, t21, -1.0);
+    std::vector<uint8_t> already1((size_t)N1, 0), already2((size_t)N2, 0);
+    for (int i = 0; i < N1; i++) {
+        if (matches12[i] != -1) {
+            already1[i] = 1;
+            const int idx2 = matches12[i];
+            if (idx2 >= 0 && idx2 < N2) already2[idx2] = 1;
+        }
+    }
+    const float logSF = log_scale_factor(*kf1);
+    for (int dir = 0; dir < 2; ++dir) {
+        // dir 0: the map points of KF1 into KF2 (:1157-1232); dir 1: those of KF2 into KF1 (:1235-1309)
+        const olf_frame_view &src = dir ? *kf2 : *kf1, &dst = dir ? *kf1 : *kf2;
+        const std::vector<uint8_t>& already = dir ? already2 : already1;
+        const float *sR = dir ? sR12 : sR21, *t = dir ? t12 : t21;
+        int32_t* out = dir ? vn_match2 : vn_match1;
+        for (int i = 0; i < src.n; ++i) out[i] = -1;
+        const Grid grid(dst);
+        Batch q;
+        std::vector<int> levels;
+        for (int i = 0; i < src.n; ++i) {
+            if (!src.mp_valid[i] || already[i]) continue;
+            if (src.mp_bad[i]) continue;
+            float pa[3], pb[3], u, v, invz;
+            rot_apply(src.Tcw, src.mp_world + 3 * (size_t)i, 1.0f, pa);
+            r3_apply(sR, pa, t, pb);
+            if (!project_in_image(dst, pb, u, v, invz)) continue;
+            const float maxDistance = 1.2f * src.mp_maxd[i], minDistance = 0.8f * src.mp_mind[i];
+            double nrm = 0;
+            for (int k = 0; k < 3; ++k) nrm += (double)pb[k] * (double)pb[k];
+            const float dist3D = (float)std::sqrt(nrm);
+            if (dist3D < minDistance || dist3D > maxDistance) continue;
+            const int nPredictedLevel = predict_scale(src.mp_maxd[i], dist3D, logSF, dst.n_levels);
+            const float radius = th * dst.scale_factors[nPredictedLevel];
+            if (!grid.area(u, v, radius, -1, -1, q.cand)) continue;
+            q.add(i, src.mp_desc + 32 * (size_t)i);
+            levels.push_back(nPredictedLevel);
+        }
+        OLF_TRY(q.run(c, dst.desc, dst.n));
+        for (size_t k = 0; k < q.owner.size(); ++k) {
+            int bestDist = 2147483647, bestIdx = -1;
+            for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+                const int idx = q.cand[p];
+                const int oct = dst.keys[idx].octave;
+                if (oct < levels[k] - 1 || oct > levels[k]) continue;
+                const int dist = q.dist[p];
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+            if (bestDist <= TH_HIGH) out[q.owner[k]] = bestIdx;
+        }
+    }
+    // Check agreement
+    int found = 0;
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int idx2 = vn_match1[i1];
+        if (idx2 >= 0 && vn_match2[idx2] == i1) { matches12[i1] = idx2; found++; }
+    }
+    *nfound = found;
     return OLF_OK;
 }
 

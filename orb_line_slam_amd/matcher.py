@@ -199,11 +199,6 @@ def _candidate_distances(descQ, lists, descT, context=None):
     return [dist[offs[i]:offs[i + 1]] for i in range(len(lists))]
 
 
-def _c_round(v):
-    v = float(v)
-    return int(np.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
-
-
 def ComputeThreeMaxima(histo):
     """src/ORBmatcher.cc:1749-1790"""
     max1 = max2 = max3 = 0
@@ -253,6 +248,7 @@ def _view_c(v, keep):
     c.fx, c.fy, c.cx, c.cy, c.mbf = float(v.fx), float(v.fy), float(v.cx), float(v.cy), float(v.mbf)
     c.minX, c.maxX, c.minY, c.maxY = float(v.mnMinX), float(v.mnMaxX), float(v.mnMinY), float(v.mnMaxY)
     c.scale_factors, c.n_levels = p(v.mvScaleFactors, np.float32), len(v.mvScaleFactors)
+    c.mp_maxd, c.mp_mind = p(getattr(v, "mp_maxd", None), np.float32), p(getattr(v, "mp_mind", None), np.float32)
     nodes = sorted(v.mFeatVec)
     offs = np.zeros(len(nodes) + 1, np.int32)
     offs[1:] = np.cumsum([len(v.mFeatVec[k]) for k in nodes])
@@ -303,11 +299,6 @@ class MapPointView:
         self.mbTrackInView, self.isBad, self.obs = b(mbTrackInView, True), b(isBad, False), b(obs, True)
 
 
-def RadiusByViewingCos(viewCos):
-    """src/ORBmatcher.cc:133-139 (the float is compared with the double literal 0.998)"""
-    return np.float32(2.5) if float(np.float32(viewCos)) > 0.998 else np.float32(4.0)
-
-
 def _search_local_map(self, F, vpMapPoints, th=1.0):
     """int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:47-131
     (Tracking::SearchLocalPoints, every frame) -> olf_search_local_map.  Returns (nmatches, matches) with matches[idx] = index into
@@ -325,90 +316,18 @@ def _search_local_map(self, F, vpMapPoints, th=1.0):
     return int(n[0]), matches
 
 
-_libm = None
-
-
-def _logf(x):
-    """glibc logf (MapPoint::PredictScale calls std::log on a float, src/MapPoint.cc:422): numpy's float32 log is not guaranteed to be it"""
-    global _libm
-    if _libm is None:
-        import ctypes
-        _libm = ctypes.CDLL("libm.so.6")
-        _libm.logf.restype = ctypes.c_float
-        _libm.logf.argtypes = [ctypes.c_float]
-    return np.float32(_libm.logf(float(np.float32(x))))
-
-
 def _search_by_projection_kf(self, CurrentFrame, pKF, sAlreadyFound, th, ORBdist):
     """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
-    const int ORBdist), src/ORBmatcher.cc:1620-1747 (relocalisation).  pKF: KeyFrameView with mp_valid / mp_bad / mp_world / mp_desc and
-    mp_maxd / mp_mind (mfMaxDistance / mfMinDistance); sAlreadyFound: bool mask over pKF's features.  Returns (nmatches, matches) with
-    matches[i2] = pKF feature index; CurrentFrame.mp_valid is updated like mvpMapPoints."""
-    f32 = np.float32
-    HL = self.HISTO_LENGTH
-    rotHist = [[] for _ in range(HL)]
-    factor = f32(1.0) / f32(HL)
-    Rcw, tcw = CurrentFrame.mTcw[:3, :3], CurrentFrame.mTcw[:3, 3]
-    Ow = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
-    nLevels = len(CurrentFrame.mvScaleFactors)
-    logScale = _logf(CurrentFrame.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)       # mfLogScaleFactor = log(mfScaleFactor), src/Frame.cc:157
-    found = np.zeros(pKF.N, bool) if sAlreadyFound is None else np.asarray(sAlreadyFound, bool)
-    queries, lists = [], []
-    for i in range(pKF.N):
-        if not pKF.mp_valid[i] or pKF.mp_bad[i] or found[i]:
-            continue
-        x3Dw = pKF.mp_world[i]
-        x3Dc = (Rcw.astype(np.float64) @ x3Dw.astype(np.float64) + tcw.astype(np.float64)).astype(f32)
-        xc, yc = x3Dc[0], x3Dc[1]
-        invzc = f32(1.0 / np.float64(x3Dc[2])) if x3Dc[2] != 0 else f32(np.inf)
-        u = f32(f32(f32(CurrentFrame.fx * xc) * invzc) + CurrentFrame.cx)
-        v = f32(f32(f32(CurrentFrame.fy * yc) * invzc) + CurrentFrame.cy)
-        if u < CurrentFrame.mnMinX or u > CurrentFrame.mnMaxX or v < CurrentFrame.mnMinY or v > CurrentFrame.mnMaxY:
-            continue
-        PO = (x3Dw - Ow).astype(f32)
-        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
-        maxDistance, minDistance = f32(f32(1.2) * pKF.mp_maxd[i]), f32(f32(0.8) * pKF.mp_mind[i])
-        if dist3D < minDistance or dist3D > maxDistance:
-            continue
-        ratio = f32(pKF.mp_maxd[i] / dist3D)
-        nPredictedLevel = int(np.ceil(f32(_logf(ratio) / logScale)))
-        nPredictedLevel = 0 if nPredictedLevel < 0 else min(nPredictedLevel, nLevels - 1)
-        radius = f32(f32(th) * CurrentFrame.mvScaleFactors[nPredictedLevel])
-        idx = CurrentFrame.GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1)
-        if not idx:
-            continue
-        queries.append(i); lists.append(idx)
-    dists = _candidate_distances(pKF.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, CurrentFrame.mDescriptors, self._context)
-    matches = np.full(CurrentFrame.N, -1, np.int32)
-    nmatches = 0
-    for qi, i in enumerate(queries):
-        bestDist, bestIdx2 = 256, -1
-        for i2, dist in zip(lists[qi], dists[qi]):
-            if CurrentFrame.mp_valid[i2]:
-                continue
-            if int(dist) < bestDist:
-                bestDist, bestIdx2 = int(dist), i2
-        if bestDist <= ORBdist:
-            CurrentFrame.mp_valid[bestIdx2] = True
-            matches[bestIdx2] = i
-            nmatches += 1
-            if self.mbCheckOrientation:
-                rot = f32(pKF.mvKeysUn["angle"][i] - CurrentFrame.mvKeysUn["angle"][bestIdx2])
-                if rot < 0.0:
-                    rot = f32(rot + f32(360.0))
-                b = _c_round(f32(rot * factor))
-                if b == HL:
-                    b = 0
-                rotHist[b].append(bestIdx2)
-    if self.mbCheckOrientation:
-        ind = ComputeThreeMaxima(rotHist)
-        for b in range(HL):
-            if b not in ind:
-                for j in rotHist[b]:
-                    CurrentFrame.mp_valid[j] = False
-                    matches[j] = -1
-                    nmatches -= 1
-    return nmatches, matches
+    const int ORBdist), src/ORBmatcher.cc:1620-1747 (relocalisation) -> olf_search_by_projection_kf.  pKF: KeyFrameView with mp_valid /
+    mp_bad / mp_world / mp_desc and mp_maxd / mp_mind (mfMaxDistance / mfMinDistance); sAlreadyFound: bool mask over pKF's features.
+    Returns (nmatches, matches) with matches[i2] = pKF feature index; CurrentFrame.mp_valid is updated like mvpMapPoints."""
+    keep = []
+    cur, kf = _view_c(CurrentFrame, keep), _view_c(pKF, keep)
+    found = None if sAlreadyFound is None else np.ascontiguousarray(sAlreadyFound, np.uint8)
+    matches, n = np.full(CurrentFrame.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_projection_kf(_ctx(self._context).handle, cur, kf, None if found is None else ptr(found), float(th), int(ORBdist),
+                                            int(bool(self.mbCheckOrientation)), ptr(matches), ptr(n)), "olf_search_by_projection_kf")
+    return int(n[0]), matches
 
 
 def _search_by_projection_dispatch(self, a, b, *args):
@@ -426,145 +345,34 @@ def _search_by_projection_dispatch2(self, a, b, th=1.0, bMono=False):
 
 ORBmatcher.SearchByProjection = _search_by_projection_dispatch
 def _search_by_bow_kf(self, pKF1, pKF2):
-    """int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:524-657 (loop closing).
-    Returns (nmatches, vpMatches12) with vpMatches12[idx1] = feature index idx2 of pKF2 whose map point is taken (-1 = NULL)."""
-    f32 = np.float32
-    HL = self.HISTO_LENGTH
-    rotHist = [[] for _ in range(HL)]
-    factor = f32(1.0) / f32(HL)
-    common = sorted(set(pKF1.mFeatVec) & set(pKF2.mFeatVec))
-    queries, lists = [], []
-    for node in common:
-        for idx1 in pKF1.mFeatVec[node]:
-            if not pKF1.mp_valid[idx1] or pKF1.mp_bad[idx1]:
-                continue
-            queries.append(idx1); lists.append(list(pKF2.mFeatVec[node]))
-    dists = _candidate_distances(pKF1.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF2.mDescriptors, self._context)
-    matches12 = np.full(pKF1.N, -1, np.int32)
-    vbMatched2 = np.zeros(pKF2.N, bool)
-    nmatches = 0
-    for qi, idx1 in enumerate(queries):
-        bestDist1, bestIdx2, bestDist2 = 256, -1, 256
-        for idx2, dist in zip(lists[qi], dists[qi]):
-            if vbMatched2[idx2] or not pKF2.mp_valid[idx2] or pKF2.mp_bad[idx2]:
-                continue
-            dist = int(dist)
-            if dist < bestDist1:
-                bestDist2, bestDist1, bestIdx2 = bestDist1, dist, idx2
-            elif dist < bestDist2:
-                bestDist2 = dist
-        if bestDist1 < self.TH_LOW and f32(bestDist1) < f32(self.mfNNratio) * f32(bestDist2):
-            matches12[idx1] = bestIdx2
-            vbMatched2[bestIdx2] = True
-            if self.mbCheckOrientation:
-                rot = f32(pKF1.mvKeysUn["angle"][idx1] - pKF2.mvKeysUn["angle"][bestIdx2])
-                if rot < 0.0:
-                    rot = f32(rot + f32(360.0))
-                b = _c_round(f32(rot * factor))
-                if b == HL:
-                    b = 0
-                rotHist[b].append(idx1)
-            nmatches += 1
-    if self.mbCheckOrientation:
-        ind = ComputeThreeMaxima(rotHist)
-        for b in range(HL):
-            if b in ind:
-                continue
-            for j in rotHist[b]:
-                matches12[j] = -1
-                nmatches -= 1
-    return nmatches, matches12
+    """int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:524-657 (loop closing)
+    -> olf_search_by_bow_kf.  Returns (nmatches, vpMatches12) with vpMatches12[idx1] = feature index idx2 of pKF2 whose map point is taken
+    (-1 = NULL)."""
+    keep = []
+    k1, k2 = _view_c(pKF1, keep), _view_c(pKF2, keep)
+    m12, n = np.full(pKF1.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_bow_kf(_ctx(self._context).handle, k1, k2, float(self.mfNNratio), int(bool(self.mbCheckOrientation)), ptr(m12), ptr(n)),
+          "olf_search_by_bow_kf")
+    return int(n[0]), m12
 
 
 def _search_by_bow_dispatch(self, pKF, other):
     return _search_by_bow_kf(self, pKF, other) if isinstance(other, KeyFrameView) else _search_by_bow(self, pKF, other)
 
 
-def _epipolar_ok(kp1, kp2, F12, levelSigma2):
-    """ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:142-161 (float arithmetic, the threshold product in double)"""
-    f32 = np.float32
-    x1, y1, x2, y2 = f32(kp1["x"]), f32(kp1["y"]), f32(kp2["x"]), f32(kp2["y"])
-    a = f32(f32(f32(x1 * F12[0, 0]) + f32(y1 * F12[1, 0])) + F12[2, 0])
-    b = f32(f32(f32(x1 * F12[0, 1]) + f32(y1 * F12[1, 1])) + F12[2, 1])
-    c = f32(f32(f32(x1 * F12[0, 2]) + f32(y1 * F12[1, 2])) + F12[2, 2])
-    num = f32(f32(f32(a * x2) + f32(b * y2)) + c)
-    den = f32(f32(a * a) + f32(b * b))
-    if den == 0:
-        return False
-    dsqr = f32(f32(num * num) / den)
-    return float(dsqr) < 3.84 * float(levelSigma2[int(kp2["octave"])])
-
-
 def _search_for_triangulation(self, pKF1, pKF2, F12, bOnlyStereo, Cw=None):
     """int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t,size_t>> &vMatchedPairs,
-    const bool bOnlyStereo), src/ORBmatcher.cc:659-825 (LocalMapping::CreateNewMapPoints).  Cw = pKF1->GetCameraCenter() (default: from
-    pKF1.mTcw); pKF2.mTcw gives R2w / t2w.  Returns (nmatches, vMatchedPairs) with vMatchedPairs = [(idx1, idx2), ...] in idx1 order."""
-    f32 = np.float32
-    HL = self.HISTO_LENGTH
-    F12 = np.ascontiguousarray(F12, f32).reshape(3, 3)
-    if Cw is None:
-        R1, t1 = pKF1.mTcw[:3, :3], pKF1.mTcw[:3, 3]
-        Cw = (-(R1.T.astype(np.float64) @ t1.astype(np.float64))).astype(f32)
-    R2w, t2w = pKF2.mTcw[:3, :3], pKF2.mTcw[:3, 3]
-    C2 = (R2w.astype(np.float64) @ np.asarray(Cw, f32).astype(np.float64) + t2w.astype(np.float64)).astype(f32)
-    invz = f32(f32(1.0) / C2[2])
-    ex = f32(f32(f32(pKF2.fx * C2[0]) * invz) + pKF2.cx)
-    ey = f32(f32(f32(pKF2.fy * C2[1]) * invz) + pKF2.cy)
-    sigma2 = (pKF2.mvScaleFactors * pKF2.mvScaleFactors).astype(f32)          # mvLevelSigma2, src/ORBextractor.cc:430-436
-    rotHist = [[] for _ in range(HL)]
-    factor = f32(1.0) / f32(HL)
-    common = sorted(set(pKF1.mFeatVec) & set(pKF2.mFeatVec))
-    queries, lists = [], []
-    for node in common:
-        for idx1 in pKF1.mFeatVec[node]:
-            if pKF1.mp_valid[idx1]:
-                continue
-            if bOnlyStereo and not pKF1.mvuRight[idx1] >= 0:
-                continue
-            queries.append(idx1); lists.append(list(pKF2.mFeatVec[node]))
-    dists = _candidate_distances(pKF1.mDescriptors[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF2.mDescriptors, self._context)
-    vMatches12 = np.full(pKF1.N, -1, np.int32)
-    nmatches = 0
-    for qi, idx1 in enumerate(queries):
-        bStereo1 = bool(pKF1.mvuRight[idx1] >= 0)
-        kp1 = pKF1.mvKeysUn[idx1]
-        bestDist, bestIdx2 = self.TH_LOW, -1
-        for idx2, dist in zip(lists[qi], dists[qi]):
-            if pKF2.mp_valid[idx2]:                      # (vbMatched2 is never set in the reference)
-                continue
-            bStereo2 = bool(pKF2.mvuRight[idx2] >= 0)
-            if bOnlyStereo and not bStereo2:
-                continue
-            dist = int(dist)
-            if dist > self.TH_LOW or dist > bestDist:
-                continue
-            kp2 = pKF2.mvKeysUn[idx2]
-            if not bStereo1 and not bStereo2:
-                dx, dy = f32(ex - kp2["x"]), f32(ey - kp2["y"])
-                if f32(f32(dx * dx) + f32(dy * dy)) < f32(f32(100) * pKF2.mvScaleFactors[int(kp2["octave"])]):
-                    continue
-            if _epipolar_ok(kp1, kp2, F12, sigma2):
-                bestIdx2, bestDist = idx2, dist
-        if bestIdx2 >= 0:
-            vMatches12[idx1] = bestIdx2
-            nmatches += 1
-            if self.mbCheckOrientation:
-                rot = f32(kp1["angle"] - pKF2.mvKeysUn["angle"][bestIdx2])
-                if rot < 0.0:
-                    rot = f32(rot + f32(360.0))
-                b = _c_round(f32(rot * factor))
-                if b == HL:
-                    b = 0
-                rotHist[b].append(idx1)
-    if self.mbCheckOrientation:
-        ind = ComputeThreeMaxima(rotHist)
-        for b in range(HL):
-            if b in ind:
-                continue
-            for j in rotHist[b]:
-                vMatches12[j] = -1
-                nmatches -= 1
-    return nmatches, [(int(i), int(vMatches12[i])) for i in range(pKF1.N) if vMatches12[i] >= 0]
+    const bool bOnlyStereo), src/ORBmatcher.cc:659-825 (LocalMapping::CreateNewMapPoints) -> olf_search_for_triangulation.  Cw =
+    pKF1->GetCameraCenter() (default: from pKF1.mTcw); pKF2.mTcw gives R2w / t2w.  Returns (nmatches, vMatchedPairs) with vMatchedPairs =
+    [(idx1, idx2), ...] in idx1 order."""
+    keep = []
+    k1, k2 = _view_c(pKF1, keep), _view_c(pKF2, keep)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    cw = None if Cw is None else np.ascontiguousarray(Cw, np.float32).reshape(3)
+    m12, n = np.full(pKF1.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_for_triangulation(_ctx(self._context).handle, k1, k2, ptr(F), None if cw is None else ptr(cw), int(bool(bOnlyStereo)),
+                                             int(bool(self.mbCheckOrientation)), ptr(m12), ptr(n)), "olf_search_for_triangulation")
+    return int(n[0]), [(int(i), int(m12[i])) for i in range(pKF1.N) if m12[i] >= 0]
 
 
 class MapPointGeom:
@@ -581,73 +389,21 @@ class MapPointGeom:
 
 
 def _fuse_search(self, pKF, vpMapPoints, th=3.0, Ow=None):
-    """The search part of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:827-948:
-    per map point the most similar key point of pKF inside the projection window.  Returns (bestIdx, bestDist) arrays (-1 / 256 where a gate
-    rejects the point).  The reference's loop then fuses when bestDist <= TH_LOW (:950-972: Replace / AddObservation on the map, host
-    code); that mutation never feeds back into another point's search, so the loop body splits exactly there."""
-    f32 = np.float32
+    """The search part of int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:827-948
+    -> olf_fuse_search: per map point the most similar key point of pKF inside the projection window.  Returns (bestIdx, bestDist) arrays
+    (-1 / 256 where a gate rejects the point).  The reference's loop then fuses when bestDist <= TH_LOW (:950-972: Replace / AddObservation
+    on the map, host code); that mutation never feeds back into another point's search, so the loop body splits exactly there."""
     mp = vpMapPoints
-    Rcw, tcw = pKF.mTcw[:3, :3], pKF.mTcw[:3, 3]
-    if Ow is None:
-        Ow = (-(Rcw.T.astype(np.float64) @ tcw.astype(np.float64))).astype(f32)
-    Ow = np.asarray(Ow, f32)
-    nLevels = len(pKF.mvScaleFactors)
-    logScale = _logf(pKF.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
-    sigma2 = (pKF.mvScaleFactors * pKF.mvScaleFactors).astype(f32)
-    invSigma2 = (f32(1.0) / sigma2).astype(f32)                                   # mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]
-    queries, lists, meta = [], [], []
-    for i in range(mp.n):
-        if mp.skip[i]:
-            continue
-        p3Dw = mp.world[i]
-        p3Dc = (Rcw.astype(np.float64) @ p3Dw.astype(np.float64) + tcw.astype(np.float64)).astype(f32)
-        if p3Dc[2] < 0.0:
-            continue
-        invz = f32(f32(1) / p3Dc[2]) if p3Dc[2] != 0 else f32(np.inf)
-        x, y = f32(p3Dc[0] * invz), f32(p3Dc[1] * invz)
-        u, v = f32(f32(pKF.fx * x) + pKF.cx), f32(f32(pKF.fy * y) + pKF.cy)
-        if not (u >= pKF.mnMinX and u < pKF.mnMaxX and v >= pKF.mnMinY and v < pKF.mnMaxY):
-            continue
-        ur = f32(u - f32(pKF.mbf * invz))
-        maxDistance, minDistance = f32(f32(1.2) * mp.maxd[i]), f32(f32(0.8) * mp.mind[i])
-        PO = (p3Dw - Ow).astype(f32)
-        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
-        if dist3D < minDistance or dist3D > maxDistance:
-            continue
-        if float(np.sum(PO.astype(np.float64) * mp.normal[i].astype(np.float64))) < 0.5 * float(dist3D):
-            continue
-        ratio = f32(mp.maxd[i] / dist3D)
-        lvl = int(np.ceil(f32(_logf(ratio) / logScale)))
-        lvl = 0 if lvl < 0 else min(lvl, nLevels - 1)
-        radius = f32(f32(th) * pKF.mvScaleFactors[lvl])
-        idx = pKF.GetFeaturesInArea(u, v, radius)
-        if not idx:
-            continue
-        queries.append(i); lists.append(idx); meta.append((u, v, ur, lvl))
-    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF.mDescriptors, self._context)
-    bestIdx, bestDist = np.full(mp.n, -1, np.int32), np.full(mp.n, 256, np.int32)
-    kx, ky, ko = pKF.mvKeysUn["x"], pKF.mvKeysUn["y"], pKF.mvKeysUn["octave"]
-    for qi, i in enumerate(queries):
-        u, v, ur, lvl = meta[qi]
-        bd, bi = 256, -1
-        for idx, dist in zip(lists[qi], dists[qi]):
-            kpLevel = int(ko[idx])
-            if kpLevel < lvl - 1 or kpLevel > lvl:
-                continue
-            ex, ey = f32(u - kx[idx]), f32(v - ky[idx])
-            if pKF.mvuRight[idx] >= 0:
-                er = f32(ur - pKF.mvuRight[idx])
-                e2 = f32(f32(f32(ex * ex) + f32(ey * ey)) + f32(er * er))
-                if float(f32(e2 * invSigma2[kpLevel])) > 7.8:
-                    continue
-            else:
-                e2 = f32(f32(ex * ex) + f32(ey * ey))
-                if float(f32(e2 * invSigma2[kpLevel])) > 5.99:
-                    continue
-            if int(dist) < bd:
-                bd, bi = int(dist), idx
-        bestIdx[i], bestDist[i] = bi, bd
-    return bestIdx, bestDist
+    keep = []
+    kf = _view_c(pKF, keep)
+    a = np.ascontiguousarray
+    arrs = [a(mp.skip, np.uint8), a(mp.world, np.float32), a(mp.normal, np.float32), a(mp.maxd, np.float32), a(mp.mind, np.float32),
+            a(mp.descriptor, np.uint8)]
+    ow = None if Ow is None else a(Ow, np.float32).reshape(3)
+    bi, bd = np.full(mp.n, -1, np.int32), np.full(mp.n, 256, np.int32)
+    check(lib().olf_fuse_search(_ctx(self._context).handle, kf, mp.n, *(ptr(x) for x in arrs), float(th), None if ow is None else ptr(ow), ptr(bi),
+                                ptr(bd)), "olf_fuse_search")
+    return bi, bd
 
 
 def _scale(m, s):
@@ -673,126 +429,43 @@ def Sim3Decompose(Scw):
     return Rcw, tcw, _gemv(Rcw.T, tcw, alpha=-1.0)
 
 
-def _predict_scale(maxd, dist3D, logScale, nLevels):
-    """MapPoint::PredictScale, src/MapPoint.cc:414-429"""
-    lvl = int(np.ceil(np.float32(_logf(np.float32(maxd / dist3D)) / logScale)))
-    return 0 if lvl < 0 else min(lvl, nLevels - 1)
-
-
-def _project_in_image(KF, p3Dc):
-    """pinhole projection + KeyFrame::IsInImage; (u, v) or None"""
-    f32 = np.float32
-    if p3Dc[2] < 0.0:
-        return None
-    invz = f32(1.0 / np.float64(p3Dc[2])) if p3Dc[2] != 0 else f32(np.inf)
-    x, y = f32(p3Dc[0] * invz), f32(p3Dc[1] * invz)
-    u, v = f32(f32(KF.fx * x) + KF.cx), f32(f32(KF.fy * y) + KF.cy)
-    if not (u >= KF.mnMinX and u < KF.mnMaxX and v >= KF.mnMinY and v < KF.mnMaxY):
-        return None
-    return u, v
-
-
-def _best_in_lists(KF, queries, lists, levels, dists, n, empty):
-    """per query the candidate with octave in [level - 1, level] and the smallest distance (first wins)"""
-    bestIdx, bestDist = np.full(n, -1, np.int32), np.full(n, empty, np.int64)
-    ko = KF.mvKeysUn["octave"]
-    for qi, i in enumerate(queries):
-        bd, bi = empty, -1
-        for idx, dist in zip(lists[qi], dists[qi]):
-            if ko[idx] < levels[qi] - 1 or ko[idx] > levels[qi]:
-                continue
-            if int(dist) < bd:
-                bd, bi = int(dist), idx
-        bestIdx[i], bestDist[i] = bi, bd
-    return bestIdx, bestDist
-
-
 INT_MAX = 2147483647
 
 
 def _fuse_search_sim3(self, pKF, Scw, vpPoints, th):
     """The search part of int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th,
-    vector<MapPoint*> &vpReplacePoint), src/ORBmatcher.cc:977-1102 (loop correction): per point the most similar key point of pKF inside the
-    projection window under the Sim3 pose, (bestIdx, bestDist), (-1, INT_MAX) where a gate rejects the point.  vpPoints.skip =
-    isBad() || spAlreadyFound.count(pMP).  The reference then records a replacement / adds the observation when bestDist <= TH_LOW
-    (:1086-1099, host code on the map)."""
-    f32 = np.float32
+    vector<MapPoint*> &vpReplacePoint), src/ORBmatcher.cc:977-1102 (loop correction) -> olf_fuse_search_sim3: per point the most similar key
+    point of pKF inside the projection window under the Sim3 pose, (bestIdx, bestDist), (-1, INT_MAX) where a gate rejects the point.
+    vpPoints.skip = isBad() || spAlreadyFound.count(pMP).  The reference then records a replacement / adds the observation when
+    bestDist <= TH_LOW (:1086-1099, host code on the map)."""
     mp = vpPoints
-    Rcw, tcw, Ow = Sim3Decompose(Scw)
-    nLevels = len(pKF.mvScaleFactors)
-    logScale = _logf(pKF.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
-    queries, lists, levels = [], [], []
-    for i in range(mp.n):
-        if mp.skip[i]:
-            continue
-        p3Dw = mp.world[i]
-        uv = _project_in_image(pKF, _gemv(Rcw, p3Dw, tcw))
-        if uv is None:
-            continue
-        maxDistance, minDistance = f32(f32(1.2) * mp.maxd[i]), f32(f32(0.8) * mp.mind[i])
-        PO = (p3Dw - Ow).astype(f32)
-        dist3D = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
-        if dist3D < minDistance or dist3D > maxDistance:
-            continue
-        if float(np.sum(PO.astype(np.float64) * mp.normal[i].astype(np.float64))) < 0.5 * float(dist3D):
-            continue
-        lvl = _predict_scale(mp.maxd[i], dist3D, logScale, nLevels)
-        idx = pKF.GetFeaturesInArea(uv[0], uv[1], f32(f32(th) * pKF.mvScaleFactors[lvl]))
-        if not idx:
-            continue
-        queries.append(i); lists.append(idx); levels.append(lvl)
-    dists = _candidate_distances(mp.descriptor[queries] if queries else np.zeros((0, 32), np.uint8), lists, pKF.mDescriptors, self._context)
-    return _best_in_lists(pKF, queries, lists, levels, dists, mp.n, INT_MAX)
+    keep = []
+    kf = _view_c(pKF, keep)
+    a = np.ascontiguousarray
+    S = a(Scw, np.float32).reshape(16)
+    arrs = [a(mp.skip, np.uint8), a(mp.world, np.float32), a(mp.normal, np.float32), a(mp.maxd, np.float32), a(mp.mind, np.float32),
+            a(mp.descriptor, np.uint8)]
+    bi, bd = np.full(mp.n, -1, np.int32), np.full(mp.n, INT_MAX, np.int32)
+    check(lib().olf_fuse_search_sim3(_ctx(self._context).handle, kf, ptr(S), mp.n, *(ptr(x) for x in arrs), float(th), ptr(bi), ptr(bd)),
+          "olf_fuse_search_sim3")
+    return bi, bd.astype(np.int64)
 
 
 def _search_by_sim3(self, pKF1, pKF2, vpMatches12, s12, R12, t12, th):
     """int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
-    const cv::Mat &t12, const float th), src/ORBmatcher.cc:1104-1328.  pKF1 / pKF2: KeyFrameView (mp_valid, mp_bad, mp_world, mp_desc, mp_maxd,
-    mp_mind, mTcw).  vpMatches12: int array over pKF1's features, the index in pKF2 of the feature whose map point is already matched
-    (pMP->GetIndexInKeyFrame(pKF2)), -1 for none, or -2 for "matched to a map point that pKF2 does not observe"; updated in place like the
-    reference's vector.  Returns (nFound, vnMatch1, vnMatch2)."""
-    f32 = np.float32
-    N1, N2 = pKF1.N, pKF2.N
-    m12 = np.asarray(vpMatches12)
-    already1 = m12 != -1
-    already2 = np.zeros(N2, bool)
-    already2[m12[(m12 >= 0) & (m12 < N2)]] = True
-    sR12 = _scale(R12, f32(s12))
-    sR21 = _scale(np.asarray(R12, f32).T, f32(1.0 / np.float64(f32(s12))))
-    t21 = _gemv(sR21, t12, alpha=-1.0)
-    nLevels = len(pKF1.mvScaleFactors)
-    logScale = _logf(pKF1.mvScaleFactors[1]) if nLevels > 1 else f32(1.0)
-    vn = []
-    for src, dst, already, sR, t in ((pKF1, pKF2, already1, sR21, t21), (pKF2, pKF1, already2, sR12, np.asarray(t12, f32).reshape(3))):
-        Rw, tw = src.mTcw[:3, :3], src.mTcw[:3, 3]
-        queries, lists, levels = [], [], []
-        for i in range(src.N):
-            if not src.mp_valid[i] or already[i] or src.mp_bad[i]:
-                continue
-            pb = _gemv(sR, _gemv(Rw, src.mp_world[i], tw), t)
-            uv = _project_in_image(dst, pb)
-            if uv is None:
-                continue
-            maxDistance, minDistance = f32(f32(1.2) * src.mp_maxd[i]), f32(f32(0.8) * src.mp_mind[i])
-            dist3D = f32(np.sqrt(np.sum(pb.astype(np.float64) ** 2)))
-            if dist3D < minDistance or dist3D > maxDistance:
-                continue
-            lvl = _predict_scale(src.mp_maxd[i], dist3D, logScale, nLevels)
-            idx = dst.GetFeaturesInArea(uv[0], uv[1], f32(f32(th) * dst.mvScaleFactors[lvl]))
-            if not idx:
-                continue
-            queries.append(i); lists.append(idx); levels.append(lvl)
-        dists = _candidate_distances(src.mp_desc[queries] if queries else np.zeros((0, 32), np.uint8), lists, dst.mDescriptors, self._context)
-        bi, bd = _best_in_lists(dst, queries, lists, levels, dists, src.N, INT_MAX)
-        vn.append(np.where(bd <= self.TH_HIGH, bi, -1).astype(np.int32))
-    vnMatch1, vnMatch2 = vn
-    nFound = 0
-    for i1 in range(N1):
-        idx2 = vnMatch1[i1]
-        if idx2 >= 0 and vnMatch2[idx2] == i1:
-            vpMatches12[i1] = idx2
-            nFound += 1
-    return nFound, vnMatch1, vnMatch2
+    const cv::Mat &t12, const float th), src/ORBmatcher.cc:1104-1328 -> olf_search_by_sim3.  pKF1 / pKF2: KeyFrameView (mp_valid, mp_bad,
+    mp_world, mp_desc, mp_maxd, mp_mind, mTcw).  vpMatches12: int array over pKF1's features, the index in pKF2 of the feature whose map
+    point is already matched (pMP->GetIndexInKeyFrame(pKF2)), -1 for none, or -2 for "matched to a map point that pKF2 does not observe";
+    updated in place like the reference's vector.  Returns (nFound, vnMatch1, vnMatch2)."""
+    keep = []
+    k1, k2 = _view_c(pKF1, keep), _view_c(pKF2, keep)
+    m12 = np.ascontiguousarray(vpMatches12, np.int32)
+    R, t = np.ascontiguousarray(R12, np.float32).reshape(9), np.ascontiguousarray(t12, np.float32).reshape(3)
+    v1, v2, n = np.full(pKF1.N, -1, np.int32), np.full(pKF2.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_sim3(_ctx(self._context).handle, k1, k2, ptr(m12), float(s12), ptr(R), ptr(t), float(th), ptr(v1), ptr(v2), ptr(n)),
+          "olf_search_by_sim3")
+    vpMatches12[...] = m12
+    return int(n[0]), v1, v2
 
 
 ORBmatcher.SearchForTriangulation = _search_for_triangulation
