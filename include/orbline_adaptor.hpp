@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 #include "orbline.h"
 
@@ -226,6 +227,69 @@ public:
         vpMapPointMatches.assign(F.n, -1);
         int32_t n = 0;
         olf_detail::check(olf_search_by_bow(ctx, &KF, &F, mfNNratio, mbCheckOrientation ? 1 : 0, vpMapPointMatches.data(), &n), "olf_search_by_bow");
+        return n;
+    }
+    // The members of the reference's MapPoints read by the two Fuse searches, gathered into arrays
+    struct FuseMapPoints {
+        int n = 0;
+        const uint8_t* skip = nullptr;             // !pMP || isBad() || IsInKeyFrame(pKF)   (Sim3 form: isBad() || spAlreadyFound.count(pMP))
+        const float* world = nullptr; const float* normal = nullptr; const float* mfMaxDistance = nullptr; const float* mfMinDistance = nullptr;
+        const uint8_t* descriptor = nullptr;
+    };
+    // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist), :1620-1747
+    int SearchByProjection(olf_ctx* ctx, const olf_frame_view& CurrentFrame, const olf_frame_view& KF, const uint8_t* sAlreadyFound, float th,
+                           int ORBdist, std::vector<int32_t>& matches) const
+    {
+        matches.assign(CurrentFrame.n, -1);
+        int32_t n = 0;
+        olf_detail::check(olf_search_by_projection_kf(ctx, &CurrentFrame, &KF, sAlreadyFound, th, ORBdist, mbCheckOrientation ? 1 : 0, matches.data(), &n),
+                          "olf_search_by_projection_kf");
+        return n;
+    }
+    // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), :524-657 (distinguished from the Frame form by the tag)
+    struct KeyFramePair {};
+    int SearchByBoW(olf_ctx* ctx, KeyFramePair, const olf_frame_view& KF1, const olf_frame_view& KF2, std::vector<int32_t>& vpMatches12) const
+    {
+        vpMatches12.assign(KF1.n, -1);
+        int32_t n = 0;
+        olf_detail::check(olf_search_by_bow_kf(ctx, &KF1, &KF2, mfNNratio, mbCheckOrientation ? 1 : 0, vpMatches12.data(), &n), "olf_search_by_bow_kf");
+        return n;
+    }
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo), :659-825
+    int SearchForTriangulation(olf_ctx* ctx, const olf_frame_view& KF1, const olf_frame_view& KF2, const float* F12, bool bOnlyStereo,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs) const
+    {
+        std::vector<int32_t> m12(KF1.n, -1);
+        int32_t n = 0;
+        olf_detail::check(olf_search_for_triangulation(ctx, &KF1, &KF2, F12, nullptr, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), &n),
+                          "olf_search_for_triangulation");
+        vMatchedPairs.clear();
+        for (int i = 0; i < KF1.n; ++i) if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);
+        return n;
+    }
+    // the search of int Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0), :827-948: best key point per map
+    // point; the caller fuses where bestDist <= TH_LOW (:950-972)
+    void FuseSearch(olf_ctx* ctx, const olf_frame_view& KF, const FuseMapPoints& m, float th, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) const
+    {
+        bestIdx.assign(m.n, -1); bestDist.assign(m.n, 256);
+        olf_detail::check(olf_fuse_search(ctx, &KF, m.n, m.skip, m.world, m.normal, m.mfMaxDistance, m.mfMinDistance, m.descriptor, th, nullptr,
+                                          bestIdx.data(), bestDist.data()), "olf_fuse_search");
+    }
+    // the search of int Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint), :977-1102
+    void FuseSearch(olf_ctx* ctx, const olf_frame_view& KF, const float* Scw, const FuseMapPoints& m, float th, std::vector<int32_t>& bestIdx,
+                    std::vector<int32_t>& bestDist) const
+    {
+        bestIdx.assign(m.n, -1); bestDist.assign(m.n, 2147483647);
+        olf_detail::check(olf_fuse_search_sim3(ctx, &KF, Scw, m.n, m.skip, m.world, m.normal, m.mfMaxDistance, m.mfMinDistance, m.descriptor, th,
+                                               bestIdx.data(), bestDist.data()), "olf_fuse_search_sim3");
+    }
+    // int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th), :1104-1328
+    int SearchBySim3(olf_ctx* ctx, const olf_frame_view& KF1, const olf_frame_view& KF2, std::vector<int32_t>& vpMatches12, float s12, const float* R12,
+                     const float* t12, float th) const
+    {
+        std::vector<int32_t> v1(KF1.n), v2(KF2.n);
+        int32_t n = 0;
+        olf_detail::check(olf_search_by_sim3(ctx, &KF1, &KF2, vpMatches12.data(), s12, R12, t12, th, v1.data(), v2.data(), &n), "olf_search_by_sim3");
         return n;
     }
     float mfNNratio;

@@ -29,7 +29,17 @@ int main()
         try { m.SearchByProjection(nullptr, f, f, 7.f, false, matches); } catch (const std::runtime_error&) { ++thrown; }
         try { m.SearchByProjection(nullptr, f, mps, 1.f, matches); } catch (const std::runtime_error&) { ++thrown; }
         try { m.SearchByBoW(nullptr, f, f, matches); } catch (const std::runtime_error&) { ++thrown; }
-        if (thrown != 3) return 6;
+        ORB_SLAM2::ORBmatcher::FuseMapPoints fm;
+        std::vector<std::pair<size_t, size_t>> pairs;
+        std::vector<int32_t> bi, bd;
+        const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0}, I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        try { m.SearchByProjection(nullptr, f, f, nullptr, 10.f, 100, matches); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.SearchByBoW(nullptr, ORB_SLAM2::ORBmatcher::KeyFramePair(), f, f, matches); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.SearchForTriangulation(nullptr, f, f, I9, false, pairs); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.FuseSearch(nullptr, f, fm, 3.f, bi, bd); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.FuseSearch(nullptr, f, I16, fm, 4.f, bi, bd); } catch (const std::runtime_error&) { ++thrown; }
+        try { m.SearchBySim3(nullptr, f, f, matches, 1.f, I9, z3, 7.5f); } catch (const std::runtime_error&) { ++thrown; }
+        if (thrown != 9) return 6;
     }
     std::printf("ADAPTOR_OK\n");
     return 0;
