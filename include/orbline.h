@@ -198,6 +198,13 @@ int olf_search_local_map(olf_ctx* ctx, const olf_frame_view* f, int n_mp, const 
                          const int32_t* track_scale_level, const float* track_view_cos, const float* track_proj3, const uint8_t* mp_desc,
                          const uint8_t* mp_obs, float th, float nnratio, int32_t* matches, int32_t* nmatches);
 
+/* bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit), src/Frame.cc:388-444, for n_mp map points at once (host arithmetic, no
+ * device work): the producer of olf_search_local_map's inputs in Tracking::SearchLocalPoints (src/Tracking.cc:1900-1945).  f supplies mTcw,
+ * the calibration, the image bounds and mvScaleFactors.  Outputs per point: mbTrackInView, mnTrackScaleLevel, mTrackViewCos and
+ * (mTrackProjX, mTrackProjY, mTrackProjXR); a point that fails a gate only gets track_in_view = 0. */
+int olf_is_in_frustum(const olf_frame_view* f, int n_mp, const float* world, const float* normal, const float* maxd, const float* mind,
+                      float viewing_cos_limit, uint8_t* track_in_view, int32_t* track_scale_level, float* track_view_cos, float* track_proj3);
+
 /* ---- the LocalMapping / LoopClosing / relocalisation searches, same split (host candidates, GPU distances, host resolution) ----
  * int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
  * const int ORBdist), src/ORBmatcher.cc:1620-1747.  already_found[i] = sAlreadyFound.count(pKF's i-th map point) (may be NULL);

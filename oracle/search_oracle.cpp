@@ -470,6 +470,46 @@ extern "C" void orc_fuse_search(const olf_keypoint* keys, const uint8_t* desc, c
     }
 }
 
+// Frame::isInFrustum, src/Frame.cc:388-444, over arrays of map points (GetMaxDistanceInvariance = 1.2f * mfMaxDistance,
+// GetMinDistanceInvariance = 0.8f * mfMinDistance, src/MapPoint.cc:402-412; PredictScale :414-429)
+extern "C" void orc_is_in_frustum(const float* Tcw, const float* cam9, const float* scaleFactors, int nLevels, float logScaleFactor, int nMP,
+                                  const float* world, const float* normal, const float* maxd, const float* mind, float viewingCosLimit,
+                                  uint8_t* inView, int* level, float* viewCosOut, float* proj3)
+{
+    using namespace orc;
+    const Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    float mOw[3];
+    for (int r = 0; r < 3; ++r) {                                  // mOw = -mRcw.t() * mtcw
+        double acc = 0;
+        for (int k = 0; k < 3; ++k) acc += (double)Tcw[4 * k + r] * (double)Tcw[4 * k + 3];
+        mOw[r] = (float)(-acc);
+    }
+    for (int i = 0; i < nMP; ++i) {
+        inView[i] = 0;
+        const float* P = world + 3 * i;
+        float Pc[3];
+        mat3_mul_add(Tcw, P, Pc);
+        if (Pc[2] < 0.0f) continue;
+        const float invz = 1.0f / Pc[2];
+        const float u = c.fx * Pc[0] * invz + c.cx;
+        const float v = c.fy * Pc[1] * invz + c.cy;
+        if (u < c.minX || u > c.maxX) continue;
+        if (v < c.minY || v > c.maxY) continue;
+        const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+        double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { const float po = P[k] - mOw[k]; nrm += (double)po * po; dot += (double)po * (double)normal[3 * i + k]; }
+        const float dist = (float)std::sqrt(nrm);
+        if (dist < minDistance || dist > maxDistance) continue;
+        const float viewCos = (float)(dot / dist);
+        if (viewCos < viewingCosLimit) continue;
+        const float ratio = maxd[i] / dist;
+        int nScale = (int)std::ceil(std::log(ratio) / logScaleFactor);
+        if (nScale < 0) nScale = 0; else if (nScale >= nLevels) nScale = nLevels - 1;
+        inView[i] = 1; level[i] = nScale; viewCosOut[i] = viewCos;
+        proj3[3 * i] = u; proj3[3 * i + 1] = v; proj3[3 * i + 2] = u - c.mbf * invz;
+    }
+}
+
 // ---- Sim3 searches of the loop closer -------------------------------------------------------------------------------------------
 // cv::Mat scalar algebra used below (CV_32F): `M / s` and `s * M` are MatExpr scalings evaluated by convertTo, i.e. every element times
 // the double factor rounded to float ((float)(1.0 / s), (float)s); Mat::dot accumulates float products in double; `-A*b` is a gemm with

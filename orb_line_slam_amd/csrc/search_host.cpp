@@ -391,6 +391,48 @@ bool project_in_image(const olf_frame_view& K, const float* p3Dc, float& u, floa
 
 extern "C" {
 
+int olf_is_in_frustum(const olf_frame_view* f, int n_mp, const float* world, const float* normal, const float* maxd, const float* mind,
+                      float viewing_cos_limit, uint8_t* track_in_view, int32_t* track_scale_level, float* track_view_cos, float* track_proj3)
+{
+    if (!f || !f->Tcw || !f->scale_factors || f->n_levels < 1 || n_mp < 0 ||
+        (n_mp && (!world || !normal || !maxd || !mind || !track_in_view || !track_scale_level || !track_view_cos || !track_proj3))) {
+        set_error("olf_is_in_frustum: bad argument"); return OLF_ERR_INVALID;
+    }
+    float Ow[3];
+    camera_centre(f->Tcw, Ow);                                   // mOw, Frame::UpdatePoseMatrices (src/Frame.cc:380-386)
+    const float logSF = log_scale_factor(*f);
+    for (int i = 0; i < n_mp; ++i) {
+        track_in_view[i] = 0;
+        const float* P = world + 3 * (size_t)i;
+        // 3D in camera coordinates
+        float Pc[3];
+        rot_apply(f->Tcw, P, 1.0f, Pc);
+        const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+        // Check positive depth
+        if (PcZ < 0.0f) continue;
+        // Project in image and check it is not outside
+        const float invz = 1.0f / PcZ;
+        const float u = f->fx * PcX * invz + f->cx, v = f->fy * PcY * invz + f->cy;
+        if (u < f->minX || u > f->maxX) continue;
+        if (v < f->minY || v > f->maxY) continue;
+        // Check distance is in the scale invariance region of the MapPoint
+        const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+        float PO[3]; double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { PO[k] = P[k] - Ow[k]; nrm += (double)PO[k] * (double)PO[k]; dot += (double)PO[k] * (double)normal[3 * (size_t)i + k]; }
+        const float dist = (float)std::sqrt(nrm);
+        if (dist < minDistance || dist > maxDistance) continue;
+        // Check viewing angle
+        const float viewCos = (float)(dot / dist);
+        if (viewCos < viewing_cos_limit) continue;
+        // Predict scale in the image; data used by the tracking
+        track_scale_level[i] = predict_scale(maxd[i], dist, logSF, f->n_levels);
+        track_in_view[i] = 1;
+        track_proj3[3 * (size_t)i] = u; track_proj3[3 * (size_t)i + 1] = v; track_proj3[3 * (size_t)i + 2] = u - f->mbf * invz;
+        track_view_cos[i] = viewCos;
+    }
+    return OLF_OK;
+}
+
 int olf_search_by_projection_kf(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* kf, const uint8_t* already_found, float th,
                                 int orb_dist, int check_orientation, int32_t* matches, int32_t* nmatches)
 {

@@ -299,6 +299,23 @@ class MapPointView:
         self.mbTrackInView, self.isBad, self.obs = b(mbTrackInView, True), b(isBad, False), b(obs, True)
 
 
+def isInFrustum(F, vpMapPoints, viewingCosLimit=0.5):
+    """bool Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit), src/Frame.cc:388-444, for every point of a MapPointGeom (world, normal,
+    maxd = mfMaxDistance, mind = mfMinDistance, descriptor) -> olf_is_in_frustum (host arithmetic in the library).  Returns the MapPointView
+    that SearchByProjection(Frame, vector<MapPoint*>) reads: mbTrackInView, mnTrackScaleLevel, mTrackViewCos, mTrackProjX / Y / XR."""
+    mp = vpMapPoints
+    keep = []
+    f = _view_c(F, keep)
+    a = np.ascontiguousarray
+    inview, level = np.zeros(mp.n, np.uint8), np.zeros(mp.n, np.int32)
+    cosv, proj3 = np.zeros(mp.n, np.float32), np.zeros((mp.n, 3), np.float32)
+    arrs = [a(mp.world, np.float32), a(mp.normal, np.float32), a(mp.maxd, np.float32), a(mp.mind, np.float32)]
+    check(lib().olf_is_in_frustum(f, mp.n, *(ptr(x) for x in arrs), float(viewingCosLimit), ptr(inview), ptr(level), ptr(cosv), ptr(proj3)),
+          "olf_is_in_frustum")
+    return MapPointView(mp.descriptor, proj3[:, 0].copy(), proj3[:, 1].copy(), proj3[:, 2].copy(), level, cosv, mbTrackInView=inview.astype(bool),
+                        isBad=mp.skip)
+
+
 def _search_local_map(self, F, vpMapPoints, th=1.0):
     """int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th), src/ORBmatcher.cc:47-131
     (Tracking::SearchLocalPoints, every frame) -> olf_search_local_map.  Returns (nmatches, matches) with matches[idx] = index into

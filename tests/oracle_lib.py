@@ -469,3 +469,15 @@ def search_by_sim3(kf1, kf2, matches12, s12, R12, t12, th):
     res = m12.copy()
     res[out >= 0] = out[out >= 0]
     return n, v1, v2, res
+
+
+def is_in_frustum(f, mp, viewing_cos_limit):
+    """f: FrameView (mTcw, calibration, bounds, mvScaleFactors); mp: MapPointGeom -> (inView, level, viewCos, proj3)"""
+    a = np.ascontiguousarray
+    cam, sf = _cam(f), a(f.mvScaleFactors)
+    inv, lvl = np.zeros(mp.n, np.uint8), np.zeros(mp.n, np.int32)
+    cosv, proj = np.zeros(mp.n, np.float32), np.zeros((mp.n, 3), np.float32)
+    arrs = [a(f.mTcw, np.float32), a(mp.world), a(mp.normal), a(mp.maxd), a(mp.mind)]
+    _L.orc_is_in_frustum(_p(arrs[0]), _p(cam), _p(sf), len(sf), _logsf(sf), mp.n, _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
+                         C.c_float(viewing_cos_limit), _p(inv), _p(lvl), _p(cosv), _p(proj))
+    return inv.astype(bool), lvl, cosv, proj

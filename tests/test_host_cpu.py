@@ -234,3 +234,32 @@ def test_default_params_match_reference_config():
             "lsd_nfeatures": p.line.lsd_nfeatures}
     for k, v in want.items():
         assert np.float32(y[k]) == np.float32(v), (k, v, y[k])
+
+
+def test_is_in_frustum_matches_oracle():
+    """Frame::isInFrustum over arrays (host arithmetic inside the product library, no device): every gate and every output bit against the
+    oracle's restatement, on points scattered around the frustum so that each gate fires"""
+    import orb_line_slam_amd as ola
+    from orb_line_slam_amd import matcher
+    import oracle_lib as oracle
+    rng = np.random.default_rng(17)
+    n = 20000
+    kp = np.zeros(4, ola.KEYPOINT_DTYPE)
+    f = ola.FrameView(kp, np.zeros((4, 32), np.uint8), None, np.float32(1.2) ** np.arange(8, dtype=np.float32), bounds=(0.0, 1241.0, 0.0, 376.0))
+    f.mTcw = np.eye(4, dtype=np.float32)
+    f.mTcw[:3, :3] = np.array([[0.9998, -0.01, 0.015], [0.0101, 0.9999, -0.005], [-0.0149, 0.0052, 0.9999]], np.float32)
+    f.mTcw[:3, 3] = np.array([0.3, -0.1, 0.5], np.float32)
+    world = np.stack([rng.uniform(-40, 40, n), rng.uniform(-12, 12, n), rng.uniform(-5, 60, n)], 1).astype(np.float32)
+    d = np.linalg.norm(world, axis=1).astype(np.float32)
+    normal = (world / np.maximum(d, 1e-3)[:, None] + rng.normal(0, 0.6, world.shape)).astype(np.float32)
+    maxd = (d * rng.uniform(0.5, 4.0, n)).astype(np.float32)
+    mind = (maxd / np.float32(1.2) ** 7 * rng.uniform(0.5, 1.5, n)).astype(np.float32)
+    mp = ola.MapPointGeom(world, normal, maxd, mind, np.zeros((n, 32), np.uint8))
+    for lim in (0.5, 0.0):
+        oi, ol, oc, op = oracle.is_in_frustum(f, mp, lim)
+        v = matcher.isInFrustum(f, mp, lim)
+        assert np.array_equal(v.mbTrackInView, oi) and 0.02 * n < oi.sum() < 0.9 * n
+        assert np.array_equal(v.mnTrackScaleLevel[oi], ol[oi]) and len(np.unique(ol[oi])) == 8
+        assert np.array_equal(v.mTrackViewCos[oi].view(np.uint32), oc[oi].view(np.uint32))
+        for k, arr in enumerate((v.mTrackProjX, v.mTrackProjY, v.mTrackProjXR)):
+            assert np.array_equal(arr[oi].view(np.uint32), op[oi, k].view(np.uint32))
