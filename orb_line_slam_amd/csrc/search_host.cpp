@@ -1,11 +1,14 @@
-// search_host.cpp -- host side of the per-frame ORBmatcher searches behind the C ABI (olf_search_by_projection, olf_search_by_bow,
-// olf_search_local_map).  Split of the reference's loops, as SURVEY 8(b) / App. C.7 prescribe:
+// search_host.cpp -- host side of the ORBmatcher searches behind the C ABI: the three every-frame ones (olf_search_by_projection,
+// olf_search_by_bow, olf_search_local_map, fed by olf_is_in_frustum) and the relocalisation / LocalMapping / LoopClosing ones
+// (olf_search_by_projection_kf, olf_search_by_bow_kf, olf_search_for_triangulation, olf_fuse_search, olf_fuse_search_sim3,
+// olf_search_by_sim3).  Split of the reference's loops, as SURVEY 8(b) / App. C.7 prescribe:
 //   1. candidate generation on the host, exactly as the reference walks them (Frame::GetFeaturesInArea over the 64 x 48 grid,
 //      src/Frame.cc:517-570; the merge of two DBoW2 feature vectors, src/ORBmatcher.cc:176-203),
 //   2. every DescriptorDistance of the search in one k_match_candidates launch (match.hip),
 //   3. the reference's greedy resolution, which depends on the map points assigned so far, on the host in the reference's order.
-// Float expressions are written as the reference writes them (src/ORBmatcher.cc, float unless a double literal promotes them); the
-// library is built with -ffp-contract=off.
+// Map mutations (MapPoint::Replace / AddObservation in the Fuse functions) stay with the caller: they never feed back into a search.
+// Float expressions are written as the reference writes them (src/ORBmatcher.cc, float unless a double literal promotes them); cv::Mat
+// products of CV_32F operands accumulate in double and round once; the library is built with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
