@@ -693,10 +693,9 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
-    // fork: the line path runs beside the ORB path (the reference's 4 extraction threads, src/Frame.cc:164-171)
-    // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171): the LSD
-    // agents are long latency-bound waves that need only 64 VGPRs, so the ORB kernels fill the issue slots and registers they leave idle
-    // (7.8k vs 6.5k stereo frames/s at 2048 pairs).  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
+    // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  The two
+    // sides cannot really share a SIMD while all growth agents are resident; the second stream mainly fills the agents'
+    // ragged tail with ORB work.  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
     static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
     if (one_stream) {
         OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
