@@ -31,6 +31,7 @@ struct olf_ctx {
     float* d_depth = nullptr;
     int* d_sad = nullptr;
     int* d_bestkey = nullptr;
+    unsigned* d_rowperm = nullptr; // [max_images][outCap] key point lists ordered by row (stereo candidate search)
     // line side
     LineHostTables line;
     LineDeviceBufs lb;
@@ -178,7 +179,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
     A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 64);
-    A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap); A(c->d_bestkey, ((n + 1) / 2) * g.outCap);
+    A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap); A(c->d_bestkey, ((n + 1) / 2) * g.outCap); A(c->d_rowperm, n * g.outCap);
     A(c->d_images, n * width * height); A(c->d_kps, n * g.outCap); A(c->d_desc, n * g.outCap * OLF_DESC_BYTES); A(c->d_counts, n);
 #undef A
     if (hipMemcpy(b.rx, c->orb.rx.data(), c->orb.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
@@ -403,7 +404,7 @@ int olf_stereo_points_dev(olf_ctx* c, int n_pairs, const olf_keypoint* d_kps, co
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     StageScope t(c, s, ST_STEREO_POINTS);
     return launch_stereo_points(c->orb.geom, c->ob, n_pairs, d_kps, d_desc, d_counts, c->orb.geom.outCap, c->params.stereo.bf,
-                                c->params.stereo.fx, d_uright, d_depth, c->d_sad, c->d_bestkey, s);
+                                c->params.stereo.fx, d_uright, d_depth, c->d_sad, c->d_bestkey, c->d_rowperm, s);
 }
 
 int olf_stereo_points(olf_ctx* c, const uint8_t* images, int n_pairs, olf_keypoint* kps, uint8_t* desc, int32_t* counts, float* uright,

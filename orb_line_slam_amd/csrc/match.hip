@@ -25,43 +25,94 @@ constexpr int TH_HIGH = 100, TH_LOW = 50;
 // disparity-range gates.  best = min (distance, iR): the reference scans candidates in increasing iR with a strict '<'.
 constexpr int ST_TILE = 128;
 
+// Both key point lists of a pair ordered by image row ((int)y << 16 | index, ascending): a block of the candidate search then covers a
+// narrow band of left rows and only has to look at the right key points whose rows can reach it.
+__global__ __launch_bounds__(256) void k_stereo_rowsort(const olf_keypoint* __restrict__ kps, const int* __restrict__ counts, int cap, int sortN,
+                                                        unsigned* __restrict__ perm)
+{
+    extern __shared__ unsigned keys[];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = counts[img];
+    for (int i = tid; i < sortN; i += 256) {
+        unsigned k = 0xffffffffu;
+        if (i < n) k = ((unsigned)min(max((int)kps[(size_t)img * cap + i].y, 0), 65534) << 16) | (unsigned)i;
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned a = keys[i], b = keys[ixj];
+                    const bool asc = (i & k) == 0;
+                    if (asc ? (a > b) : (a < b)) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 256) perm[(size_t)img * cap + i] = keys[i];
+}
+
 __global__ __launch_bounds__(256) void k_stereo_cand(const OrbGeom* __restrict__ gp, const olf_keypoint* __restrict__ kps,
                                                      const uint8_t* __restrict__ desc, const int* __restrict__ counts, int cap, float mbf,
-                                                     float fx, unsigned* __restrict__ bestKey)
+                                                     float fx, const unsigned* __restrict__ perm, unsigned* __restrict__ bestKey)
 {
     __shared__ uint4 s_d[ST_TILE * 2];
     __shared__ int s_rows[ST_TILE];      // minr | maxr << 16
     __shared__ int s_oct[ST_TILE];
     __shared__ float s_x[ST_TILE];
+    __shared__ int s_idx[ST_TILE];
+    __shared__ int s_range[2];
     const OrbGeom& g = *gp;
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 256 + threadIdx.x;
+    const int tL = blockIdx.x * 256 + threadIdx.x;           // position in the row-sorted left list
     const int nL = counts[2 * pair], nR = counts[2 * pair + 1];
     if (blockIdx.x * 256 >= nL) return;
     const size_t oL = (size_t)(2 * pair) * cap, oR = (size_t)(2 * pair + 1) * cap;
-    const bool live = iL < nL;
-    olf_keypoint kL = kps[oL + (live ? iL : 0)];
-    const uint4* dLp = reinterpret_cast<const uint4*>(desc + (oL + (live ? iL : 0)) * OLF_DESC_BYTES);
+    const unsigned* pL = perm + oL;
+    const unsigned* pR = perm + oR;
+    const bool live = tL < nL;
+    const int iL = (int)(pL[live ? tL : 0] & 0xffffu);
+    olf_keypoint kL = kps[oL + iL];
+    const uint4* dLp = reinterpret_cast<const uint4*>(desc + (oL + iL) * OLF_DESC_BYTES);
     const uint4 a0 = dLp[0], a1 = dLp[1];
     const int levelL = kL.octave, row = (int)kL.y;
     const float mb = f_div(mbf, fx);
     const float maxD = f_div(mbf, mb);
     const float minU = f_sub(kL.x, maxD), maxU = kL.x;
     unsigned best = ((unsigned)TH_HIGH << 16) | 0xffffu;
-    for (int t0 = 0; t0 < nR; t0 += ST_TILE) {
-        const int cnt = min(ST_TILE, nR - t0);
+    if (threadIdx.x == 0) {
+        // right key points whose band (row +- 2 * scale, rounded outwards) can contain one of this block's rows: a superset, the exact
+        // test stays below
+        const int rad = (int)ceilf(f_mul(2.0f, g.lv[g.nlevels - 1].scale)) + 2;
+        const int first = (int)blockIdx.x * 256, last = min(first + 255, nL - 1);
+        const int rlo = (int)(pL[first] >> 16) - rad, rhi = (int)(pL[last] >> 16) + rad;
+        int lo = 0, hi = nR;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(pR[m] >> 16) < rlo) lo = m + 1; else hi = m; }
+        s_range[0] = lo;
+        hi = nR;
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((int)(pR[m] >> 16) <= rhi) lo = m + 1; else hi = m; }
+        s_range[1] = lo;
+    }
+    __syncthreads();
+    const int jlo = s_range[0], jhi = s_range[1];
+    for (int t0 = jlo; t0 < jhi; t0 += ST_TILE) {
+        const int cnt = min(ST_TILE, jhi - t0);
         __syncthreads();
         if (threadIdx.x < cnt) {
-            const olf_keypoint kR = kps[oR + t0 + threadIdx.x];
+            const int iR = (int)(pR[t0 + threadIdx.x] & 0xffffu);
+            const olf_keypoint kR = kps[oR + iR];
             const float r = f_mul(2.0f, g.lv[kR.octave].scale);
             const int maxr = (int)ceilf(f_add(kR.y, r)), minr = (int)floorf(f_sub(kR.y, r));
             s_rows[threadIdx.x] = (minr & 0xffff) | (maxr << 16);
             s_oct[threadIdx.x] = kR.octave;
             s_x[threadIdx.x] = kR.x;
+            s_idx[threadIdx.x] = iR;
         }
-        {
-            const uint4* dRp = reinterpret_cast<const uint4*>(desc + (oR + t0) * OLF_DESC_BYTES);
-            if (threadIdx.x < 2 * cnt) s_d[threadIdx.x] = dRp[threadIdx.x];
+        if (threadIdx.x < 2 * cnt) {
+            const int iR = (int)(pR[t0 + (threadIdx.x >> 1)] & 0xffffu);
+            s_d[threadIdx.x] = reinterpret_cast<const uint4*>(desc + (oR + iR) * OLF_DESC_BYTES)[(int)(threadIdx.x & 1)];
         }
         __syncthreads();
         for (int j = 0; j < cnt; ++j) {
@@ -73,7 +124,7 @@ __global__ __launch_bounds__(256) void k_stereo_cand(const OrbGeom* __restrict__
             const float xr = s_x[j];
             if (!(xr >= minU && xr <= maxU)) continue;
             const unsigned d = (unsigned)ham256(a0, a1, s_d[2 * j], s_d[2 * j + 1]);
-            best = min(best, (d << 16) | (unsigned)(t0 + j));
+            best = min(best, (d << 16) | (unsigned)s_idx[j]);       // min over (distance, iR): the reference scans iR upwards with a strict '<'
         }
     }
     if (live) bestKey[(size_t)pair * cap + iL] = best;
@@ -483,11 +534,16 @@ int launch_distinctive(const uint8_t* desc, const int* offs, int n_points, int* 
 // ---------------------------------------------------------------------------------------------
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
                          const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, int* d_bestKey,
-                         hipStream_t s)
+                         unsigned* d_perm /* [2 * n_pairs][cap] */, hipStream_t s)
 {
+    if (cap > 65534) { set_error("stereo points: more than 65534 key points per image"); return OLF_ERR_CAPACITY; }   // 16-bit indices in the keys
     // d_sad doubles as the (distance, index) scratch of the candidate search until k_stereo_match overwrites it per key point
     unsigned* bestKey = reinterpret_cast<unsigned*>(d_bestKey);
-    hipLaunchKernelGGL(k_stereo_cand, dim3((cap + 255) / 256, n_pairs), dim3(256), 0, s, b.geom, d_kps, d_desc, d_counts, cap, mbf, fx, bestKey);
+    int sortK = 64;
+    while (sortK < cap) sortK <<= 1;
+    hipLaunchKernelGGL(k_stereo_rowsort, dim3(2 * n_pairs), dim3(256), sortK * sizeof(unsigned), s, d_kps, d_counts, cap, sortK, d_perm);
+    hipLaunchKernelGGL(k_stereo_cand, dim3((cap + 255) / 256, n_pairs), dim3(256), 0, s, b.geom, d_kps, d_desc, d_counts, cap, mbf, fx, d_perm,
+                       bestKey);
     hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, b.geom, b.pyr, d_kps, d_desc, d_counts, cap, mbf,
                        fx, bestKey, d_uRight, d_depth, d_sad);
     int sortN = 64;

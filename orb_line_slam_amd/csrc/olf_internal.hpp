@@ -132,7 +132,7 @@ int launch_remap_linear(const uint8_t* src, int sw, int sh, const float* mapx, c
 // match.hip
 int launch_stereo_points(const OrbGeom& g, const OrbDeviceBufs& b, int n_pairs, const olf_keypoint* d_kps, const uint8_t* d_desc,
                          const int* d_counts, int cap, float mbf, float fx, float* d_uRight, float* d_depth, int* d_sad, int* d_bestKey,
-                         hipStream_t s);
+                         unsigned* d_perm, hipStream_t s);
 int launch_match_bf(const uint8_t* dA, const int* nA, int strideA, int aStep, const uint8_t* dB, const int* nB, int strideB, int bStep,
                     int n_sets, float nnr, int best_lr, int* ws, int* m12, hipStream_t s);
 int launch_knn2(const uint8_t* dA, const int* nA, int strideA, const uint8_t* dB, const int* nB, int strideB, int n_sets, int* idx0,
