@@ -114,10 +114,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, B = args.width, args.height, args.pairs
-    # the batch lives in HBM (context buffers + outputs, about 55 MB per KITTI pair): shrink it if this GPU has less free memory than the
+    # the batch lives in HBM (context buffers + outputs, about 62 MB per KITTI pair): shrink it if this GPU has less free memory than the
     # default batch needs, and use the same size on every rank
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    per_pair = 55e6 * (W * H) / (1242 * 375)
+    per_pair = 62e6 * (W * H) / (1242 * 375)
     fit = int((free_b - 6e9) / per_pair) // 256 * 256
     if fit < B:
         print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 256)}", file=sys.stderr, flush=True)

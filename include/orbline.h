@@ -120,6 +120,9 @@ int olf_orb_pyramid_level(olf_ctx* ctx, int image, int level, int blurred, uint8
 int olf_orb_debug_candidates(olf_ctx* ctx, int image, int level, int32_t* xys, int cap, int32_t* count);
 /* debug: the context's 64-int device status block (overflow flags in [0]; instrumented builds put cycle counters at [16..31]). */
 int olf_debug_status(olf_ctx* ctx, int32_t* out64);
+/* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
+ * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
+int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
 /* debug/test: the LSD agent's unscaled exact float division against IEEE division on blocks*256*per_thread pseudo-random operand pairs
  * from its operand range; *mismatches = number of quotients that differ in any bit (must be 0). */
 int olf_debug_fdiv_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread, uint64_t* mismatches);

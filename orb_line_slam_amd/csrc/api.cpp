@@ -199,7 +199,9 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     LineDeviceBufs& l = c->lb;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
-    A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n); A(l.region, n * lg.Ps);
+    A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n);
+    l.nChunks = 512 + lg.Ps / 32 + 64;
+    A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
     A(l.angDeg, (size_t)1 << 22); A(l.cosSin, (size_t)1 << 22); A(l.seedCS, (size_t)1 << 22);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
@@ -363,6 +365,15 @@ int olf_debug_status(olf_ctx* c, int32_t* out64)
     if (!c || !out64) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipDeviceSynchronize());
     OLF_HIP_CHECK(hipMemcpy(out64, c->ob.status, 256, hipMemcpyDeviceToHost));
+    return OLF_OK;
+}
+
+int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
+{
+    const bool pow2 = rob_entries > 0 && (rob_entries & (rob_entries - 1)) == 0;
+    if (!c || waves_per_image > 16 || (rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512))) { set_error("olf_debug_lsd_waves: bad argument"); return OLF_ERR_INVALID; }
+    c->lb.forceNW = waves_per_image;
+    c->lb.forceE = rob_entries;
     return OLF_OK;
 }
 

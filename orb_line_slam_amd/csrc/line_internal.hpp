@@ -68,6 +68,11 @@ struct LineDeviceBufs {
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
     double2* cosSin = nullptr;     // [2^22] cos / sin of that angle as the reference evaluates them for an added pixel (float-rounded argument)
     float2* seedCS = nullptr;      // [2^22] (float)cos / (float)sin of the unrounded angle: the sums a region starts with
+    uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
+    int* links = nullptr;          // [n][nChunks] next chunk of a region's pixel list (-1: last)
+    int nChunks = 0;               // 32-pixel chunks per image in `region` (ids < 512: the ROB slots' own chunks, then the pool)
+    int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic
+    bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
 };
 
 struct LineHostTables {

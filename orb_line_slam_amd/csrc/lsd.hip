@@ -12,23 +12,11 @@
 // only the accept chain is serial -- run as speculative rounds that need one fastAtan2 per round instead of one per accepted pixel.
 // Regions that are large enough are logged and fitted afterwards, in parallel, by k_lsd_rect / k_lsd_emit (region2rect + KeyLine).
 // Parallelism comes from the batch: thousands of images in flight, up to 8 agents per SIMD.
-#include "line_internal.hpp"
-#include "device_math.hpp"
+#include "lsd_device.hpp"
 #include <rocprim/rocprim.hpp>
 
 namespace olf {
 
-constexpr double kPI = 3.1415926535897932384626433832795;
-constexpr double kDegToRads = kPI / 180;
-constexpr double kM32PI = (3 * kPI) / 2, kM2PI = 2 * kPI;
-// grad word: bits 0-10 gx, 11-21 gy (11-bit two's complement, |g| <= 510), bit 30 NOTDEF, bit 31 USED
-constexpr unsigned kNotDef = 0x40000000u, kUsed = 0x80000000u, kIso = 0x00400000u;   // bit 22: no neighbour is aligned with this pixel
-__device__ __forceinline__ int unpack_gx(uint32_t p) { return ((int)(p << 21)) >> 21; }
-__device__ __forceinline__ int unpack_gy(uint32_t p) { return ((int)(p << 10)) >> 21; }
-
-// one grown region that is large enough to be fitted: its pixels are region[start .. start + n) in growth order
-struct RegionRec { int start, n; double angle; };
-__device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0x7ffu) | (((uint32_t)gy & 0x7ffu) << 11); }
 
 __device__ __forceinline__ int refl101(int p, int n)
 {
@@ -144,7 +132,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // bits with a stable sort: equal bins stay in raster order, which is the reference's list order.
 __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
-                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf, const float* __restrict__ angDeg)
+                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf, const float* __restrict__ angDeg,
+                                                  uint32_t* __restrict__ owner)
 {
     constexpr int SPAN = LG_CHUNK / 4;
     __shared__ uint32_t s_keys[LG_CHUNK];
@@ -178,6 +167,7 @@ __global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ g
                 def = true;
                 // level-line angle (degrees) of the defined pixel, kept for k_lsd_iso in the (not yet used) FIFO buffer
                 degbuf[(size_t)img * g.Ps + idx] = __float_as_uint(angDeg[p & 0x3fffffu]);      // fastAtan2(gx, -gy), tabulated per context
+                owner[(size_t)img * g.Ps + idx] = 0xffffffffu;                                   // nobody has claimed the pixel (lsd_grow.hip)
             }
         }
         const unsigned long long m = __ballot(def);
@@ -243,12 +233,6 @@ __global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double shfl_d(double v, int l)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl(lo, l); hi = __shfl(hi, l);
-    return __hiloint2double(hi, lo);
-}
 
 __device__ __forceinline__ double grad_angle(int gx, int gy) { return d_mul((double)dev_fastAtan2((float)gx, (float)(-gy)), kDegToRads); }
 
@@ -319,38 +303,6 @@ int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
     return OLF_OK;
 }
 
-// a / b for 0 <= a <= b, b in the normal range and far from overflow (the agent's sums): v_rcp_f32 refined by two Newton steps on the
-// reciprocal and two residual corrections on the quotient -- the core of the IEEE division expansion (correctly rounded for any
-// reciprocal seed within 1 ulp) without the range scaling (v_div_scale / v_div_fixup) that these operands never need.
-// tests/test_device_math_gpu.py compares it with the compiler's IEEE division on 2^30 operand pairs.
-__device__ __forceinline__ float fdiv_unscaled(float a, float b)
-{
-    float y = __builtin_amdgcn_rcpf(b);
-    y = __fmaf_rn(__fmaf_rn(-b, y, 1.0f), y, y);
-    float q = __fmul_rn(a, y);
-    q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
-    q = __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
-    return q;
-}
-
-// cv::fastAtan2 as dev_fastAtan2 (device_math.hpp), for the agent's region angle: |x| via source modifiers and the unscaled division.
-// Only the sign of a zero result can differ from dev_fastAtan2 (x or y == -0.0f), and the region angle is only ever compared.
-__device__ __forceinline__ float agent_fastAtan2(float y, float x)
-{
-    const float k = (float)(180 / 3.1415926535897932384626433832795);
-    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
-    const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
-    const float eps = (float)2.2204460492503131e-16;
-    const float ax = fabsf(x), ay = fabsf(y);
-    const float mn = fminf(ax, ay), mx = fmaxf(ax, ay);
-    const float c = fdiv_unscaled(mn, f_add(mx, eps));
-    const float c2 = f_mul(c, c);
-    float a = f_mul(f_add(f_mul(f_add(f_mul(f_add(f_mul(p7, c2), p5), c2), p3), c2), p1), c);
-    if (!(ax >= ay)) a = f_sub(90.f, a);
-    if (x < 0) a = f_sub(180.f, a);
-    if (y < 0) a = f_sub(360.f, a);
-    return a;
-}
 
 // debug / test: fdiv_unscaled against the compiler's IEEE division on pseudo-random operand pairs 0 <= a <= b drawn from the agent's
 // operand range (sums of up to ~10^5 unit vectors, plus tiny and equal operands); counts the bit mismatches
@@ -387,11 +339,6 @@ int lsd_sort_chunk_images(int Ps);
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
 constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
 
-__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ double rlane_d(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 
 // (single-wave workgroup: LDS operations of one wave execute in order, so __builtin_amdgcn_wave_barrier() -- a
 // compiler-only barrier -- is enough between a lane-0 LDS write and the other lanes' reads; no s_barrier / vmcnt wait)
@@ -673,25 +620,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // k_lsd_emit then walks each image's candidates in detection order and writes the KeyLines that pass the length filter.
 struct SegCand { float e0, e1, e2, e3, length; int keep; };
 
+// CHAINED: the pixel lists are chains of 32-pixel chunks (lsd_grow.hip; rr.start = first chunk id) instead of one contiguous log per image.
+template <bool CHAINED>
 __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
                                                   const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
-                                                  const int* __restrict__ regCount, SegCand* __restrict__ candAll)
+                                                  const int* __restrict__ regCount, SegCand* __restrict__ candAll,
+                                                  const int* __restrict__ linksAll, int nChunks)
 {
     const LineGeom& g = *gp;
     const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
     if (r >= regCount[img]) return;
     const uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
-    const uint32_t* px_list = regionAll + (size_t)img * g.Ps + rr.start;
+    const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : regionAll + (size_t)img * g.Ps + rr.start;
+    const int* links = CHAINED ? linksAll + (size_t)img * nChunks : nullptr;
     const int n = rr.n, Ws = g.Ws;
+    int cid = rr.start, nxt = -1;
+    // U pixels of the list starting at position q0 (U divides the chunk size)
+#define RECT_BLOCK(q0) (CHAINED ? px_list + (size_t)cid * 32 + ((q0) & 31) : px_list + (q0))
+#define RECT_STEP(q0) do { if (CHAINED) { if (((q0) & 31) == 0) { if (q0) cid = nxt; nxt = links[cid]; } } } while (0)
     // both passes are chains of dependent loads (pixel list -> gradient word); 8 pixels are fetched per step so that the loads of a
     // step are in flight together, the additions stay strictly in growth order
     constexpr int U = 16;
     double x = 0, y = 0, sum = 0;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U], p[U];
+        RECT_STEP(q0);
+        const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
 #pragma unroll
@@ -708,10 +665,13 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     }
     x = x / sum; y = y / sum;
     double Ixx = 0, Iyy = 0, Ixy = 0;
+    cid = rr.start;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U], p[U];
+        RECT_STEP(q0);
+        const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
 #pragma unroll
@@ -742,10 +702,13 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     sincos(theta, &ddy, &ddx);
     // extent along the axis: "if (l > l_max) .. else if (l < l_min) .." from (0, 0) is max(0, max l) / min(0, min l)
     double l_min = 0, l_max = 0;
+    cid = rr.start;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U];
+        RECT_STEP(q0);
+        const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? px_list[q0 + u] : 0u;
+        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (q0 + u < n) {
@@ -773,6 +736,8 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
     SegCand c; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.length = (float)length; c.keep = length > g.minLength;
     candAll[(size_t)img * g.maxRegions + r] = c;
+#undef RECT_BLOCK
+#undef RECT_STEP
 }
 
 // LSDDetectorC::detectImpl, Vec4f -> KeyLine (LSDDetector_custom.cpp:290-307): one workgroup per image, candidates in detection order,
@@ -850,7 +815,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     }
     hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
     hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
-                       b.region, b.angDeg);
+                       b.region, b.angDeg, b.owner);
     hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
     const int per_chunk = lsd_sort_chunk_images(g.Ps);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, per_chunk, b.segBegin, b.segEnd);
@@ -864,8 +829,31 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     return OLF_OK;
 }
 
+int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s);
+
+// waves per image of the multi-wave growth: as many as keep the chip full (8 waves per SIMD x 1024 SIMDs) without leaving a small batch
+// to a handful of waves; 0 selects the one-wave agent of round 1 (kept for A/B measurements, OLF_LSD_NW=0)
+int lsd_grow_waves(int n_images)
+{
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? atoi(e) : -1; }
+    if (forced >= 0) return forced;
+    if (n_images <= 512) return 16;
+    if (n_images <= 1024) return 8;
+    if (n_images <= 2048) return 4;
+    return 2;
+}
+
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
+    const int nw = b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images);
+    b.chained = nw > 0;
+    if (nw > 0) {
+        static int envE = -1;
+        if (envE < 0) { const char* e = getenv("OLF_LSD_ROB"); envE = e ? atoi(e) : 0; }
+        const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 8 ? 512 : 256);
+        return launch_lsd_grow_mw(g, b, n_images, nw, E, s);
+    }
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                        reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS);
     OLF_HIP_CHECK(hipGetLastError());
@@ -875,8 +863,12 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
 int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
     // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
-    hipLaunchKernelGGL(k_lsd_rect, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
-                       reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB));
+    if (b.chained)
+        hipLaunchKernelGGL(k_lsd_rect<true>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
+                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);
+    else
+        hipLaunchKernelGGL(k_lsd_rect<false>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
+                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);
     hipLaunchKernelGGL(k_lsd_emit, dim3(n_images), dim3(256), 0, s, b.geom, reinterpret_cast<const SegCand*>(b.keysB), b.regCount, b.rawLines,
                        b.rawCount, b.status);
     OLF_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,502 @@
+// lsd_grow.hip -- region growing of cv::LineSegmentDetector (OpenCV 3.4 lsd.cpp region_grow, restated in oracle/line_oracle.cpp:121-148)
+// with SEVERAL waves per image, bit-identical to the sequential seed loop.
+//
+// The reference grows one region after the other: seeds in pseudo-order (rank = position in the sorted key list), every region sees the
+// pixels used by all regions before it.  Here NW waves of one workgroup grow regions of the same image concurrently as ORDERED
+// SPECULATION (tools/lsd_sim.cpp is the model this was designed on; it shows 12-15x fewer serial steps with 16 waves):
+//   * every pixel has an owner word: FREE, or the tag (rank << 10 | ROB slot) of the region that claimed it.  Claims are atomicMin, so
+//     the older (lower-rank) region always wins a pixel.
+//   * seeds enter a reorder buffer (ROB, a ring in LDS) in rank order and leave it in rank order (commit).  The watermark `wm` is the rank
+//     of the oldest unresolved seed: an owner whose rank is below it is final, i.e. "used" in the reference's sense.
+//   * a region that would accept a pixel claimed by an older, not yet final region cannot know whether that pixel will stay used: it
+//     yields -- releases its claims and is re-run once the older region is final.  A pixel claimed by an older region that is NOT aligned
+//     with the running region angle is rejected either way, so it is no conflict.
+//   * a region that loses a pixel to an older one (the atomicMin of the thief returns its tag) is told so through its ROB entry and is
+//     re-run as well.  A region is valid at commit time iff nobody stole from it: everything it saw as used was final when it saw it.
+//   The oldest unresolved seed never waits for anything, so there is always progress; the committed regions are exactly the sequential ones.
+// Inside a region the growth step is the wave agent of round 1 (up to 7 FIFO entries x 8 neighbours per iteration, speculative accept
+// rounds that verify every decision against the exact running angle).
+// Region pixel lists live in 32-pixel chunks (chunk id < E: the dedicated first chunk of a ROB slot; else from a per-image pool) chained
+// through links[]; k_lsd_rect walks the chains.
+#include "lsd_device.hpp"
+
+namespace olf {
+
+constexpr int MW_SLOT_BITS = 10;
+constexpr uint32_t MW_FREE = 0xffffffffu;
+constexpr int MW_RING = 256;          // FIFO window of a growing region kept in LDS, per wave
+constexpr int MW_DIR = 128;           // chunk directory per wave (ordinal -> chunk id) for reading the FIFO from memory
+constexpr int MW_FREESTK = 256;
+enum { ST_EMPTY = 0, ST_READY = 1, ST_PARKED = 2, ST_GROWING = 3, ST_DONE = 4, ST_DEAD = 5 };
+enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_N };
+
+#define WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+// Global memory shared by the waves of one workgroup (owner words, chunk lists written by another wave): workgroup-scope atomics -- coherent
+// in the L2 of the XCD the workgroup runs on.  Agent scope would be wrong for the job: on a multi-XCD part it means "coherent across the
+// XCDs' L2s", i.e. every load / atomic goes out to the fabric and every release fence writes the L2 back (measured: 16x slower in batch).
+#define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// wave-uniform read of an LDS word (every lane reads the same address)
+__device__ __forceinline__ int lds_u(int* p) { return uni(WG_LOAD(p)); }
+__device__ __forceinline__ uint32_t lds_u(uint32_t* p) { return (uint32_t)uni((int)WG_LOAD(p)); }
+
+__device__ __forceinline__ bool try_lock(int* l, int lane)
+{
+    int ok = 0;
+    if (lane == 0) { int exp = 0; ok = __hip_atomic_compare_exchange_strong(l, &exp, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0; }
+    return uni(ok) != 0;
+}
+__device__ __forceinline__ void unlock(int* l, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct MwCtx {
+    // LDS
+    int* ctl; int* freeStk;
+    int* eRank; int* eState; uint32_t* eBlock; uint32_t* eInval; int* eN; uint32_t* eSeed; double* eAng;
+    uint32_t* ring; int* dir;
+    // global, per image
+    uint32_t* owner; const uint32_t* grad; const uint32_t* keys; uint32_t* chunks; int* links; RegionRec* recs; int* status;
+    int E, mask, nkeys, nChunks, Ws, Hs, minRegSize, maxRegions, lane;
+};
+
+// chunk from the pool (LDS free stack first, then never-used ones); -1 when the pool is exhausted
+__device__ __forceinline__ int mw_alloc(const MwCtx& c)
+{
+    int id = -1, spins = 0;
+    while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return -1; }
+    if (c.lane == 0) {
+        const int ft = WG_LOAD(c.ctl + C_FREETOP);
+        if (ft > 0) { id = WG_LOAD(c.freeStk + ft - 1); WG_STORE(c.ctl + C_FREETOP, ft - 1); }
+        else { const int pt = WG_LOAD(c.ctl + C_POOLTOP); if (pt < c.nChunks) { id = pt; WG_STORE(c.ctl + C_POOLTOP, pt + 1); } }
+    }
+    unlock(c.ctl + C_LOCKALLOC, c.lane);
+    return uni(id);
+}
+__device__ __forceinline__ void mw_free(const MwCtx& c, int id)
+{
+    int spins = 0;
+    while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return; }
+    if (c.lane == 0) {
+        const int ft = WG_LOAD(c.ctl + C_FREETOP);
+        if (ft < MW_FREESTK) { WG_STORE(c.freeStk + ft, id); WG_STORE(c.ctl + C_FREETOP, ft + 1); }   // else: leaked (counts against the pool)
+    }
+    unlock(c.ctl + C_LOCKALLOC, c.lane);
+}
+
+// un-claim the n pixels of the list of `slot` (pixel 0 is the seed; 1.. from the chunk chain) and give its pool chunks back
+__device__ __forceinline__ void mw_release(const MwCtx& c, int slot, int n, uint32_t T)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the list may have been written by this wave a moment ago
+    if (c.lane == 0) {
+        uint32_t exp = T;
+        __hip_atomic_compare_exchange_strong(c.owner + (WG_LOAD(c.eSeed + slot) & 0x3fffffu), &exp, MW_FREE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    int cid = slot;
+    for (int q0 = 0; q0 < n && cid >= 0; q0 += 32) {
+        const int q = q0 + c.lane;
+        if (c.lane < 32 && q >= 1 && q < n) {
+            const uint32_t xy = AG_LOAD(c.chunks + (size_t)cid * 32 + c.lane);
+            const int a = (int)(xy >> 16) * c.Ws + (int)(xy & 0xffffu);
+            uint32_t exp = T;
+            __hip_atomic_compare_exchange_strong(c.owner + a, &exp, MW_FREE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const int nx = (q0 + 32 < n) ? uni(AG_LOAD(c.links + cid)) : -1;
+        if (cid >= c.E) mw_free(c, cid);
+        cid = nx;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the pixels are free before the entry changes state
+}
+
+// commit DONE / DEAD entries at the head of the ROB, in rank order; logs the regions that are large enough
+__device__ __forceinline__ void mw_commit(const MwCtx& c)
+{
+    {
+        const int h0 = lds_u(c.ctl + C_HEAD), t0 = lds_u(c.ctl + C_TAIL);
+        if (h0 >= t0) return;
+        const int st0 = lds_u(c.eState + (h0 & c.mask));
+        if (st0 != ST_DEAD && !(st0 == ST_DONE && lds_u(c.eInval + (h0 & c.mask)) == MW_FREE)) return;
+    }
+    if (!try_lock(c.ctl + C_LOCKCOMMIT, c.lane)) return;
+    int h = lds_u(c.ctl + C_HEAD);
+    const int t = lds_u(c.ctl + C_TAIL);
+    while (h < t) {
+        const int slot = h & c.mask;
+        const int st = lds_u(c.eState + slot);
+        if (st == ST_DONE) {
+            if (lds_u(c.eInval + slot) != MW_FREE) break;                 // stolen from: has to be re-run
+            const int n = lds_u(c.eN + slot);
+            if (n >= c.minRegSize) {
+                const int nr = lds_u(c.ctl + C_NREG);
+                const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
+                if (nc >= 0) {
+                    // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
+                    if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)slot * 32 + c.lane);
+                    if (c.lane == 0) {
+                        c.links[nc] = AG_LOAD(c.links + slot);
+                        RegionRec rr; rr.start = nc; rr.n = n; rr.angle = c.eAng[slot];
+                        c.recs[nr] = rr;
+                        WG_STORE(c.ctl + C_NREG, nr + 1);
+                    }
+                } else if (c.lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); }
+            }
+        } else if (st != ST_DEAD) break;
+        if (c.lane == 0) WG_STORE(c.eState + slot, (int)ST_EMPTY);
+        ++h;
+    }
+    // watermark: rank of the oldest unresolved seed.  dispNext is read before tail: the dispatcher publishes tail first.
+    const int dn = lds_u(c.ctl + C_DISPNEXT);
+    const int t2 = lds_u(c.ctl + C_TAIL);
+    const int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : dn;
+    if (c.lane == 0) { WG_STORE(c.ctl + C_HEAD, h); WG_STORE(c.ctl + C_WM, wm); }
+    unlock(c.ctl + C_LOCKCOMMIT, c.lane);
+}
+
+// next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do
+__device__ __forceinline__ int mw_dispatch(const MwCtx& c)
+{
+    if (lds_u(c.ctl + C_DISPNEXT) >= c.nkeys) return 0;
+    if (lds_u(c.ctl + C_TAIL) - lds_u(c.ctl + C_HEAD) > c.E - 64) return 0;
+    if (!try_lock(c.ctl + C_LOCKDISP, c.lane)) return 1;
+    const int dn = lds_u(c.ctl + C_DISPNEXT), t = lds_u(c.ctl + C_TAIL), h = lds_u(c.ctl + C_HEAD);
+    int did = 0;
+    if (dn < c.nkeys && t - h <= c.E - 64) {
+        const int rank = dn + c.lane;
+        const bool valid = rank < c.nkeys;
+        const int addr = valid ? (int)(c.keys[rank] & 0x3fffffu) : 0;
+        const uint32_t o = valid ? AG_LOAD(c.owner + addr) : 0u;
+        const uint32_t w = valid ? c.grad[addr] : 0u;
+        const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
+        const bool live = valid && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
+        const unsigned long long m = __ballot(live);
+        if (live) {
+            const int s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
+            c.eRank[s] = rank;
+            c.eSeed[s] = (uint32_t)addr | ((w & kIso) ? 0x80000000u : 0u);
+            c.eInval[s] = MW_FREE;
+            c.eN[s] = 0;
+            c.eBlock[s] = o != MW_FREE ? (o >> MW_SLOT_BITS) : 0u;
+            c.eState[s] = o != MW_FREE ? (int)ST_PARKED : (int)ST_READY;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + (int)__popcll(m)); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(dn + 64, c.nkeys)); }
+        did = 1;
+    }
+    unlock(c.ctl + C_LOCKDISP, c.lane);
+    return did;
+}
+
+// lowest-rank entry that can be (re-)run now; returns its slot with the entry in state GROWING, or -1
+__device__ __forceinline__ int mw_pick(const MwCtx& c)
+{
+    const int h = lds_u(c.ctl + C_HEAD), t = lds_u(c.ctl + C_TAIL);
+    const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
+    for (int base = h; base < t; base += 64) {
+        const int i = base + c.lane;
+        const int slot = i & c.mask;
+        const int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
+        bool el = st == ST_READY;
+        if (st == ST_PARKED) el = WG_LOAD(c.eBlock + slot) < wm;
+        if (st == ST_DONE) { const uint32_t iv = WG_LOAD(c.eInval + slot); el = iv != MW_FREE && iv < wm; }
+        unsigned long long m = __ballot(el);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            const int s = (base + l) & c.mask;
+            int exp = rlane(st, l);
+            int ok = 0;
+            if (c.lane == 0) ok = __hip_atomic_compare_exchange_strong(c.eState + s, &exp, (int)ST_GROWING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+            if (uni(ok)) return s;
+            m &= m - 1ull;
+        }
+    }
+    return -1;
+}
+
+// tell the region whose tag is `victim` that the region of `rank` took one of its pixels
+__device__ __forceinline__ void mw_notify(const MwCtx& c, uint32_t victim, uint32_t rank)
+{
+    __hip_atomic_fetch_min(c.eInval + (victim & ((1u << MW_SLOT_BITS) - 1u)), rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// grow (or re-grow) the region of ROB entry `slot`, which this wave holds in state GROWING
+__device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double prec, double precWrap, const float* __restrict__ angDeg,
+                                       const double2* __restrict__ cosSin, const float2* __restrict__ seedCS)
+{
+    const int lane = c.lane, Ws = c.Ws, Hs = c.Hs;
+    const uint32_t rank = (uint32_t)lds_u(c.eRank + slot);
+    const uint32_t T = (rank << MW_SLOT_BITS) | (uint32_t)slot;
+    const uint32_t sw = lds_u(c.eSeed + slot);
+    const int seed = (int)(sw & 0x3fffffu);
+    uint32_t* ring = c.ring + wv * MW_RING;
+    int* dir = c.dir + wv * MW_DIR;
+    {   // a finished region that was stolen from still holds its claims
+        const int nOld = lds_u(c.eN + slot);
+        if (nOld > 0) { mw_release(c, slot, nOld, T); if (lane == 0) WG_STORE(c.eN + slot, 0); }
+    }
+    if (lane == 0) WG_STORE(c.eInval + slot, MW_FREE);      // steals from here on concern this run
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t old0 = 0;
+    if (lane == 0) old0 = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old0 = (uint32_t)uni((int)old0);
+    if (old0 < T) {
+        // claimed by an older region: consumed if that one is final, else wait for it
+        const bool fin = (old0 >> MW_SLOT_BITS) < (uint32_t)lds_u(c.ctl + C_WM);
+        if (lane == 0) {
+            if (!fin) WG_STORE(c.eBlock + slot, old0 >> MW_SLOT_BITS);
+            __hip_atomic_store(c.eState + slot, fin ? (int)ST_DEAD : (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    if (old0 != MW_FREE && lane == 0) mw_notify(c, old0, rank);
+    const uint32_t seedXY = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16);
+    if (sw & 0x80000000u) {
+        // no neighbour is aligned with the seed's own angle (k_lsd_iso): the region is the seed alone, whatever is used around it
+        if (lane == 0) { WG_STORE(c.eN + slot, 1); __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        return;
+    }
+    const uint32_t pseed = c.grad[seed];
+    double reg_angle = d_mul((double)angDeg[pseed & 0x3fffffu], kDegToRads);
+    float sumdx, sumdy;
+    { const float2 s0 = seedCS[pseed & 0x3fffffu]; sumdx = s0.x; sumdy = s0.y; }
+    if (lane == 0) { ring[0] = seedXY; c.chunks[(size_t)slot * 32] = seedXY; c.links[slot] = -1; dir[0] = slot; }
+    __builtin_amdgcn_wave_barrier();
+    int n = 1, i = 0, cur = slot;
+    uint32_t blocker = MW_FREE;
+    bool fail = false;
+    while (i < n) {
+        {
+            const uint32_t iv = lds_u(c.eInval + slot);
+            if (iv != MW_FREE) { blocker = iv; fail = true; break; }
+        }
+        const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
+        const int nb = min(7, n - i);
+        const int e = lane / 9, k = lane - 9 * e;
+        bool cand = lane < 63 && e < nb && k != 4;
+        uint32_t rp;
+        if (n - i > MW_RING) {
+            // the window left the ring: read the FIFO from the chunk chain
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const int q = i + (cand ? e : 0);
+            const int ord = q >> 5;
+            int cid;
+            if (ord < MW_DIR) cid = dir[ord];
+            else { cid = dir[MW_DIR - 1]; for (int o2 = MW_DIR - 1; o2 < ord; ++o2) cid = AG_LOAD(c.links + cid); }
+            rp = AG_LOAD(c.chunks + (size_t)cid * 32 + (q & 31));
+        } else rp = ring[(i + e) & (MW_RING - 1)];
+        const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
+        cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
+        const int a = cand ? yy * Ws + xx : 0;
+        const uint32_t pw = c.grad[a];
+        const uint32_t o = AG_LOAD(c.owner + a);
+        const int xy = xx | (yy << 16);
+        // not mine, not used by a final region; an older, unfinished claim stays a candidate ("contested")
+        cand = cand && !(pw & kNotDef) && o != T && !(o < T && (o >> MW_SLOT_BITS) < wm);
+        const bool con = cand && o < T;
+        double ang = 0, cs = 0, sn = 0;
+        if (cand) {
+            const uint32_t ti = pw & 0x3fffffu;
+            ang = d_mul((double)angDeg[ti], kDegToRads);
+            const double2 t = cosSin[ti];
+            cs = t.x; sn = t.y;
+        }
+        unsigned long long cm = __ballot(cand);
+        const unsigned long long conM = __ballot(con);
+        unsigned long long acc = 0;
+        const int n0 = n;
+        while (cm) {
+            // isaligned(): see k_lsd_grow (lsd.hip) -- wrapped test against precWrap, candidates in lane order = the reference's visiting order
+            const double nth = fabs(d_sub(reg_angle, ang));
+            const bool was = nth <= prec || nth >= precWrap;
+            const unsigned long long al = __ballot(was) & cm;
+            if (!al) break;
+            if ((al & (al - 1ull)) == 0) {
+                const int cc = __builtin_ctzll(al);
+                cm &= ~((2ull << cc) - 1ull);
+                const int a_c = rlane(a, cc);
+                const double cs_c = rlane_d(cs, cc), sn_c = rlane_d(sn, cc);
+                acc |= 1ull << cc;
+                ++n;
+                sumdx = (float)d_add((double)sumdx, cs_c);
+                sumdy = (float)d_add((double)sumdy, sn_c);
+                reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                cm &= ~__ballot(a == a_c);
+                continue;
+            }
+            // speculative round (see lsd.hip): all aligned candidates assumed accepted in lane order, one fastAtan2 for all their angles, every
+            // decision re-tested against the angle that governs it, commit up to the first decision that changes
+            unsigned long long todo = al, spec = 0;
+            float sx = sumdx, sy = sumdy, psx = 0.f, psy = 0.f;
+            int dupStep = 64, j = 0;
+            while (todo) {
+                const int cc = __builtin_ctzll(todo);
+                const int a_c = rlane(a, cc);
+                const double cs_c = rlane_d(cs, cc), sn_c = rlane_d(sn, cc);
+                sx = (float)d_add((double)sx, cs_c);
+                sy = (float)d_add((double)sy, sn_c);
+                if (lane == j) { psx = sx; psy = sy; }
+                const bool tw = a == a_c;
+                if (tw && lane != cc) dupStep = j;
+                todo &= ~__ballot(tw);
+                spec |= 1ull << cc;
+                ++j;
+            }
+            const double th = d_mul((double)agent_fastAtan2(psy, psx), kDegToRads);
+            const int gq = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(spec >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)spec, 0u));
+            double thg = shfl_d(th, max(gq - 1, 0));
+            if (gq == 0) thg = reg_angle;
+            const double n2 = fabs(d_sub(thg, ang));
+            const bool re = n2 <= prec || n2 >= precWrap;
+            const unsigned long long mis = __ballot(re != was && !(dupStep < gq)) & cm;
+            const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
+            const unsigned long long okAcc = spec & bm;
+            const int tt = __popcll(okAcc);
+            acc |= okAcc;
+            n += tt;
+            cm &= ~bm;
+            cm &= ~__ballot(dupStep < tt);
+            sumdx = __int_as_float(rlane(__float_as_int(psx), tt - 1));
+            sumdy = __int_as_float(rlane(__float_as_int(psy), tt - 1));
+            reg_angle = rlane_d(th, tt - 1);
+        }
+        if (acc & conM) {
+            // the reference would add a pixel that an older, unfinished region holds right now: yield to that region
+            blocker = (uint32_t)rlane((int)(o >> MW_SLOT_BITS), __builtin_ctzll(acc & conM));
+            n = n0; fail = true; break;
+        }
+        if (acc) {
+            // chunks for list positions n0 .. n-1 (at most two new ones: an iteration adds <= 56 pixels)
+            const int curOrd = (n0 - 1) >> 5, lastOrd = (n - 1) >> 5;
+            int new1 = -1, new2 = -1;
+            if (lastOrd > curOrd) {
+                new1 = mw_alloc(c);
+                if (lastOrd > curOrd + 1 && new1 >= 0) new2 = mw_alloc(c);
+                if (new1 < 0 || (lastOrd > curOrd + 1 && new2 < 0)) {
+                    if (lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); }
+                    n = n0; blocker = 0; fail = true; break;
+                }
+                if (lane == 0) {
+                    c.links[cur] = new1;
+                    c.links[new1] = new2;
+                    if (new2 >= 0) c.links[new2] = -1;
+                    if (curOrd + 1 < MW_DIR) dir[curOrd + 1] = new1;
+                    if (new2 >= 0 && curOrd + 2 < MW_DIR) dir[curOrd + 2] = new2;
+                }
+            }
+            const bool mine = (acc >> lane) & 1ull;
+            uint32_t oldv = MW_FREE;
+            if (mine) {
+                const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
+                oldv = __hip_atomic_fetch_min(c.owner + a, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ring[idx & (MW_RING - 1)] = (uint32_t)xy;
+                const int ord = idx >> 5;
+                const int cid = ord == curOrd ? cur : (ord == curOrd + 1 ? new1 : new2);
+                c.chunks[(size_t)cid * 32 + (idx & 31)] = (uint32_t)xy;
+            }
+            if (lastOrd > curOrd) cur = new2 >= 0 ? new2 : new1;
+            // a pixel another region claimed between the test and the claim: an older one -> this region's decisions were made on a
+            // pixel that is not available: yield; a younger one -> it is ours now and that region is told
+            const unsigned long long bad = __ballot(mine && oldv < T);
+            if (mine && oldv != MW_FREE && oldv > T) mw_notify(c, oldv, rank);
+            if (bad) { blocker = (uint32_t)rlane((int)(oldv >> MW_SLOT_BITS), __builtin_ctzll(bad)); fail = true; break; }
+        }
+        i += nb;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (fail) {
+        mw_release(c, slot, n, T);
+        if (lane == 0) {
+            WG_STORE(c.eN + slot, 0);
+            WG_STORE(c.eBlock + slot, blocker);
+            __hip_atomic_store(c.eState + slot, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // list + links are in memory before the entry says DONE
+    if (lane == 0) {
+        WG_STORE(c.eN + slot, n);
+        c.eAng[slot] = reg_angle;
+        __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+size_t lsd_grow_mw_lds_bytes(int nw, int E)
+{
+    return (size_t)(C_N + 1 + MW_FREESTK) * 4 + (size_t)E * (6 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
+}
+
+__global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll, uint32_t* __restrict__ ownerAll,
+                                                      const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
+                                                      uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
+                                                      int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
+                                                      const double2* __restrict__ cosSin, const float2* __restrict__ seedCS, int E, int nChunks)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    MwCtx c;
+    {
+        unsigned char* p = smem;
+        c.eAng = reinterpret_cast<double*>(p); p += (size_t)E * 8;
+        c.ctl = reinterpret_cast<int*>(p); p += (C_N + 1) * 4;
+        c.freeStk = reinterpret_cast<int*>(p); p += MW_FREESTK * 4;
+        c.eRank = reinterpret_cast<int*>(p); p += (size_t)E * 4;
+        c.eState = reinterpret_cast<int*>(p); p += (size_t)E * 4;
+        c.eBlock = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
+        c.eInval = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
+        c.eN = reinterpret_cast<int*>(p); p += (size_t)E * 4;
+        c.eSeed = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
+        c.ring = reinterpret_cast<uint32_t*>(p); p += (size_t)nw * MW_RING * 4;
+        c.dir = reinterpret_cast<int*>(p);
+    }
+    c.owner = ownerAll + (size_t)img * g.Ps;
+    c.grad = gradAll + (size_t)img * g.Ps;
+    c.keys = keysAll + (size_t)img * g.Ps;
+    c.chunks = chunksAll + (size_t)img * nChunks * 32;
+    c.links = linksAll + (size_t)img * nChunks;
+    c.recs = recsAll + (size_t)img * g.maxRegions;
+    c.status = status;
+    c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32]; c.nChunks = nChunks; c.Ws = g.Ws; c.Hs = g.Hs;
+    c.minRegSize = g.minRegSize; c.maxRegions = g.maxRegions; c.lane = lane;
+    for (int q = threadIdx.x; q < E; q += blockDim.x) c.eState[q] = ST_EMPTY;
+    if (threadIdx.x < C_N + 1) c.ctl[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) c.ctl[C_POOLTOP] = E;              // chunk ids below E are the ROB slots' own chunks
+    __syncthreads();
+    const double prec = g.prec, precWrap = g.precWrap;
+    int idle = 0;
+    for (;;) {
+        if (lds_u(c.ctl + C_ABORT)) break;
+        mw_commit(c);
+        const int slot = mw_pick(c);
+        if (slot >= 0) { idle = 0; mw_run(c, slot, wv, prec, precWrap, angDeg, cosSin, seedCS); continue; }
+        if (mw_dispatch(c)) continue;
+        // nothing to run, nothing to dispatch: finished, or waiting for other waves' regions
+        const int dn = lds_u(c.ctl + C_DISPNEXT);
+        const int t = lds_u(c.ctl + C_TAIL), h = lds_u(c.ctl + C_HEAD);
+        if (dn >= c.nkeys && h == t) break;
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle > (1 << 21)) { if (lane == 0) { atomicOr(status, 16); WG_STORE(c.ctl + C_ABORT, 1); } break; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) regCount[img] = c.ctl[C_ABORT] ? 0 : c.ctl[C_NREG];
+}
+
+int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s)
+{
+    const size_t lds = lsd_grow_mw_lds_bytes(nw, E);
+    static bool attr_set = false;
+    if (!attr_set) { OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+    hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS, E, b.nChunks);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
+}  // namespace olf

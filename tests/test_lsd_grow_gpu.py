@@ -1,0 +1,52 @@
+"""GPU parity of the multi-wave LSD region growing (csrc/lsd_grow.hip): the detected key lines must not depend on how many waves grow an
+image concurrently nor on the size of the reorder buffer, and must equal the oracle's sequential seed loop (oracle/line_oracle.cpp:121-148)."""
+import numpy as np
+import pytest
+import orb_line_slam_amd as ola
+from orb_line_slam_amd import synth, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(ex, w, h, n, waves, rob):
+    ctx = ex._context(w, h, n)
+    _lib.check(_lib.lib().olf_debug_lsd_waves(ctx.handle, waves, rob), "olf_debug_lsd_waves")
+
+
+def _status(ex):
+    out = np.zeros(64, np.int32)
+    _lib.check(_lib.lib().olf_debug_status(ex._ctx.handle, _lib.ptr(out)), "olf_debug_status")
+    return out
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1242, 375)])
+def test_growth_is_independent_of_wave_count(oracle, w, h):
+    p = oracle.full_params(2000, 0)
+    imgs = synth.stereo_batch(71, 2, w, h)            # 4 images
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    ex = ola.Lineextractor(0, 0.025, max_images=4)
+    for waves, rob in [(0, 0), (1, 128), (2, 128), (2, 256), (4, 256), (8, 512), (16, 512), (16, 128), (3, 256), (-1, 0)]:
+        _set(ex, w, h, 4, waves, rob)
+        kls, desc, counts = ex.extract_batch(imgs)
+        assert (_status(ex)[0] & (8 | 16)) == 0, (waves, rob, "capacity / watchdog flag")
+        for i in range(4):
+            n = int(counts[i])
+            assert n == len(want[i]["kls"]), (waves, rob, i, n, len(want[i]["kls"]))
+            assert np.array_equal(kls[i, :n], want[i]["kls"]), (waves, rob, i)
+            assert np.array_equal(desc[i, :n], want[i]["desc"]), (waves, rob, i)
+
+
+def test_growth_noise_and_flat_images(oracle):
+    """Pure noise (hundreds of thousands of tiny regions, the chunk pool's worst case that still fits) and a flat image (no seed at all)."""
+    w, h = 320, 240
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    flat = np.full((h, w), 77, np.uint8)
+    p = oracle.full_params(1000, 0)
+    ex = ola.Lineextractor(0, 0.025, max_images=2)
+    for waves in (16, 4, 1):
+        _set(ex, w, h, 2, waves, 0)
+        for img in (noise, flat):
+            gk, gd = ex(img)
+            o = oracle.line_extract(img, p.line)
+            assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), waves
