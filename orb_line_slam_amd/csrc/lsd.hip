@@ -839,9 +839,9 @@ int lsd_grow_waves(int n_images)
     if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? atoi(e) : -1; }
     if (forced >= 0) return forced;
     if (n_images <= 512) return 16;
-    if (n_images <= 1024) return 8;
-    if (n_images <= 2048) return 4;
-    return 2;
+    if (n_images <= 2048) return 8;
+    if (n_images <= 3072) return 4;
+    return 0;      // big batches are throughput bound, and there the one-wave agent does the least work per image
 }
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
@@ -851,7 +851,7 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     if (nw > 0) {
         static int envE = -1;
         if (envE < 0) { const char* e = getenv("OLF_LSD_ROB"); envE = e ? atoi(e) : 0; }
-        const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 8 ? 512 : 256);
+        const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
         return launch_lsd_grow_mw(g, b, n_images, nw, E, s);
     }
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,

@@ -43,6 +43,17 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ int lds_u(int* p) { return uni(WG_LOAD(p)); }
 __device__ __forceinline__ uint32_t lds_u(uint32_t* p) { return (uint32_t)uni((int)WG_LOAD(p)); }
 
+// head, tail, dispNext, watermark: one 16-byte LDS read, wave-uniform
+struct MwCtl { int head, tail, dispNext; uint32_t wm; };
+typedef int mw_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MwCtl mw_ctl(int* ctl)
+{
+    // (the four words change independently; every use tolerates a stale or torn snapshot -- see the callers)
+    const mw_v4i v = *reinterpret_cast<volatile mw_v4i*>(ctl);
+    MwCtl r; r.head = uni(v.x); r.tail = uni(v.y); r.dispNext = uni(v.z); r.wm = (uint32_t)uni(v.w);
+    return r;
+}
+
 __device__ __forceinline__ bool try_lock(int* l, int lane)
 {
     int ok = 0;
@@ -55,28 +66,47 @@ __device__ __forceinline__ void unlock(int* l, int lane)
     if (lane == 0) __hip_atomic_store(l, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// -DOLF_MW_PROF: cycle counters per phase, summed over the waves of image 0 into status[16..] (tools/prof_mw.py)
+#ifdef OLF_MW_PROF
+#define PROF_DECL long long pf_t = __builtin_readcyclecounter(), pf_acc[PF_N] = {0}
+#define PROF(i) do { const long long _t = __builtin_readcyclecounter(); pf_acc[i] += _t - pf_t; pf_t = _t; } while (0)
+#define PROF_CNT(i) (++pf_acc[i])
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_CNT(i)
+#endif
+enum { PF_COMMIT = 0, PF_PICK, PF_DISPATCH, PF_PROLOGUE, PF_GATHER, PF_CHAIN, PF_CLAIM, PF_FINISH, PF_IDLE, PF_NRUN, PF_NITER, PF_NFAIL, PF_F_INVAL, PF_F_CONTEST, PF_F_OLDER, PF_F_DUP, PF_N };
+
 struct MwCtx {
     // LDS
     int* ctl; int* freeStk;
-    int* eRank; int* eState; uint32_t* eBlock; uint32_t* eInval; int* eN; uint32_t* eSeed; double* eAng;
+    int* eRank; int* eState; uint32_t* eBlock; uint32_t* eInval; int* eN; uint32_t* eSeed; double* eAng; float* eDeg; float* eSx; float* eSy;
     uint32_t* ring; int* dir;
     // global, per image
     uint32_t* owner; const uint32_t* grad; const uint32_t* keys; uint32_t* chunks; int* links; RegionRec* recs; int* status;
     int E, mask, nkeys, nChunks, Ws, Hs, minRegSize, maxRegions, lane;
 };
 
-// chunk from the pool (LDS free stack first, then never-used ones); -1 when the pool is exhausted
+// chunk from the pool: never-used ones by a bump counter; recycled ones (LDS stack, filled only by regions that were given up) under a lock.
+// -1 when the pool is exhausted
 __device__ __forceinline__ int mw_alloc(const MwCtx& c)
 {
-    int id = -1, spins = 0;
-    while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return -1; }
-    if (c.lane == 0) {
-        const int ft = WG_LOAD(c.ctl + C_FREETOP);
-        if (ft > 0) { id = WG_LOAD(c.freeStk + ft - 1); WG_STORE(c.ctl + C_FREETOP, ft - 1); }
-        else { const int pt = WG_LOAD(c.ctl + C_POOLTOP); if (pt < c.nChunks) { id = pt; WG_STORE(c.ctl + C_POOLTOP, pt + 1); } }
+    int id = -1;
+    if (lds_u(c.ctl + C_FREETOP) > 0) {
+        int spins = 0;
+        while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return -1; }
+        if (c.lane == 0) {
+            const int ft = WG_LOAD(c.ctl + C_FREETOP);
+            if (ft > 0) { id = WG_LOAD(c.freeStk + ft - 1); WG_STORE(c.ctl + C_FREETOP, ft - 1); }
+        }
+        unlock(c.ctl + C_LOCKALLOC, c.lane);
+        id = uni(id);
+        if (id >= 0) return id;
     }
-    unlock(c.ctl + C_LOCKALLOC, c.lane);
-    return uni(id);
+    if (c.lane == 0) id = __hip_atomic_fetch_add(c.ctl + C_POOLTOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    id = uni(id);
+    return id < c.nChunks ? id : -1;
 }
 __device__ __forceinline__ void mw_free(const MwCtx& c, int id)
 {
@@ -113,110 +143,55 @@ __device__ __forceinline__ void mw_release(const MwCtx& c, int slot, int n, uint
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the pixels are free before the entry changes state
 }
 
-// commit DONE / DEAD entries at the head of the ROB, in rank order; logs the regions that are large enough
-__device__ __forceinline__ void mw_commit(const MwCtx& c)
+// commit DONE / DEAD entries at the head of the ROB, in rank order, up to 64 per call; logs the regions that are large enough.
+// `ctl` is the caller's snapshot (the cheap test whether the head entry can go at all is made on it, without the lock).
+__device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
 {
+    if (cv.head >= cv.tail) return;
     {
-        const int h0 = lds_u(c.ctl + C_HEAD), t0 = lds_u(c.ctl + C_TAIL);
-        if (h0 >= t0) return;
-        const int st0 = lds_u(c.eState + (h0 & c.mask));
-        if (st0 != ST_DEAD && !(st0 == ST_DONE && lds_u(c.eInval + (h0 & c.mask)) == MW_FREE)) return;
+        const int st0 = WG_LOAD(c.eState + (cv.head & c.mask));
+        const uint32_t iv0 = WG_LOAD(c.eInval + (cv.head & c.mask));
+        if (!(uni(st0) == ST_DEAD || (uni(st0) == ST_DONE && (uint32_t)uni((int)iv0) == MW_FREE))) return;
     }
     if (!try_lock(c.ctl + C_LOCKCOMMIT, c.lane)) return;
-    int h = lds_u(c.ctl + C_HEAD);
-    const int t = lds_u(c.ctl + C_TAIL);
-    while (h < t) {
-        const int slot = h & c.mask;
-        const int st = lds_u(c.eState + slot);
-        if (st == ST_DONE) {
-            if (lds_u(c.eInval + slot) != MW_FREE) break;                 // stolen from: has to be re-run
-            const int n = lds_u(c.eN + slot);
-            if (n >= c.minRegSize) {
-                const int nr = lds_u(c.ctl + C_NREG);
-                const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
-                if (nc >= 0) {
-                    // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
-                    if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)slot * 32 + c.lane);
-                    if (c.lane == 0) {
-                        c.links[nc] = AG_LOAD(c.links + slot);
-                        RegionRec rr; rr.start = nc; rr.n = n; rr.angle = c.eAng[slot];
-                        c.recs[nr] = rr;
-                        WG_STORE(c.ctl + C_NREG, nr + 1);
-                    }
-                } else if (c.lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); }
+    const MwCtl cl = mw_ctl(c.ctl);
+    int h = cl.head;
+    {
+        const int i = h + c.lane, slot = i & c.mask;
+        const bool in = i < cl.tail;
+        const int st = in ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
+        const uint32_t iv = in ? WG_LOAD(c.eInval + slot) : 0u;
+        const int n = in ? WG_LOAD(c.eN + slot) : 0;
+        const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE);       // DONE with a steal noted: has to be re-run first
+        const unsigned long long cm = __ballot(can);
+        const int run = cm == ~0ull ? 64 : __builtin_ctzll(~cm);
+        const unsigned long long low = run >= 64 ? ~0ull : ((1ull << run) - 1ull);
+        unsigned long long big = __ballot(st == ST_DONE && n >= c.minRegSize) & low;
+        int nr = lds_u(c.ctl + C_NREG);
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const int sl = (h + l) & c.mask;
+            const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
+            if (nc < 0) { if (c.lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); } break; }
+            // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
+            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)sl * 32 + c.lane);
+            if (c.lane == 0) {
+                c.links[nc] = AG_LOAD(c.links + sl);
+                RegionRec rr; rr.start = nc; rr.n = rlane(n, l); rr.angle = c.eAng[sl];
+                c.recs[nr] = rr;
             }
-        } else if (st != ST_DEAD) break;
-        if (c.lane == 0) WG_STORE(c.eState + slot, (int)ST_EMPTY);
-        ++h;
+            ++nr;
+        }
+        if (c.lane < run) WG_STORE(c.eState + slot, (int)ST_EMPTY);
+        h += run;
+        // watermark: rank of the oldest unresolved seed.  The dispatcher publishes tail before dispNext and the snapshot `cl` is older than
+        // the tail read here, so an empty ROB with a stale dispNext can only give a watermark that is too low, which is safe.
+        const int t2 = lds_u(c.ctl + C_TAIL);
+        const int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
+        if (c.lane == 0) { WG_STORE(c.ctl + C_NREG, nr); WG_STORE(c.ctl + C_HEAD, h); WG_STORE(c.ctl + C_WM, wm); }
     }
-    // watermark: rank of the oldest unresolved seed.  dispNext is read before tail: the dispatcher publishes tail first.
-    const int dn = lds_u(c.ctl + C_DISPNEXT);
-    const int t2 = lds_u(c.ctl + C_TAIL);
-    const int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : dn;
-    if (c.lane == 0) { WG_STORE(c.ctl + C_HEAD, h); WG_STORE(c.ctl + C_WM, wm); }
     unlock(c.ctl + C_LOCKCOMMIT, c.lane);
-}
-
-// next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do
-__device__ __forceinline__ int mw_dispatch(const MwCtx& c)
-{
-    if (lds_u(c.ctl + C_DISPNEXT) >= c.nkeys) return 0;
-    if (lds_u(c.ctl + C_TAIL) - lds_u(c.ctl + C_HEAD) > c.E - 64) return 0;
-    if (!try_lock(c.ctl + C_LOCKDISP, c.lane)) return 1;
-    const int dn = lds_u(c.ctl + C_DISPNEXT), t = lds_u(c.ctl + C_TAIL), h = lds_u(c.ctl + C_HEAD);
-    int did = 0;
-    if (dn < c.nkeys && t - h <= c.E - 64) {
-        const int rank = dn + c.lane;
-        const bool valid = rank < c.nkeys;
-        const int addr = valid ? (int)(c.keys[rank] & 0x3fffffu) : 0;
-        const uint32_t o = valid ? AG_LOAD(c.owner + addr) : 0u;
-        const uint32_t w = valid ? c.grad[addr] : 0u;
-        const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
-        const bool live = valid && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
-        const unsigned long long m = __ballot(live);
-        if (live) {
-            const int s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
-            c.eRank[s] = rank;
-            c.eSeed[s] = (uint32_t)addr | ((w & kIso) ? 0x80000000u : 0u);
-            c.eInval[s] = MW_FREE;
-            c.eN[s] = 0;
-            c.eBlock[s] = o != MW_FREE ? (o >> MW_SLOT_BITS) : 0u;
-            c.eState[s] = o != MW_FREE ? (int)ST_PARKED : (int)ST_READY;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + (int)__popcll(m)); }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(dn + 64, c.nkeys)); }
-        did = 1;
-    }
-    unlock(c.ctl + C_LOCKDISP, c.lane);
-    return did;
-}
-
-// lowest-rank entry that can be (re-)run now; returns its slot with the entry in state GROWING, or -1
-__device__ __forceinline__ int mw_pick(const MwCtx& c)
-{
-    const int h = lds_u(c.ctl + C_HEAD), t = lds_u(c.ctl + C_TAIL);
-    const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
-    for (int base = h; base < t; base += 64) {
-        const int i = base + c.lane;
-        const int slot = i & c.mask;
-        const int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
-        bool el = st == ST_READY;
-        if (st == ST_PARKED) el = WG_LOAD(c.eBlock + slot) < wm;
-        if (st == ST_DONE) { const uint32_t iv = WG_LOAD(c.eInval + slot); el = iv != MW_FREE && iv < wm; }
-        unsigned long long m = __ballot(el);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            const int s = (base + l) & c.mask;
-            int exp = rlane(st, l);
-            int ok = 0;
-            if (c.lane == 0) ok = __hip_atomic_compare_exchange_strong(c.eState + s, &exp, (int)ST_GROWING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
-            if (uni(ok)) return s;
-            m &= m - 1ull;
-        }
-    }
-    return -1;
 }
 
 // tell the region whose tag is `victim` that the region of `rank` took one of its pixels
@@ -225,57 +200,169 @@ __device__ __forceinline__ void mw_notify(const MwCtx& c, uint32_t victim, uint3
     __hip_atomic_fetch_min(c.eInval + (victim & ((1u << MW_SLOT_BITS) - 1u)), rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// grow (or re-grow) the region of ROB entry `slot`, which this wave holds in state GROWING
-__device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double prec, double precWrap, const float* __restrict__ angDeg,
-                                       const double2* __restrict__ cosSin, const float2* __restrict__ seedCS)
+// next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do.
+// The loads (keys, seed words, owners, the seeds' table entries) are done before the lock is taken, the lock only covers the insertion;
+// isolated seeds (k_lsd_iso) are claimed right here, 64 at a time, and enter the ROB as finished one-pixel regions.
+__device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, const float* __restrict__ angDeg, const float2* __restrict__ seedCS)
 {
+    const int dn0 = cv.dispNext;
+    if (dn0 >= c.nkeys) return 0;
+    if (cv.tail - cv.head > c.E - 64) return 0;
+    const int rank = dn0 + c.lane;
+    const bool valid = rank < c.nkeys;
+    const int addr = valid ? (int)(c.keys[rank] & 0x3fffffu) : 0;
+    const uint32_t o = valid ? AG_LOAD(c.owner + addr) : 0u;
+    const uint32_t w = valid ? c.grad[addr] : 0u;
+    const bool iso = (w & kIso) != 0;
+    float deg = 0.f;
+    float2 ss = make_float2(0.f, 0.f);
+    if (valid && !iso) { deg = angDeg[w & 0x3fffffu]; ss = seedCS[w & 0x3fffffu]; }    // region_grow starts at the seed's angle and at (cos, sin) of it
+    if (!try_lock(c.ctl + C_LOCKDISP, c.lane)) return 1;
+    const MwCtl cl = mw_ctl(c.ctl);
+    const int dn = cl.dispNext, t = cl.tail, h = cl.head;
+    bool did = false, claim = false;
+    int s = 0;
+    if (dn == dn0 && t - h <= c.E - 64) {
+        const uint32_t wm = cl.wm;
+        const bool live = valid && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
+        const unsigned long long m = __ballot(live);
+        if (live) {
+            s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
+            claim = iso && o == MW_FREE;
+            c.eRank[s] = rank;
+            c.eSeed[s] = (uint32_t)addr | (iso ? 0x80000000u : 0u);
+            c.eInval[s] = MW_FREE;
+            c.eN[s] = 0;
+            c.eDeg[s] = deg; c.eSx[s] = ss.x; c.eSy[s] = ss.y;
+            c.eBlock[s] = o != MW_FREE ? (o >> MW_SLOT_BITS) : 0u;
+            c.eState[s] = o != MW_FREE ? (int)ST_PARKED : claim ? (int)ST_GROWING : (int)ST_READY;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + (int)__popcll(m)); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(dn + 64, c.nkeys)); }
+        did = true;
+    }
+    unlock(c.ctl + C_LOCKDISP, c.lane);
+    if (did && claim) {
+        const uint32_t T = ((uint32_t)rank << MW_SLOT_BITS) | (uint32_t)s;
+        const uint32_t old = __hip_atomic_fetch_min(c.owner + addr, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (old < T) {          // an older region took it in the meantime: consumed or to be re-examined once that region is final
+            c.eBlock[s] = old >> MW_SLOT_BITS;
+            __hip_atomic_store(c.eState + s, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (old != MW_FREE) mw_notify(c, old, (uint32_t)rank);     // a younger seed of a later window was quicker: the pixel is ours now
+            c.eN[s] = 1;
+            __hip_atomic_store(c.eState + s, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    return 1;
+}
+
+// lowest-rank entry that can be (re-)run now; returns its slot with the entry in state GROWING (its previous state in *prev), or -1
+__device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* prev)
+{
+    const int h = cv.head, t = cv.tail;
+    const uint32_t wm = cv.wm;
+    for (int base = h; base < t; base += 64) {
+        const int i = base + c.lane;
+        const int slot = i & c.mask;
+        const int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
+        const uint32_t bl = WG_LOAD(c.eBlock + slot), iv = WG_LOAD(c.eInval + slot);
+        const bool el = st == ST_READY || (st == ST_PARKED && bl < wm) || (st == ST_DONE && iv != MW_FREE && iv < wm);
+        unsigned long long m = __ballot(el);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            const int s = (base + l) & c.mask;
+            int exp = rlane(st, l);
+            int ok = 0;
+            if (c.lane == 0) ok = __hip_atomic_compare_exchange_strong(c.eState + s, &exp, (int)ST_GROWING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
+            if (uni(ok)) { *prev = rlane(st, l); return s; }
+            m &= m - 1ull;
+        }
+    }
+    return -1;
+}
+
+// grow (or re-grow) the region of ROB entry `slot`, which this wave holds in state GROWING
+#ifdef OLF_MW_PROF
+#define RUN_PROF_ARGS , long long& pf_t, long long* pf_acc
+#define RUN_PROF_PASS , pf_t, pf_acc
+#else
+#define RUN_PROF_ARGS
+#define RUN_PROF_PASS
+#endif
+__device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int wv, double prec, double precWrap, const float* __restrict__ angDeg,
+                                       const double2* __restrict__ cosSin RUN_PROF_ARGS)
+{
+    PROF_CNT(PF_NRUN);
     const int lane = c.lane, Ws = c.Ws, Hs = c.Hs;
-    const uint32_t rank = (uint32_t)lds_u(c.eRank + slot);
+    const int rank_v = WG_LOAD(c.eRank + slot);
+    const uint32_t sw_v = WG_LOAD(c.eSeed + slot);
+    const float deg_v = c.eDeg[slot], sx_v = c.eSx[slot], sy_v = c.eSy[slot];
+    const uint32_t rank = (uint32_t)uni(rank_v);
     const uint32_t T = (rank << MW_SLOT_BITS) | (uint32_t)slot;
-    const uint32_t sw = lds_u(c.eSeed + slot);
+    const uint32_t sw = (uint32_t)uni((int)sw_v);
     const int seed = (int)(sw & 0x3fffffu);
     uint32_t* ring = c.ring + wv * MW_RING;
     int* dir = c.dir + wv * MW_DIR;
-    {   // a finished region that was stolen from still holds its claims
+    // a claim whose result has not been looked at yet (this lane's atomicMin of the previous iteration; lane 0: the seed's)
+    uint32_t pOld = MW_FREE;
+    bool pMine = false;
+    if (prev != ST_READY) {
+        // re-run: the seed may have been consumed in the meantime, and a finished region that was stolen from still holds its claims
         const int nOld = lds_u(c.eN + slot);
         if (nOld > 0) { mw_release(c, slot, nOld, T); if (lane == 0) WG_STORE(c.eN + slot, 0); }
-    }
-    if (lane == 0) WG_STORE(c.eInval + slot, MW_FREE);      // steals from here on concern this run
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    uint32_t old0 = 0;
-    if (lane == 0) old0 = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    old0 = (uint32_t)uni((int)old0);
-    if (old0 < T) {
-        // claimed by an older region: consumed if that one is final, else wait for it
-        const bool fin = (old0 >> MW_SLOT_BITS) < (uint32_t)lds_u(c.ctl + C_WM);
-        if (lane == 0) {
-            if (!fin) WG_STORE(c.eBlock + slot, old0 >> MW_SLOT_BITS);
-            __hip_atomic_store(c.eState + slot, fin ? (int)ST_DEAD : (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) WG_STORE(c.eInval + slot, MW_FREE);      // steals from here on concern this run
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t old0 = 0;
+        if (lane == 0) old0 = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old0 = (uint32_t)uni((int)old0);
+        if (old0 < T) {
+            // claimed by an older region: consumed if that one is final, else wait for it
+            const bool fin = (old0 >> MW_SLOT_BITS) < (uint32_t)lds_u(c.ctl + C_WM);
+            if (lane == 0) {
+                if (!fin) WG_STORE(c.eBlock + slot, old0 >> MW_SLOT_BITS);
+                __hip_atomic_store(c.eState + slot, fin ? (int)ST_DEAD : (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            return;
         }
-        return;
+        if (old0 != MW_FREE && lane == 0) mw_notify(c, old0, rank);
+        if (sw & 0x80000000u) {
+            // no neighbour is aligned with the seed's own angle (k_lsd_iso): the region is the seed alone, whatever is used around it
+            if (lane == 0) { WG_STORE(c.eN + slot, 1); __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            return;
+        }
+    } else if (lane == 0) {
+        // first run of a seed that was free when it was dispatched: claim it and look at the answer with the first iteration's loads
+        pOld = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pMine = true;
     }
-    if (old0 != MW_FREE && lane == 0) mw_notify(c, old0, rank);
     const uint32_t seedXY = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16);
-    if (sw & 0x80000000u) {
-        // no neighbour is aligned with the seed's own angle (k_lsd_iso): the region is the seed alone, whatever is used around it
-        if (lane == 0) { WG_STORE(c.eN + slot, 1); __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        return;
-    }
-    const uint32_t pseed = c.grad[seed];
-    double reg_angle = d_mul((double)angDeg[pseed & 0x3fffffu], kDegToRads);
-    float sumdx, sumdy;
-    { const float2 s0 = seedCS[pseed & 0x3fffffu]; sumdx = s0.x; sumdy = s0.y; }
+    double reg_angle = d_mul((double)deg_v, kDegToRads);
+    float sumdx = sx_v, sumdy = sy_v;
     if (lane == 0) { ring[0] = seedXY; c.chunks[(size_t)slot * 32] = seedXY; c.links[slot] = -1; dir[0] = slot; }
     __builtin_amdgcn_wave_barrier();
     int n = 1, i = 0, cur = slot;
     uint32_t blocker = MW_FREE;
-    bool fail = false;
+    bool fail = false, seedLost = false;      // seedLost: the seed itself had been taken by an older region when this run claimed it
+    // results of the claims issued one iteration ago: a pixel an older region had taken between this region's test and its claim means the
+    // decisions since were made on a pixel that was not available -> yield (pOld == T: the own claim was not visible to the gather that
+    // followed it and the pixel was added twice -- not observed, but detected rather than assumed away); a younger region's pixel is
+    // ours now and that region is told
+#define MW_PENDING() do { \
+        if (pMine && pOld != MW_FREE && pOld > T) mw_notify(c, pOld, rank); \
+        const unsigned long long _bad = __ballot(pMine && pOld <= T); \
+        pMine = false; \
+        if (_bad) { const uint32_t _o = (uint32_t)rlane((int)pOld, __builtin_ctzll(_bad)); blocker = _o == T ? 0u : (_o >> MW_SLOT_BITS); fail = true; \
+                    seedLost = n == 1 && i == 0 && _bad == 1ull; \
+                    if (_o == T) PROF_CNT(PF_F_DUP); else PROF_CNT(PF_F_OLDER); } } while (0)
+    PROF(PF_PROLOGUE);
     while (i < n) {
-        {
-            const uint32_t iv = lds_u(c.eInval + slot);
-            if (iv != MW_FREE) { blocker = iv; fail = true; break; }
-        }
-        const uint32_t wm = (uint32_t)lds_u(c.ctl + C_WM);
+        PROF_CNT(PF_NITER);
+        const uint32_t iv_v = WG_LOAD(c.eInval + slot), wm_v = (uint32_t)WG_LOAD(c.ctl + C_WM);
+        const uint32_t iv = (uint32_t)uni((int)iv_v), wm = (uint32_t)uni((int)wm_v);
+        if (iv != MW_FREE) { blocker = iv; fail = true; PROF_CNT(PF_F_INVAL); break; }
         const int nb = min(7, n - i);
         const int e = lane / 9, k = lane - 9 * e;
         bool cand = lane < 63 && e < nb && k != 4;
@@ -299,6 +386,8 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double 
         // not mine, not used by a final region; an older, unfinished claim stays a candidate ("contested")
         cand = cand && !(pw & kNotDef) && o != T && !(o < T && (o >> MW_SLOT_BITS) < wm);
         const bool con = cand && o < T;
+        MW_PENDING();
+        if (fail) break;
         double ang = 0, cs = 0, sn = 0;
         if (cand) {
             const uint32_t ti = pw & 0x3fffffu;
@@ -308,6 +397,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double 
         }
         unsigned long long cm = __ballot(cand);
         const unsigned long long conM = __ballot(con);
+        PROF(PF_GATHER);
         unsigned long long acc = 0;
         const int n0 = n;
         while (cm) {
@@ -365,10 +455,11 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double 
             sumdy = __int_as_float(rlane(__float_as_int(psy), tt - 1));
             reg_angle = rlane_d(th, tt - 1);
         }
+        PROF(PF_CHAIN);
         if (acc & conM) {
             // the reference would add a pixel that an older, unfinished region holds right now: yield to that region
             blocker = (uint32_t)rlane((int)(o >> MW_SLOT_BITS), __builtin_ctzll(acc & conM));
-            n = n0; fail = true; break;
+            n = n0; fail = true; PROF_CNT(PF_F_CONTEST); break;
         }
         if (acc) {
             // chunks for list positions n0 .. n-1 (at most two new ones: an iteration adds <= 56 pixels)
@@ -390,32 +481,34 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double 
                 }
             }
             const bool mine = (acc >> lane) & 1ull;
-            uint32_t oldv = MW_FREE;
             if (mine) {
                 const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
-                oldv = __hip_atomic_fetch_min(c.owner + a, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pOld = __hip_atomic_fetch_min(c.owner + a, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pMine = true;
                 ring[idx & (MW_RING - 1)] = (uint32_t)xy;
                 const int ord = idx >> 5;
                 const int cid = ord == curOrd ? cur : (ord == curOrd + 1 ? new1 : new2);
                 c.chunks[(size_t)cid * 32 + (idx & 31)] = (uint32_t)xy;
             }
             if (lastOrd > curOrd) cur = new2 >= 0 ? new2 : new1;
-            // a pixel another region claimed between the test and the claim: an older one -> this region's decisions were made on a
-            // pixel that is not available: yield; a younger one -> it is ours now and that region is told
-            const unsigned long long bad = __ballot(mine && oldv < T);
-            if (mine && oldv != MW_FREE && oldv > T) mw_notify(c, oldv, rank);
-            if (bad) { blocker = (uint32_t)rlane((int)(oldv >> MW_SLOT_BITS), __builtin_ctzll(bad)); fail = true; break; }
         }
         i += nb;
         __builtin_amdgcn_wave_barrier();
+        PROF(PF_CLAIM);
     }
+    MW_PENDING();      // the last iteration's claims (steals are reported even when the region is given up)
+#undef MW_PENDING
     if (fail) {
-        mw_release(c, slot, n, T);
+        PROF_CNT(PF_NFAIL);
+        // the seed consumed by a region that is final already: resolved for good; anything else waits for the region it ran into
+        const bool dead = seedLost && blocker < (uint32_t)lds_u(c.ctl + C_WM);
+        if (!seedLost) mw_release(c, slot, n, T);
         if (lane == 0) {
             WG_STORE(c.eN + slot, 0);
             WG_STORE(c.eBlock + slot, blocker);
-            __hip_atomic_store(c.eState + slot, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(c.eState + slot, dead ? (int)ST_DEAD : (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        PROF(PF_FINISH);
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // list + links are in memory before the entry says DONE
@@ -424,11 +517,12 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int wv, double 
         c.eAng[slot] = reg_angle;
         __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    PROF(PF_FINISH);
 }
 
 size_t lsd_grow_mw_lds_bytes(int nw, int E)
 {
-    return (size_t)(C_N + 1 + MW_FREESTK) * 4 + (size_t)E * (6 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
+    return (size_t)(C_N + 1 + MW_FREESTK) * 4 + (size_t)E * (9 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
 }
 
 __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll, uint32_t* __restrict__ ownerAll,
@@ -452,6 +546,9 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         c.eInval = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
         c.eN = reinterpret_cast<int*>(p); p += (size_t)E * 4;
         c.eSeed = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
+        c.eDeg = reinterpret_cast<float*>(p); p += (size_t)E * 4;
+        c.eSx = reinterpret_cast<float*>(p); p += (size_t)E * 4;
+        c.eSy = reinterpret_cast<float*>(p); p += (size_t)E * 4;
         c.ring = reinterpret_cast<uint32_t*>(p); p += (size_t)nw * MW_RING * 4;
         c.dir = reinterpret_cast<int*>(p);
     }
@@ -471,19 +568,32 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     __syncthreads();
     const double prec = g.prec, precWrap = g.precWrap;
     int idle = 0;
+    PROF_DECL;
     for (;;) {
+        const MwCtl cv = mw_ctl(c.ctl);
         if (lds_u(c.ctl + C_ABORT)) break;
-        mw_commit(c);
-        const int slot = mw_pick(c);
-        if (slot >= 0) { idle = 0; mw_run(c, slot, wv, prec, precWrap, angDeg, cosSin, seedCS); continue; }
-        if (mw_dispatch(c)) continue;
+        mw_commit(c, cv);
+        PROF(PF_COMMIT);
+        int prev = ST_READY;
+        const int slot = mw_pick(c, cv, &prev);
+        PROF(PF_PICK);
+        if (slot >= 0) { idle = 0; mw_run(c, slot, prev, wv, prec, precWrap, angDeg, cosSin RUN_PROF_PASS); continue; }
+        const int dsp = mw_dispatch(c, cv, angDeg, seedCS);
+        PROF(PF_DISPATCH);
+        if (dsp) continue;
         // nothing to run, nothing to dispatch: finished, or waiting for other waves' regions
-        const int dn = lds_u(c.ctl + C_DISPNEXT);
-        const int t = lds_u(c.ctl + C_TAIL), h = lds_u(c.ctl + C_HEAD);
-        if (dn >= c.nkeys && h == t) break;
+        if (cv.dispNext >= c.nkeys && cv.head == cv.tail) {
+            // (snapshot: dispNext is published after tail, and nothing is inserted once dispNext has reached nkeys)
+            const MwCtl c2 = mw_ctl(c.ctl);
+            if (c2.dispNext >= c.nkeys && c2.head == c2.tail) break;
+        }
         __builtin_amdgcn_s_sleep(8);
+        PROF(PF_IDLE);
         if (++idle > (1 << 21)) { if (lane == 0) { atomicOr(status, 16); WG_STORE(c.ctl + C_ABORT, 1); } break; }
     }
+#ifdef OLF_MW_PROF
+    if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)pf_acc[q]);
+#endif
     __syncthreads();
     if (threadIdx.x == 0) regCount[img] = c.ctl[C_ABORT] ? 0 : c.ctl[C_NREG];
 }

@@ -13,7 +13,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_ANY SQ_WAVES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_ITEMS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -d $O/g$i -o run -- python $R/tools/prof_lines.py $N > $O/g$i.log 2>&1 || echo "group $i failed: $grp"
+  rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $O/g$i -o run -- python $R/tools/prof_lines.py $N > $O/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
 python $R/tools/pmc_sum.py $O k_lsd_grow > $O/summary.txt 2>&1
 cat $O/summary.txt
