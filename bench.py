@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- stereo frames/s for extract + match (ORB + LBD) on KITTI-size synthetic stereo, 1..8 GPUs.
+"""bench.py -- stereo frames/s for extract + match (ORB + LBD) on synthetic stereo, 1..8 GPUs (BASELINE.json's metric).
 
-One "step" = one pass of the whole hot path over one batch of B stereo pairs per GPU, inputs already
-resident in HBM: olf_stereo_frames_dev (ExtractORB x2, ExtractLine x2, ComputeStereoMatches,
-ComputeStereoMatches_Lines) + the frame-to-frame LBD match (match(), src/LineMatcher.cpp:104-132) and
-the frame-to-frame dense ORB kNN match against the previous frame of the batch.
-Workload = BASELINE.json configs[2]: 1242x375, 2000 ORB + 500 LBD (the config the metric is quoted on).
+One "step" = one pass of the whole hot path over one batch of B stereo pairs per GPU, inputs already resident in HBM:
+olf_stereo_frames_dev (ExtractORB x2, ExtractLine x2, ComputeStereoMatches, ComputeStereoMatches_Lines; reference src/Frame.cc:136-221)
++ the frame-to-frame LBD match (match(), src/LineMatcher.cpp:104-132) and the frame-to-frame dense ORB kNN match against the previous
+frame of the batch.  Workloads (--config): C2 640x480 1000+200, C3 KITTI 1242x375 2000+500 (default: the configuration
+the metric is quoted on), C4 EuRoC 752x480 1200+500, C5 1920x1080 4000+1000.
 
-Multi-GPU: frames are independent -> every rank processes its own B pairs (weak scaling,
-no data-path collective); rank 0 prints ONE JSON line with the whole-job aggregate.  The gather of the
-per-rank feature records to rank 0 is exercised once after the timed region (it is not part of a step).
+Multi-GPU: frames are independent -> every rank processes its own B pairs (weak scaling, no data-path collective).
+The design's one communication step runs INSIDE the timed region: after every step each rank packs the trimmed feature record of its
+batch (csrc/records.hip) and sends it to rank 0 (orb_line_slam_amd/distributed.py: one-word all_gather of the sizes + point-to-point
+sends, on a side stream, overlapped with the next step's kernels).  --verify: rank 0 re-runs every other rank's input (same seeds) and
+byte-compares the records it received with its own.
+
+The JSON line also carries: the dominant stage's roofline (algorithmic bytes / HIP-event duration, all stages considered), a measured
+copy-kernel ceiling next to the 8 TB/s specification, host-to-host latency of small batches (1, 8, 128 pairs per call), the PCIe-inclusive
+rate of the double-buffered offline pipeline, and the CPU oracle timed on this box's host cores in two shapes (A: 4 threads per frame, one
+frame at a time, like the reference; B: one frame per core on all cores).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 \
-        bench.py --gpus 8 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 bench.py --gpus 8 --steps 5 --warmup 2
 """
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -27,38 +35,54 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD lines, fx, bf, default pairs per GPU per step
+    "C2": dict(w=640, h=480, nf=1000, nl=200, fx=435.2047, bf=47.9064, pairs=4096),
+    "C3": dict(w=1242, h=375, nf=2000, nl=500, fx=718.856, bf=386.1448, pairs=3072),
+    "C4": dict(w=752, h=480, nf=1200, nl=500, fx=435.2047, bf=47.9064, pairs=3584),
+    "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=640),
+}
+STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
+                "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow",
+                "lsd_rect": "olf::k_lsd_rect", "line_select_lbd": "olf::k_lbd_rows", "stereo_lines": "olf::k_lines_dist", "match_bf": "olf::k_knn2"}
+
+
+def source_hash():
+    """Identifies the kernel sources a PMC summary was collected on (.git does not travel to the GPU box)."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "orb_line_slam_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 
 def algorithmic_bytes(W, H, N, NL, mean_len, nlevels=8, sf=1.2):
-    """SURVEY.md Appendix D, re-evaluated for this build's layouts (DESIGN.md "byte model"):
-    LSD keeps the integer gradient pair (4 B/px) instead of fp32 modgrad+angle (8 B/px); the pseudo-sort
-    reads it once and writes 4-byte keys for the defined pixels (budgeted for all pixels); region growing
-    reads grad (4) + r/w used (2)."""
-    lv = []
-    s = 1.0
+    """SURVEY.md Appendix D per image and stage, re-evaluated for this build's layouts (DESIGN.md "byte model"): LSD keeps the integer
+    gradient pair (4 B/px) instead of fp32 modgrad + angle (8 B/px); the pseudo-sort reads it once and writes 4-byte keys; region growing
+    reads the gradient word (4) and reads + writes the used / owner state (2, as the reference's byte map)."""
+    lv, s = [], 1.0
     for _ in range(nlevels):
         lv.append((int(round(W / s)), int(round(H / s))))
         s *= sf
     P = [w * h for w, h in lv]
     Pp, P0, P7 = sum(P), P[0], P[-1]
-    Ws, Hs = int(round(W * 1.2)), int(round(H * 1.2))
-    Ps = Ws * Hs
-    orb = P0 + (Pp - P0) + (Pp - P7) + Pp + 2 * Pp + 749 * N + (512 + 32 + 28) * N
-    lsd = 2 * P0 + (P0 + Ps) + (Ps + 4 * Ps) + (4 * Ps + 4 * Ps) + (4 * Ps + 2 * Ps)
-    lbd = 2 * P0 + (P0 + 4 * P0) + 63 * mean_len * 4 * NL + (32 + 68) * NL
-    grow = (4 + 2) * Ps
-    return dict(orb=orb, lsd=lsd, lbd=lbd, pair=2 * (orb + lsd + lbd), grow_per_image=grow, Ps=Ps, Pp=Pp)
+    Ps = int(round(W * 1.2)) * int(round(H * 1.2))
+    st = {"orb_pyramid": P0 + (Pp - P0) + (Pp - P7), "orb_fast": Pp, "orb_octree": 0, "orb_blur": 2 * Pp, "orb_describe": (749 + 512 + 32 + 28) * N,
+          "stereo_points": 0, "lsd_front": 2 * P0 + (P0 + Ps) + (Ps + 4 * Ps) + (4 * Ps + 4 * Ps), "lsd_grow": (4 + 2) * Ps, "lsd_rect": 0,
+          "line_select_lbd": 2 * P0 + (P0 + 4 * P0) + 63 * mean_len * 4 * NL + (32 + 68) * NL, "stereo_lines": 0, "match_bf": 0}
+    orb = st["orb_pyramid"] + st["orb_fast"] + st["orb_blur"] + st["orb_describe"]
+    lsd = st["lsd_front"] + st["lsd_grow"]
+    return dict(stage=st, orb=orb, lsd=lsd, lbd=st["line_select_lbd"], pair=2 * (orb + lsd + st["line_select_lbd"]), Ps=Ps, Pp=Pp)
 
 
 def cpu_baseline(W, H, params, seconds_budget=20.0):
-    """The CPU oracle (oracle/liboracle_fast.so, -O3 -march=native -ffp-contract=off) timed on this box's host
-    cores in the reference's shape: 4 std::threads per frame (src/Frame.cc:164-171), frames one at a time."""
+    """The CPU oracle (oracle/liboracle_fast.so, -O3 -march=native -ffp-contract=off; the reference itself cannot be built: OpenCV / Eigen /
+    Pangolin are not in the image) timed on this box's host cores.  Mode A, the reference's shape: 4 std::threads per frame
+    (src/Frame.cc:164-171), frames one at a time -- the per-frame latency.  Mode B, throughput: one frame per core on all cores."""
     import subprocess
     subprocess.run(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True)   # -march=native: always rebuilt on the box that runs it
     L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
     from orb_line_slam_amd import synth
-    times = []
-    t_all = time.time()
-    seed = 1000
+    times, t_all, seed = [], time.time(), 1000
     while True:
         l, r = synth.stereo_pair(seed, W, H)
         seed += 1
@@ -69,13 +93,46 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
                                 None, None, C.byref(n[2]), None, None, C.byref(n[3]), 1 << 20, None, None, None)
         times.append(time.perf_counter() - t)
         assert rc == 0
-        if (time.time() - t_all > seconds_budget and len(times) >= 8) or len(times) >= 400:
+        if (time.time() - t_all > seconds_budget * 0.6 and len(times) >= 8) or len(times) >= 400:
             break
     times = np.array(times[2:])   # drop warm-up
     med = float(np.median(times))
-    return {"value": round(1.0 / med, 3), "unit": "stereo frames/s", "cores": 4, "kind": "port",
-            "sample": f"{len(times)} synthetic {W}x{H} stereo pairs, one at a time, 4 threads/frame like src/Frame.cc:164-171, "
-                      f"median {med * 1e3:.1f} ms/frame (mean {times.mean() * 1e3:.1f})", "host_cores": os.cpu_count()}
+    out = {"value": round(1.0 / med, 3), "unit": "stereo frames/s", "cores": 4, "kind": "port",
+           "sample": f"{len(times)} synthetic {W}x{H} stereo pairs, one at a time, 4 threads/frame like src/Frame.cc:164-171, "
+                     f"median {med * 1e3:.1f} ms/frame (mean {times.mean() * 1e3:.1f})", "host_cores": os.cpu_count()}
+    # Mode B: all cores, one frame per thread at a time (threads = 1 inside a frame)
+    try:
+        cores = len(os.sched_getaffinity(0))
+        nd = 16
+        imgs = synth.stereo_batch(2000, nd, W, H)
+        L.orc_stereo_frames_throughput.restype = C.c_double
+        L.orc_stereo_frames_throughput.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        frames = max(cores * 2, 16)
+        fps = L.orc_stereo_frames_throughput(imgs.ctypes.data_as(C.c_void_p), nd, W, H, C.byref(params), cores, frames)
+        out["mode_b"] = {"value": round(float(fps), 2), "unit": "stereo frames/s", "cores": cores,
+                         "sample": f"{frames} frames ({nd} distinct), one frame per thread, {cores} threads"}
+    except Exception as e:   # the throughput leg is extra information: never lose the line over it
+        out["mode_b"] = {"error": str(e)}
+    return out
+
+
+def small_batch_latency(params, W, H, sizes=(1, 8, 128)):
+    """Host buffers in, host buffers out (olf_stereo_frames, what a Frame constructor would call): milliseconds per call."""
+    import orb_line_slam_amd as ola
+    from orb_line_slam_amd import synth
+    out = {}
+    for n in sizes:
+        fe = ola.StereoFrontEnd(params, W, H, max_pairs=n)
+        imgs = synth.stereo_batch(11, min(n, 16), W, H)
+        imgs = np.tile(imgs, ((n + 15) // 16, 1, 1))[:2 * n].copy()
+        fe.frames(imgs)
+        reps = 5 if n <= 8 else 3
+        t = time.perf_counter()
+        for _ in range(reps):
+            fe.frames(imgs)
+        out[str(n)] = round((time.perf_counter() - t) / reps * 1e3, 3)
+        fe.ctx.close()
+    return out
 
 
 def main():
@@ -83,19 +140,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=3072, help="stereo pairs per GPU per step")
-    ap.add_argument("--width", type=int, default=1242)
-    ap.add_argument("--height", type=int, default=375)
-    ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--lines", type=int, default=500)
-    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic pairs (tiled to --pairs)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
+    ap.add_argument("--pairs", type=int, default=0, help="stereo pairs per GPU per step (0: the configuration's default)")
+    ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic pairs per rank (tiled to --pairs)")
+    ap.add_argument("--scene", choices=("default", "long"), default="default", help="long: fewer, larger shapes -> key lines of about 0.08*W pixels (SURVEY App. D's model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
+    ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
     args = ap.parse_args()
 
     import torch
     import orb_line_slam_amd as ola
-    from orb_line_slam_amd import _lib, synth
+    from orb_line_slam_amd import _lib, synth, records
     from orb_line_slam_amd._lib import FrameBuffers, check, lib
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,29 +171,35 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    W, H, B = args.width, args.height, args.pairs
+    cfg = CONFIGS[args.config]
+    W, H = cfg["w"], cfg["h"]
+    B = args.pairs or cfg["pairs"]
     # the batch lives in HBM (context buffers + outputs, about 62 MB per KITTI pair): shrink it if this GPU has less free memory than the
-    # default batch needs, and use the same size on every rank
+    # batch needs, and use the same size on every rank
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    per_pair = 62e6 * (W * H) / (1242 * 375)
-    fit = int((free_b - 6e9) / per_pair) // 256 * 256
+    per_pair = 62e6 * (W * H) / (1242 * 375) * (1.15 if world > 1 else 1.0)     # + packed records (double buffered) when they are gathered
+    fit = int((free_b - 6e9) / per_pair) // 64 * 64
     if fit < B:
-        print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 256)}", file=sys.stderr, flush=True)
-        B = max(fit, 256)
+        print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 64)}", file=sys.stderr, flush=True)
+        B = max(fit, 64)
     if world > 1:
         tb = torch.tensor([B], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         B = int(tb.item())
     params = _lib.default_params()
-    params.orb.nfeatures, params.line.lsd_nfeatures = args.features, args.lines
+    params.orb.nfeatures, params.line.lsd_nfeatures = cfg["nf"], cfg["nl"]
+    params.stereo.fx, params.stereo.bf = cfg["fx"], cfg["bf"]
     ctx = _lib.Context(params, W, H, 2 * B)
     cap, lcap = ctx.orb_capacity, ctx.line_capacity
 
     # synthetic input: `distinct` seeded pairs per rank, tiled to B pairs, resident in HBM before timing
     nd = min(args.distinct, B)
-    host = synth.stereo_batch(7000 + 1000 * rank, nd, W, H)
-    reps = (B + nd - 1) // nd
-    imgs = torch.from_numpy(np.tile(host, (reps, 1, 1))[:2 * B].copy()).to(dev)
+
+    def make_input(r):
+        host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=args.scene)
+        reps = (B + nd - 1) // nd
+        return torch.from_numpy(np.tile(host, (reps, 1, 1))[:2 * B].copy()).to(dev)
+    imgs = make_input(rank)
 
     def z(shape, dt):
         return torch.zeros(shape, dtype=dt, device=dev)
@@ -148,9 +212,9 @@ def main():
     Lh = lib()
     nnr_l = float(params.stereo.min_ratio_12_l)
 
-    def step():
+    def step(images):
         s = torch.cuda.current_stream().cuda_stream
-        check(Lh.olf_stereo_frames_dev(ctx.handle, imgs.data_ptr(), B, C.byref(fb), s), "olf_stereo_frames_dev")
+        check(Lh.olf_stereo_frames_dev(ctx.handle, images.data_ptr(), B, C.byref(fb), s), "olf_stereo_frames_dev")
         if B > 1:
             # frame i (left image 2i) against frame i-1: match(last.mDescriptors_Line, cur.mDescriptors_Line) (src/Tracking.cc:1308)
             check(Lh.olf_match_bf_dev(ctx.handle, ldesc.data_ptr() + 2 * lcap * 32, lcounts.data_ptr() + 8, 2 * lcap, 2, ldesc.data_ptr(),
@@ -159,18 +223,58 @@ def main():
             check(Lh.olf_match_bf_dev(ctx.handle, desc.data_ptr() + 2 * cap * 32, counts.data_ptr() + 8, 2 * cap, 2, desc.data_ptr(),
                                       counts.data_ptr(), 2 * cap, 2, B - 1, 0.7, 1, f2f_orb.data_ptr(), s), "olf_match_bf_dev(orb)")
 
+    # ---- the gather of the feature records to rank 0 (N > 1) ---------------------------------------------------------------------
+    gather_on = world > 1 and args.gather != "off"
+    gstat = {"bytes": 0, "seconds": 0.0, "last": None}
+    if gather_on:
+        from orb_line_slam_amd.distributed import gather_records
+        bound = int(Lh.olf_frames_pack_bound(ctx.handle, B))
+        # the trimmed record is about half of the bound at the configured feature counts; a record that does not fit is reported by ctx.synchronize()
+        pk_bytes = bound if args.verify else bound // 2 + (1 << 20)
+        packed = [torch.empty(pk_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        nbytes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+        ev = [torch.cuda.Event() for _ in range(2)]
+        recv = [torch.empty(pk_bytes, dtype=torch.uint8, device=dev) if (rank == 0 and r != 0) else None for r in range(world)]
+        comm_stream = torch.cuda.Stream(device=dev) if args.gather == "overlap" else torch.cuda.current_stream()
+
+        def pack(k):
+            s = torch.cuda.current_stream().cuda_stream
+            check(Lh.olf_frames_pack_dev(ctx.handle, C.byref(fb), B, packed[k % 2].data_ptr(), pk_bytes, nbytes[k % 2].data_ptr(), s), "olf_frames_pack_dev")
+            ev[k % 2].record()
+
+        def comm(k):
+            # ordered after the pack of step k; the main stream is already running step k+1 underneath
+            t = time.perf_counter()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev[k % 2])
+                n = int(nbytes[k % 2].item())
+                recs, sizes = gather_records(packed[k % 2], min(n, pk_bytes), dist, 0, recv if rank == 0 else None)
+                comm_stream.synchronize()
+            gstat["seconds"] += time.perf_counter() - t
+            gstat["bytes"] += sum(sizes) - sizes[0]
+            gstat["last"] = (recs, sizes)
+
+    def run_steps(n):
+        for k in range(n):
+            step(imgs)
+            if gather_on:
+                pack(k)
+                if k > 0:
+                    comm(k - 1)
+        if gather_on and n > 0:
+            comm(n - 1)
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
+    gstat["bytes"], gstat["seconds"] = 0, 0.0
     ctx.profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     ctx.synchronize()                        # outside the timed region: raises if any step overflowed a fixed-capacity device buffer
@@ -180,51 +284,93 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # the only collective of the design: gather the (trimmed) feature records to rank 0, outside the timed region
-        try:
-            from orb_line_slam_amd.distributed import gather_counts
-            gather_counts(counts, lcounts, dist)
-        except Exception as e:   # the gather is not part of the measurement: report, do not lose the bench line
-            print(f"[rank {rank}] gather_to_rank0 failed: {e}", file=sys.stderr, flush=True)
 
+    verify = None
+    if gather_on and args.verify:
+        # rank 0 runs every other rank's input itself and compares the record it received in the last step, byte for byte
+        if rank == 0:
+            recs, sizes = gstat["last"]
+            verify = {"ranks": world, "identical": True}
+            for r in range(1, world):
+                step(make_input(r))
+                pack(0)
+                torch.cuda.synchronize()
+                n = int(nbytes[0].item())
+                mine = records.merge_records([packed[0][:n].cpu().numpy().tobytes()])         # normalises the padding between sections
+                theirs = records.merge_records([recs[r].cpu().numpy().tobytes()])
+                if mine != theirs:
+                    verify["identical"] = False
+                    verify.setdefault("mismatch", []).append(r)
+        dist.barrier()
+
+    out = None
     if rank == 0:
         total_pairs = world * B * args.steps
         fps = total_pairs / dt
         nk = counts.float().mean().item(); nkl = lcounts.float().mean().item()
         kl_np = kls.cpu().numpy().view(ola.KEYLINE_DTYPE).reshape(2 * B, lcap)
         lc_np = lcounts.cpu().numpy()
-        mean_len = float(np.mean([kl_np[i, :lc_np[i]]["numOfPixels"].mean() for i in range(min(2 * B, 64)) if lc_np[i] > 0]))
+        mean_len = float(np.mean([kl_np[i, :lc_np[i]]["numOfPixels"].mean() for i in range(min(2 * B, 256)) if lc_np[i] > 0]))
         ab = algorithmic_bytes(W, H, nk, nkl, mean_len)
         stages = {k: {"ms_per_step": v[0] / max(args.steps, 1), "calls": v[1]} for k, v in prof.items() if v[1]}
-        dom = max(("lsd_grow", "orb_octree", "orb_describe"), key=lambda k: stages.get(k, {"ms_per_step": 0})["ms_per_step"])
+        # dominant stage: the largest HIP-event time per step over ALL stages
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
         dom_ms = stages[dom]["ms_per_step"] / max(stages[dom]["calls"] // args.steps, 1)
-        per_launch_bytes = {"lsd_grow": ab["grow_per_image"] * 2 * B,
-                            "orb_octree": 0, "orb_describe": (749 + 512 + 32 + 28) * nk * 2 * B}[dom]
+        per_launch_bytes = ab["stage"].get(dom, 0) * 2 * B
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/*_pmc_hbm_traffic.json,
-        # KiB counters, per image), scaled to this launch's image count; null when no PMC summary has been committed for the kernel.
-        traffic = None
+        # HBM traffic of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/*_pmc_hbm_traffic.json, per
+        # image), valid only for the sources it was collected on: the summary carries a hash of csrc/, anything else gives null
+        traffic, sh = None, source_hash()
         try:
-            import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]))    # latest committed PMC summary
-            kname = {"lsd_grow": "olf::k_lsd_grow", "orb_octree": "olf::k_octree", "orb_describe": "olf::k_describe"}[dom]
-            if kname in pm["kernels"]:
-                traffic = int(pm["kernels"][kname]["bytes_per_image"] * 2 * B)
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
+                pm = json.load(open(f))
+                if pm.get("source_hash") == sh and STAGE_KERNEL[dom] in pm["kernels"]:
+                    traffic = int(pm["kernels"][STAGE_KERNEL[dom]]["bytes_per_image"] * 2 * B)
+                    break
         except Exception:
             traffic = None
         out = {
-            "metric": "stereo frames/s extract+match (ORB+LBD), KITTI 1242x375", "value": round(fps, 2), "unit": "stereo frames/s",
+            "metric": f"stereo frames/s extract+match (ORB+LBD), {'KITTI ' if args.config == 'C3' else ''}{W}x{H}", "value": round(fps, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} stereo, {args.features} ORB + {args.lines} LBD per image, extract + stereo point/line match + "
+            "config": {"workload": f"{args.config}: {W}x{H} stereo, {cfg['nf']} ORB + {cfg['nl']} LBD per image, extract + stereo point/line match + "
                                    f"f2f LBD match + f2f dense ORB kNN match", "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
-                       "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1), "mean_line_pixels": round(mean_len, 1)},
-            "roofline": {"bound": "hbm", "kernel": {"lsd_grow": "olf::k_lsd_grow", "orb_octree": "olf::k_octree", "orb_describe": "olf::k_describe"}[dom],
-                         "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(dom_ms, 4),
-                         "path_bytes_per_pair": int(ab["pair"]), "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6)},
+                       "distinct_pairs": nd, "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
+                       "mean_line_pixels": round(mean_len, 1), "source_hash": sh},
+            "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                         "avg_launch_ms": round(dom_ms, 4), "path_bytes_per_pair": int(ab["pair"]),
+                         "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6)},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
         }
+        if gather_on:
+            out["gather"] = {"mode": args.gather, "bytes_per_step": int(gstat["bytes"] / max(args.steps, 1)),
+                             "GBps": round(gstat["bytes"] / max(gstat["seconds"], 1e-9) / 1e9, 3),
+                             "host_seconds_per_step": round(gstat["seconds"] / max(args.steps, 1), 5), "verify": verify}
+        if not args.no_extras:
+            # measured ceiling of a plain copy kernel, next to the 8 TB/s of the specification
+            try:
+                g = C.c_double()
+                check(Lh.olf_debug_copy_bandwidth(ctx.handle, 1 << 30, 20, C.byref(g)), "olf_debug_copy_bandwidth")
+                out["roofline"]["copy_kernel_GBps"] = round(g.value, 1)
+                out["roofline"]["frac_of_copy_kernel"] = round(achieved / g.value, 6)
+            except Exception as e:
+                out["roofline"]["copy_kernel_GBps"] = None
+                print(f"copy ceiling failed: {e}", file=sys.stderr)
+    del imgs, kps, desc, ur, dp, kls, ldesc, lm, ldisp, lle, f2f_lines, f2f_orb
+    ctx.close()
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if not args.no_extras:
+            try:
+                out["pair_latency_ms"] = small_batch_latency(params, W, H)
+            except Exception as e:
+                out["pair_latency_ms"] = {"error": str(e)}
+            try:
+                from orb_line_slam_amd.pipeline import pcie_inclusive_rate
+                out["pcie_inclusive"] = pcie_inclusive_rate(params, W, H, pairs=min(B, 1024), batches=4)
+            except Exception as e:
+                out["pcie_inclusive"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, H, params, args.cpu_seconds)
         print(json.dumps(out), flush=True)

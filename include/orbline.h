@@ -32,6 +32,10 @@ int olf_device_count(void);                 /* number of visible HIP devices (0 
 int olf_default_params(olf_params* p);
 
 /* context: replaces constructing ORBextractor x2 + Lineextractor x2 (src/Tracking.cc:131-142) */
+/* A context belongs to the device that is current when it is created (calls made with another device current return OLF_ERR_INVALID) and
+ * to ONE host thread.  Its scratch buffers are shared by every call, so at most one stream may have work of a context in flight at a time:
+ * the *_dev entry points accept any stream, but work enqueued on a second stream must be ordered after the first (event / synchronise) by
+ * the caller. */
 int  olf_ctx_create(const olf_params* p, int width, int height, int max_images, olf_ctx** out);
 void olf_ctx_destroy(olf_ctx* ctx);
 /* Capacity overflows (more corners / key points / segments than a fixed-size device buffer holds) are never silent: the blocking
@@ -287,6 +291,17 @@ typedef struct olf_frame_buffers {
  * device pointers for the _dev form, host pointers otherwise. */
 int olf_stereo_frames_dev(olf_ctx* ctx, const uint8_t* d_images, int n_pairs, const olf_frame_buffers* out, void* stream);
 int olf_stereo_frames(olf_ctx* ctx, const uint8_t* images, int n_pairs, const olf_frame_buffers* out);
+
+/* ---- multi-GPU: the trimmed wire record of a batch ------------------------------------------------------------------
+ * What a rank sends to rank 0 after a batch: header, counts, then only the rows in use of every array of olf_frame_buffers (layout in
+ * csrc/records.hip; host mirror and parser in orb_line_slam_amd/records.py).  `out` holds device pointers; d_dst >= olf_frames_pack_bound
+ * bytes is always enough; *d_bytes (device or pinned host memory) receives the record size.  A record larger than dst_capacity sets the
+ * capacity flag (olf_ctx_synchronize) and writes only the header. */
+size_t olf_frames_pack_bound(const olf_ctx* ctx, int n_pairs);
+int olf_frames_pack_dev(olf_ctx* ctx, const olf_frame_buffers* out, int n_pairs, uint8_t* d_dst, size_t dst_capacity, uint64_t* d_bytes, void* stream);
+/* measurement: rate of a plain 16-byte-per-thread device copy kernel over `bytes` (read + written bytes per second): the practical HBM
+ * ceiling bench.py reports next to the specification's 8 TB/s */
+int olf_debug_copy_bandwidth(olf_ctx* ctx, size_t bytes, int reps, double* gbytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,8 @@ void stereo_lines(const std::vector<olf_keyline>& klL, const uint8_t* descL, con
                   std::vector<double>& le);
 }
 #include <thread>
+#include <atomic>
+#include <chrono>
 using namespace orc;
 
 extern "C" {
@@ -96,6 +98,30 @@ int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, con
     if (ldescR) std::memcpy(ldescR, dr.data(), dr.size());
     if (lm12) for (size_t i = 0; i < m.size(); ++i) { lm12[i] = m[i]; ldisp[2 * i] = dsp[2 * i]; ldisp[2 * i + 1] = dsp[2 * i + 1]; lle[3 * i] = le[3 * i]; lle[3 * i + 1] = le[3 * i + 1]; lle[3 * i + 2] = le[3 * i + 2]; }
     return OLF_OK;
+}
+
+// cpu_baseline "mode B" of bench.py: n_threads workers, each running whole frames (the four extractions back to back) taken from a shared
+// counter, over n_frames frames cycling through n_distinct stereo pairs (imgs: [2 * n_distinct][h][w]); returns stereo frames per second
+double orc_stereo_frames_throughput(const uint8_t* imgs, int n_distinct, int w, int h, const olf_params* p, int n_threads, int n_frames)
+{
+    std::atomic<int> next(0), failed(0);
+    const size_t npx = (size_t)w * h;
+    auto worker = [&] {
+        for (;;) {
+            const int f = next.fetch_add(1);
+            if (f >= n_frames) return;
+            const int d = f % n_distinct;
+            int a, b, c, e;
+            if (orc_stereo_frame(imgs + (size_t)(2 * d) * npx, imgs + (size_t)(2 * d + 1) * npx, w, h, p, 1, nullptr, nullptr, &a, nullptr, nullptr, &b, 1 << 20,
+                                 nullptr, nullptr, nullptr, nullptr, &c, nullptr, nullptr, &e, 1 << 20, nullptr, nullptr, nullptr) != OLF_OK) failed.fetch_add(1);
+        }
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_threads; ++i) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return failed.load() ? -1.0 : n_frames / sec;
 }
 
 }  // extern "C"

@@ -12,7 +12,10 @@
 //   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:47-131 (+ RadiusByViewingCos :133-139)
 //   ORBmatcher::ComputeThreeMaxima                                    src/ORBmatcher.cc:1749-1790
 //   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea        src/Frame.cc:334-349, :572-582, :517-570
-// cv::Mat products of CV_32F operands (Rcw*x3Dw+tcw) accumulate in double and round once (cv::gemm generic path).
+// cv::Mat products of CV_32F operands (convention C.12): a plain product of inner length 3 (Rcw*x3Dw+tcw, Rlw*twc+tlw, sR21*p+t21, -sR21*t12)
+// takes cv::gemm's small-matrix path -- the three products summed in float, alpha / the C term applied in double, one rounding; a product
+// with a transposed operand (-Rcw.t()*tcw) takes the generic path -- double accumulation, one rounding.  Recalled from OpenCV 3.4
+// matmul.cpp; OpenCV is not in the image, so this is a stated convention, not a verified fact.
 // PARITY UNPINNED (see oracle_common.hpp).
 #include "oracle_common.hpp"
 #include <climits>
@@ -79,9 +82,8 @@ static void three_maxima(std::vector<int>* histo, int L, int& ind1, int& ind2, i
 static void mat3_mul_add(const float* T /*4x4 row-major*/, const float v[3], float out[3])   // R*v + t
 {
     for (int r = 0; r < 3; ++r) {
-        double acc = 0;
-        for (int k = 0; k < 3; ++k) acc += (double)T[4 * r + k] * v[k];
-        out[r] = (float)(acc + (double)T[4 * r + 3]);
+        const float t = T[4 * r] * v[0] + T[4 * r + 1] * v[1] + T[4 * r + 2] * v[2];      // float sum of the three products
+        out[r] = (float)((double)t + (double)T[4 * r + 3]);
     }
 }
 }  // namespace orc
@@ -513,12 +515,13 @@ extern "C" void orc_is_in_frustum(const float* Tcw, const float* cam9, const flo
 // ---- Sim3 searches of the loop closer -------------------------------------------------------------------------------------------
 // cv::Mat scalar algebra used below (CV_32F): `M / s` and `s * M` are MatExpr scalings evaluated by convertTo, i.e. every element times
 // the double factor rounded to float ((float)(1.0 / s), (float)s); Mat::dot accumulates float products in double; `-A*b` is a gemm with
-// alpha = -1 (double accumulation, one rounding, as everywhere in this file).
-static void r3_mul_add(const float* R9, const float* v, const float* t3, float out[3], double alpha = 1.0)
+// alpha = -1 (small-matrix path unless an operand is transposed, see the header).
+static void r3_mul_add(const float* R9, const float* v, const float* t3, float out[3], double alpha = 1.0, bool transposed = false)
 {
     for (int r = 0; r < 3; ++r) {
         double acc = 0;
-        for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * v[k];
+        if (transposed) for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * v[k];
+        else { const float t = R9[3 * r] * v[0] + R9[3 * r + 1] * v[1] + R9[3 * r + 2] * v[2]; acc = (double)t; }
         out[r] = (float)(alpha * acc + (t3 ? (double)t3[r] : 0.0));
     }
 }
@@ -536,7 +539,7 @@ extern "C" void orc_sim3_decompose(const float* Scw /*4x4 row-major*/, float* Rc
     }
     float Rt[9];
     for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Rt[3 * r + k] = Rcw9[3 * k + r];
-    r3_mul_add(Rt, tcw3, nullptr, Ow3, -1.0);
+    r3_mul_add(Rt, tcw3, nullptr, Ow3, -1.0, true);      // Ow = -Rcw.t() * tcw: transposed operand, generic path
 }
 
 static int predict_scale(float maxd, float dist, float logScaleFactor, int nLevels)     // MapPoint::PredictScale, src/MapPoint.cc:414-429

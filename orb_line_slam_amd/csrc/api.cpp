@@ -45,6 +45,8 @@ struct olf_ctx {
     float* d_ldisp = nullptr;
     double* d_lle = nullptr;
     hipStream_t stream2 = nullptr;
+    bool mark_front = false;
+    hipEvent_t ev_front = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
     bool prof_on = false;
@@ -59,16 +61,32 @@ struct olf_ctx {
     std::vector<void*> allocs;
 };
 
+// A context (and everything it owns) lives on the device that was current when it was created; calling into it with another device
+// current would send its launches and allocations to the wrong GPU.
+static int check_device(const olf_ctx* c, const char* who)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d != c->device) { set_error(std::string(who) + ": the context belongs to another device than the current one"); return OLF_ERR_INVALID; }
+    return OLF_OK;
+}
+
 static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
 {
     if (c->scratch_bytes[slot] < bytes) {
-        if (c->scratch[slot]) { OLF_HIP_CHECK(hipStreamSynchronize(c->stream)); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
+        if (c->scratch[slot]) { OLF_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(c->scratch[slot]); c->scratch[slot] = nullptr; c->scratch_bytes[slot] = 0; }
         size_t want = std::max<size_t>(bytes * 3 / 2, 4096);
         OLF_HIP_CHECK(hipMalloc(&c->scratch[slot], want));
         c->scratch_bytes[slot] = want;
     }
     *out = c->scratch[slot];
     return OLF_OK;
+}
+
+namespace olf {
+int launch_pack_records(const olf_frame_buffers& fb, int n_pairs, int cap, int lcap, uint8_t* d_dst, size_t dst_capacity, int* d_rowOfs,
+                        unsigned long long* d_bytes, int* d_status, hipStream_t s);
+size_t pack_records_bound(int n_pairs, int cap, int lcap);
+int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);
 }
 
 namespace olf {
@@ -194,7 +212,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
     const LineGeom& lg = c->line.geom;
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }
     LineDeviceBufs& l = c->lb;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
@@ -310,6 +328,7 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
                         void* stream)
 {
     if (!c || !d_images || !d_kps || !d_desc || !d_counts) { set_error("olf_orb_extract_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_orb_extract_dev"));
     if (n_images < 0 || n_images > c->max_images) { set_error("olf_orb_extract_dev: n_images exceeds the context capacity"); return OLF_ERR_CAPACITY; }
     if (n_images == 0) return OLF_OK;   // ORBextractor::operator() returns silently on an empty image
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -329,7 +348,8 @@ static int check_status(olf_ctx* c)
     OLF_HIP_CHECK(hipMemcpy(st, c->ob.status, sizeof(st), hipMemcpyDeviceToHost));
     if (st[0]) {
         (void)hipMemset(c->ob.status, 0, 16);
-        set_error("device capacity overflow, flags=" + std::to_string(st[0]));
+        set_error("device capacity overflow, flags=" + std::to_string(st[0]) +
+                  " (1/2/4: ORB corner / candidate / key point buffers, 8: LSD regions, segments or pixel-list pool, 16: LSD growth watchdog, 32: frame record buffer)");
         return OLF_ERR_CAPACITY;
     }
     return OLF_OK;
@@ -365,6 +385,46 @@ int olf_debug_status(olf_ctx* c, int32_t* out64)
     if (!c || !out64) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipDeviceSynchronize());
     OLF_HIP_CHECK(hipMemcpy(out64, c->ob.status, 256, hipMemcpyDeviceToHost));
+    return OLF_OK;
+}
+
+size_t olf_frames_pack_bound(const olf_ctx* c, int n_pairs)
+{
+    return c && n_pairs >= 0 ? olf::pack_records_bound(n_pairs, c->orb.geom.outCap, c->line.geom.outCap) : 0;
+}
+
+int olf_frames_pack_dev(olf_ctx* c, const olf_frame_buffers* fb, int n_pairs, uint8_t* d_dst, size_t dst_capacity, uint64_t* d_bytes, void* stream)
+{
+    if (!c || !fb || !d_dst || !d_bytes || n_pairs < 0 || 2 * n_pairs > c->max_images || dst_capacity < 64 + (size_t)16 * n_pairs + 16) {
+        set_error("olf_frames_pack_dev: bad argument"); return OLF_ERR_INVALID;
+    }
+    OLF_TRY(check_device(c, "olf_frames_pack_dev"));
+    void* ofs = nullptr;
+    OLF_TRY(scratch_get(c, 3, (size_t)8 * n_pairs * sizeof(int) + 64, &ofs));
+    return olf::launch_pack_records(*fb, n_pairs, c->orb.geom.outCap, c->line.geom.outCap, d_dst, dst_capacity, static_cast<int*>(ofs),
+                                    reinterpret_cast<unsigned long long*>(d_bytes), c->ob.status, stream ? (hipStream_t)stream : c->stream);
+}
+
+int olf_debug_copy_bandwidth(olf_ctx* c, size_t bytes, int reps, double* gbytes_per_s)
+{
+    if (!c || !gbytes_per_s || bytes < 16 || reps < 1) { set_error("olf_debug_copy_bandwidth: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_debug_copy_bandwidth"));
+    void *a = nullptr, *b = nullptr;
+    OLF_HIP_CHECK(hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes) != hipSuccess) { (void)hipFree(a); set_error("olf_debug_copy_bandwidth: hipMalloc failed"); return OLF_ERR_HIP; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipMemsetAsync(a, 1, bytes, c->stream);
+    int rc = olf::launch_copy16(a, b, bytes, c->stream);                    // warm-up
+    (void)hipEventRecord(e0, c->stream);
+    for (int i = 0; i < reps && rc == OLF_OK; ++i) rc = olf::launch_copy16(i & 1 ? b : a, i & 1 ? a : b, bytes, c->stream);
+    (void)hipEventRecord(e1, c->stream);
+    const hipError_t se = hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(a); (void)hipFree(b);
+    if (rc != OLF_OK || se != hipSuccess || !(ms > 0)) { set_error("olf_debug_copy_bandwidth: copy failed"); return OLF_ERR_HIP; }
+    *gbytes_per_s = 2.0 * (double)(bytes / 16 * 16) * reps / (ms * 1e-3) / 1e9;      // bytes read + bytes written
     return OLF_OK;
 }
 
@@ -410,6 +470,7 @@ int olf_stereo_points_dev(olf_ctx* c, int n_pairs, const olf_keypoint* d_kps, co
                           float* d_uright, float* d_depth, void* stream)
 {
     if (!c || !d_kps || !d_desc || !d_counts || !d_uright || !d_depth) { set_error("olf_stereo_points_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_stereo_points_dev"));
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -442,6 +503,7 @@ int olf_match_bf_dev(olf_ctx* c, const uint8_t* dA, const int32_t* nA, int strid
                      int strideB, int b_step, int n_sets, float nnr, int best_lr, int32_t* d_m12, void* stream)
 {
     if (!c || !dA || !dB || !nA || !nB || !d_m12 || strideA < 0 || strideB < 0 || n_sets < 0) { set_error("olf_match_bf_dev: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_match_bf_dev"));
     if (n_sets == 0 || strideA == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     void* ws = nullptr;
@@ -493,6 +555,7 @@ int olf_match_candidates_dev(olf_ctx* c, const uint8_t* dQ, int nQ, const uint8_
                              uint16_t* d_dist, void* stream)
 {
     if (!c || nQ < 0 || nT < 0 || (nQ && (!dQ || !d_offs || !d_dist))) { set_error("olf_match_candidates_dev: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_match_candidates_dev"));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     StageScope t(c, s, ST_MATCH_BF);
     return launch_match_candidates(dQ, nQ, dT, nT, d_offs, d_cand, d_dist, s);
@@ -523,6 +586,7 @@ int olf_match_candidates(olf_ctx* c, const uint8_t* descQ, int nQ, const uint8_t
 int olf_cvt_gray_dev(olf_ctx* c, const uint8_t* d_src, int code, int n_images, uint8_t* d_gray, void* stream)
 {
     if (!c || !d_src || !d_gray || code < 0 || code > 3 || n_images < 0) { set_error("olf_cvt_gray_dev: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_cvt_gray_dev"));
     if (n_images == 0) return OLF_OK;
     return launch_cvt_gray(d_src, d_gray, c->W, c->H, code, n_images, stream ? (hipStream_t)stream : c->stream);
 }
@@ -531,6 +595,7 @@ int olf_remap_linear_dev(olf_ctx* c, const uint8_t* d_src, int sw, int sh, const
                          uint8_t* d_dst, void* stream)
 {
     if (!c || !d_src || !d_mapx || !d_mapy || !d_dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || n_images < 0) { set_error("olf_remap_linear_dev: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_remap_linear_dev"));
     if (n_images == 0) return OLF_OK;
     return launch_remap_linear(d_src, sw, sh, d_mapx, d_mapy, dw, dh, d_dst, n_images, stream ? (hipStream_t)stream : c->stream);
 }
@@ -611,10 +676,12 @@ int olf_line_capacity(const olf_ctx* c) { return c ? c->line.geom.outCap : OLF_E
 int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_keyline* d_kls, uint8_t* d_ldesc, int32_t* d_lcounts, void* stream)
 {
     if (!c || !d_images || !d_kls || !d_ldesc || !d_lcounts) { set_error("olf_line_extract_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_line_extract_dev"));
     if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
     if (n_images == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     { StageScope t(c, s, ST_LSD_FRONT); OLF_TRY(launch_lsd_front(c->line.geom, c->lb, d_images, c->W, n_images, s)); }
+    if (c->mark_front) OLF_HIP_CHECK(hipEventRecord(c->ev_front, s));
     { StageScope t(c, s, ST_LSD_GROW); OLF_TRY(launch_lsd_grow(c->line.geom, c->lb, n_images, s)); }
     { StageScope t(c, s, ST_LSD_RECT); OLF_TRY(launch_lsd_rect(c->line.geom, c->lb, n_images, s)); }
     { StageScope t(c, s, ST_LINE_LBD); OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s)); }
@@ -669,6 +736,7 @@ int olf_stereo_lines_dev(olf_ctx* c, int n_pairs, const olf_keyline* d_kls, cons
                          float* d_disp, double* d_le, void* stream)
 {
     if (!c || !d_kls || !d_ldesc || !d_lcounts || !d_m12 || !d_disp || !d_le) { set_error("olf_stereo_lines_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_stereo_lines_dev"));
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
@@ -701,13 +769,15 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
 {
     if (!c || !d_images || !o || !o->kps || !o->desc || !o->counts || !o->uright || !o->depth || !o->kls || !o->ldesc || !o->lcounts ||
         !o->lmatches12 || !o->ldisp || !o->lle) { set_error("olf_stereo_frames_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_stereo_frames_dev"));
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
-    // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  The two
-    // sides cannot really share a SIMD while all growth agents are resident; the second stream mainly fills the agents'
-    // ragged tail with ORB work.  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
+    // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  The ORB
+    // path starts when the dense front half of LSD is through: two dense pipelines at once only slow each other down, whereas the ORB
+    // kernels running beside the latency-bound growth agents leave those at their stand-alone speed (measured: 265 against 278 ms per
+    // 3072-pair step; OLF_SCHED=0 starts both paths together).  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
     static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
     if (one_stream) {
         OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
@@ -716,11 +786,16 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
         OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
         return OLF_OK;
     }
+    static const int sched = getenv("OLF_SCHED") ? atoi(getenv("OLF_SCHED")) : 1;
     OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2));
+    c->mark_front = (sched & 1) != 0;
+    const int rcl = olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2);
+    c->mark_front = false;
+    OLF_TRY(rcl);
     OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
     OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    if (sched & 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     OLF_TRY(olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s));
     OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));

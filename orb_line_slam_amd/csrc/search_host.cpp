@@ -114,20 +114,25 @@ int rot_bin(float angle1, float angle2)
     return bin;
 }
 
-// cv::Mat products of CV_32F operands (cv::gemm): double accumulation, one rounding (convention of DESIGN.md App. C)
+// cv::Mat products of CV_32F operands (convention C.12): a plain product A*b (+ c) of inner length 3 takes cv::gemm's
+// small-matrix path (flags == 0, 2 <= len <= 4): the three products are summed in float, alpha and the C term are applied in double and the
+// result is rounded once.  Products with a transposed operand (A.t()*b) take the generic path: double accumulation, one rounding.
+inline float dot3_small(const float* a, const float* b)
+{
+    float t = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];        // ((a0*b0 + a1*b1) + a2*b2) in float, no contraction (-ffp-contract=off)
+    return t;
+}
 void rot_apply(const float* T, const float* v, float alpha_t, float* out)     // R * v + alpha_t * t, T = 4x4 row-major
 {
-    for (int r = 0; r < 3; ++r) {
-        double acc = 0;
-        for (int k = 0; k < 3; ++k) acc += (double)T[4 * r + k] * (double)v[k];
-        out[r] = (float)(acc + (double)alpha_t * (double)T[4 * r + 3]);
-    }
+    for (int r = 0; r < 3; ++r) out[r] = (float)((double)dot3_small(T + 4 * r, v) + (double)alpha_t * (double)T[4 * r + 3]);
 }
 
 bool bad_view(const olf_frame_view* f, bool needs_pose)
 {
     return !f || f->n < 0 || (f->n && (!f->keys || !f->desc)) || (needs_pose && !f->Tcw);
 }
+// views whose scale tables are indexed by a predicted pyramid level (MapPoint::PredictScale) or by a key point's octave
+bool bad_levels(const olf_frame_view* f) { return f->n_levels < 1 || f->n_levels > OLF_MAX_LEVELS || !f->scale_factors; }
 }  // namespace
 
 extern "C" {
@@ -362,11 +367,13 @@ void camera_centre(const float* Tcw, float* Ow)                 // -Rcw.t() * tc
     }
 }
 
-void r3_apply(const float* R9, const float* v, const float* t3, float* out, double alpha = 1.0)     // alpha * R * v (+ t), cv::gemm
+// alpha * R * v (+ t), cv::gemm.  transposed: R9 holds the transpose of the matrix the reference multiplies with .t() -> generic path
+void r3_apply(const float* R9, const float* v, const float* t3, float* out, double alpha = 1.0, bool transposed = false)
 {
     for (int r = 0; r < 3; ++r) {
         double acc = 0;
-        for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * (double)v[k];
+        if (transposed) for (int k = 0; k < 3; ++k) acc += (double)R9[3 * r + k] * (double)v[k];
+        else acc = (double)dot3_small(R9 + 3 * r, v);
         out[r] = (float)(alpha * acc + (t3 ? (double)t3[r] : 0.0));
     }
 }
@@ -443,6 +450,7 @@ int olf_search_by_projection_kf(olf_ctx* c, const olf_frame_view* cur, const olf
         (kf->n && (!kf->mp_valid || !kf->mp_bad || !kf->mp_world || !kf->mp_desc || !kf->mp_maxd || !kf->mp_mind))) {
         set_error("olf_search_by_projection_kf: bad argument"); return OLF_ERR_INVALID;
     }
+    if (bad_levels(cur)) { set_error("olf_search_by_projection_kf: n_levels / scale_factors missing"); return OLF_ERR_INVALID; }
     for (int i = 0; i < cur->n; ++i) matches[i] = -1;
     *nmatches = 0;
     float Ow[3];
@@ -654,6 +662,7 @@ int fuse_core(olf_ctx* c, const char* who, const olf_frame_view* kf, const float
               const uint8_t* skip, const float* world, const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th,
               bool stereo_gate, int none_dist, int32_t* best_idx, int32_t* best_dist)
 {
+    if (bad_levels(kf)) { set_error(std::string(who) + ": n_levels / scale_factors missing"); return OLF_ERR_INVALID; }
     const float logSF = log_scale_factor(*kf);
     const Grid grid(*kf);
     Batch q;
@@ -742,7 +751,7 @@ int olf_fuse_search_sim3(olf_ctx* c, const olf_frame_view* kf, const float* Scw,
     const float inv = (float)(1.0 / (double)scw);
     float R[9], Rt[9], t[3], ow[3];
     for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) { R[3 * r + k] = Scw[4 * r + k] * inv; Rt[3 * k + r] = R[3 * r + k]; } t[r] = Scw[4 * r + 3] * inv; }
-    r3_apply(Rt, t, nullptr, ow, -1.0);
+    r3_apply(Rt, t, nullptr, ow, -1.0, true);          // Ow = -Rcw.t() * tcw (src/ORBmatcher.cc:989)
     return fuse_core(c, "olf_fuse_search_sim3", kf, R, t, ow, n_mp, skip, world, normal, maxd, mind, desc, th, false, 2147483647, best_idx,
                      best_dist);
 }
@@ -757,6 +766,7 @@ int olf_search_by_sim3(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_vi
         !kf1->scale_factors || !kf2->scale_factors || incomplete(kf1) || incomplete(kf2)) {
         set_error("olf_search_by_sim3: bad argument"); return OLF_ERR_INVALID;
     }
+    if (bad_levels(kf1) || bad_levels(kf2)) { set_error("olf_search_by_sim3: n_levels / scale_factors missing"); return OLF_ERR_INVALID; }
     const int N1 = kf1->n, N2 = kf2->n;
     // Transformation between cameras (:1123-1125)
     float sR12[9], sR21[9], t21[3];

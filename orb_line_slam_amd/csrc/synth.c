@@ -55,7 +55,39 @@ static void paint_rect(uint8_t* img, int W, int H, int cx, int cy, int a, int b,
         }
 }
 
-static void make_scene(uint8_t* scene, int W, int H, uint64_t seed)
+/* scene 0: the default mix; scene 1 ("long"): fewer, larger shapes and longer strokes, so that the detected segments average about
+ * 0.08 * W pixels, the length SURVEY App. D's byte model assumes for a KITTI frame */
+/* the same shape with anti-aliased borders: pixels near the border take the grey value in proportion to their covered area (4 x 4
+ * sub-samples), like the edges of a real camera image -- an aliased staircase breaks the LSD regions of a long edge into short pieces */
+static void paint_rect_aa(uint8_t* img, int W, int H, int cx, int cy, int a, int b, int hu, int hv, int grey)
+{
+    int n = isqrt_i(a * a + b * b);
+    if (n == 0) { a = 1; b = 0; n = 1; }
+    int ext = hu + hv + 3;
+    int x0 = cx - ext < 0 ? 0 : cx - ext, x1 = cx + ext >= W ? W - 1 : cx + ext;
+    int y0 = cy - ext < 0 ? 0 : cy - ext, y1 = cy + ext >= H ? H - 1 : cy + ext;
+    const int margin = (a < 0 ? -a : a) + (b < 0 ? -b : b);
+    for (int y = y0; y <= y1; ++y)
+        for (int x = x0; x <= x1; ++x) {
+            int dx = x - cx, dy = y - cy;
+            int u = dx * a + dy * b, v = -dx * b + dy * a;
+            int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+            if (au > hu * n + margin || av > hv * n + margin) continue;
+            if (au <= hu * n - margin && av <= hv * n - margin) { img[(size_t)y * W + x] = (uint8_t)grey; continue; }
+            int c = 0;                                  /* coverage in sixteenths: sub-sample centres at (x + (2i-3)/8, y + (2j-3)/8) */
+            for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 4; ++i) {
+                    int sx = 8 * dx + 2 * i - 3, sy = 8 * dy + 2 * j - 3;
+                    int su = sx * a + sy * b, sv = -sx * b + sy * a;
+                    if (su < 0) su = -su;
+                    if (sv < 0) sv = -sv;
+                    if (su <= 8 * hu * n && sv <= 8 * hv * n) ++c;
+                }
+            if (c) img[(size_t)y * W + x] = (uint8_t)(((int)img[(size_t)y * W + x] * (16 - c) + grey * c + 8) / 16);
+        }
+}
+
+static void make_scene(uint8_t* scene, int W, int H, uint64_t seed, int kind)
 {
     rng_t r; r.s = 0x9E3779B97F4A7C15ULL ^ (seed + 1);
     if (r.s == 0) r.s = 1;
@@ -64,6 +96,32 @@ static void make_scene(uint8_t* scene, int W, int H, uint64_t seed)
         for (int x = 0; x < W; ++x)
             scene[(size_t)y * W + x] = (uint8_t)(32 + (x * 96) / W + (y * 64) / H);
     int K = (W * H) / 2500;
+    if (kind == 1) {
+        int Kl = K / 5 > 4 ? K / 5 : 4;
+        for (int k = 0; k < Kl; ++k) {                  /* large rotated rectangles */
+            int cx = rng_range(&r, 0, W - 1), cy = rng_range(&r, 0, H - 1);
+            int a = rng_range(&r, -64, 64), b = rng_range(&r, -64, 64);
+            int hu = rng_range(&r, 40, 220), hv = rng_range(&r, 30, 160);
+            int g = rng_range(&r, 16, 240);
+            paint_rect_aa(scene, W, H, cx, cy, a, b, hu, hv, g);
+        }
+        for (int k = 0; k < 3 * Kl; ++k) {              /* long strokes */
+            int cx = rng_range(&r, 0, W - 1), cy = rng_range(&r, 0, H - 1);
+            int a = rng_range(&r, -64, 64), b = rng_range(&r, -64, 64);
+            int hl = rng_range(&r, 80, W / 2 > 81 ? W / 2 : 81);
+            int hw = rng_range(&r, 0, 2);
+            int g = rng_range(&r, 0, 255);
+            paint_rect_aa(scene, W, H, cx, cy, a, b, hl, hw, g);
+        }
+        for (int k = 0; k < K; ++k) {                   /* tiny blobs: corners for FAST, sides below the minimum line length */
+            int cx = rng_range(&r, 0, W - 1), cy = rng_range(&r, 0, H - 1);
+            int a = rng_range(&r, -64, 64), b = rng_range(&r, -64, 64);
+            int hu = rng_range(&r, 1, 3), hv = rng_range(&r, 1, 3);
+            int g = rng_range(&r, 0, 255);
+            paint_rect(scene, W, H, cx, cy, a, b, hu, hv, g);
+        }
+        return;
+    }
     for (int k = 0; k < K; ++k) {                       /* rotated rectangles */
         int cx = rng_range(&r, 0, W - 1), cy = rng_range(&r, 0, H - 1);
         int a = rng_range(&r, -64, 64), b = rng_range(&r, -64, 64);
@@ -97,13 +155,13 @@ static void add_noise(uint8_t* dst, const uint8_t* src, int n, rng_t* r)
 }
 
 /* left/right: W*H bytes each, row-major, stride W.  Returns 0, or -1 on bad arguments. */
-int olf_synth_stereo(uint64_t seed, int W, int H, uint8_t* left, uint8_t* right)
+int olf_synth_stereo_scene(uint64_t seed, int W, int H, int kind, uint8_t* left, uint8_t* right)
 {
-    if (W < 64 || H < 64 || !left || !right) return -1;
+    if (W < 64 || H < 64 || !left || !right || kind < 0 || kind > 1) return -1;
     uint8_t* scene = (uint8_t*)malloc((size_t)W * H);
     uint8_t* shifted = (uint8_t*)malloc((size_t)W * H);
     if (!scene || !shifted) { free(scene); free(shifted); return -1; }
-    make_scene(scene, W, H, seed);
+    make_scene(scene, W, H, seed, kind);
     for (int y = 0; y < H; ++y) {
         int d = 4 + (60 * y) / H;
         for (int x = 0; x < W; ++x) {
@@ -121,3 +179,5 @@ int olf_synth_stereo(uint64_t seed, int W, int H, uint8_t* left, uint8_t* right)
     free(scene); free(shifted);
     return 0;
 }
+
+int olf_synth_stereo(uint64_t seed, int W, int H, uint8_t* left, uint8_t* right) { return olf_synth_stereo_scene(seed, W, H, 0, left, right); }

@@ -108,3 +108,24 @@ class OfflinePipeline:
                 prev["out_done"].synchronize()
                 self.ctx.poll_status()
                 yield self._frames(prev)
+
+
+def pcie_inclusive_rate(params, width, height, pairs=1024, batches=4):
+    """bench.py leg: stereo frames/s host-to-host through the double-buffered pipeline (pageable input copied into the pinned staging buffer,
+    trimmed nothing: the outputs come back at their fixed capacity)."""
+    import time
+    import torch
+    from . import synth
+    pipe = OfflinePipeline(params, width, height, pairs)
+    base = synth.stereo_batch(7000, min(pairs, 32), width, height)
+    batch = np.tile(base, (pairs // 32 + 1, 1, 1))[:2 * pairs].copy()
+    for _ in pipe.run([batch, batch]):      # warm-up
+        pass
+    torch.cuda.synchronize()
+    t, n = time.time(), 0
+    for f in pipe.run(batch for _ in range(batches)):
+        n += len(f.N)
+    dt = time.time() - t
+    pipe.ctx.close()
+    return {"value": round(n / dt, 1), "unit": "stereo frames/s", "pairs_per_batch": pairs, "batches": batches,
+            "note": "host images in, host results out, upload / path / download overlapped on three streams"}

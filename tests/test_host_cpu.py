@@ -116,34 +116,53 @@ _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
-from orb_line_slam_amd.distributed import shard_range, gather_to_rank0
+from orb_line_slam_amd.distributed import shard_range, gather_records
+from orb_line_slam_amd.records import pack_records, merge_records, parse_records
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=world)
-n_frames = 7
+# full-capacity output arrays of 7 stereo frames, as the fused entry writes them: rows from the committed fixture of the feature path
+# (tests/golden/frame_320x240_seed11.npz), a different number of rows in use per frame
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "frame_320x240_seed11.npz"))
+n_frames, cap, lcap = 7, 520, 100
+def frames(lo, hi):
+    n = hi - lo
+    a = {"kps": np.zeros((2 * n, cap, 28), np.uint8), "desc": np.zeros((2 * n, cap, 32), np.uint8), "uright": np.full((n, cap), -1, np.float32),
+         "depth": np.full((n, cap), -1, np.float32), "kls": np.zeros((2 * n, lcap, 68), np.uint8), "ldesc": np.zeros((2 * n, lcap, 32), np.uint8),
+         "lmatches12": np.full((n, lcap), -1, np.int32), "ldisp": np.full((n, lcap, 2), -1, np.float32), "lle": np.zeros((n, lcap, 3), np.float64)}
+    counts, lcounts = np.zeros(2 * n, np.int32), np.zeros(2 * n, np.int32)
+    for q, f in enumerate(range(lo, hi)):
+        nl_, nr_ = 504 - 31 * f, 300 + 7 * f
+        ll_, lr_ = 100 - 9 * f, 40 + 3 * f
+        counts[2 * q], counts[2 * q + 1], lcounts[2 * q], lcounts[2 * q + 1] = nl_, nr_, ll_, lr_
+        kb, klb = g["kpsL"].view(np.uint8).reshape(-1, 28), g["klsL"].view(np.uint8).reshape(-1, 68)
+        a["kps"][2 * q, :nl_] = kb[:nl_]; a["kps"][2 * q + 1, :nr_] = np.roll(kb, f, 0)[:nr_]
+        a["desc"][2 * q, :nl_] = g["descL"][:nl_]; a["desc"][2 * q + 1, :nr_] = np.roll(g["descL"], f, 0)[:nr_]
+        a["uright"][q, :nl_] = g["uRight"][:nl_]; a["depth"][q, :nl_] = g["depth"][:nl_]
+        a["kls"][2 * q, :ll_] = klb[:ll_]; a["kls"][2 * q + 1, :lr_] = np.roll(klb, f, 0)[:lr_]
+        a["ldesc"][2 * q, :ll_] = g["ldescL"][:ll_]; a["ldesc"][2 * q + 1, :lr_] = np.roll(g["ldescL"], f, 0)[:lr_]
+        a["lmatches12"][q, :ll_] = g["lm12"][:ll_]; a["ldisp"][q, :ll_] = g["ldisp"][:ll_]; a["lle"][q, :ll_] = g["lle"][:ll_]
+    return a, counts, lcounts
 lo, hi = shard_range(n_frames, rank, world)
-# every "frame" f carries records that are a pure function of f, like per-frame features of a fixed input
-def rec(f):
-    g = np.random.default_rng(f)
-    return g.integers(0, 255, (5, 32), dtype=np.uint8), np.int32(f * 3 + 1), g.normal(size=(4,)).astype(np.float32)
-loc = [rec(f) for f in range(lo, hi)]
-local = {"desc": torch.from_numpy(np.stack([a for a, _, _ in loc]) if loc else np.zeros((0, 5, 32), np.uint8)),
-         "count": torch.from_numpy(np.array([b for _, b, _ in loc], np.int32)),
-         "depth": torch.from_numpy(np.stack([c for _, _, c in loc]) if loc else np.zeros((0, 4), np.float32))}
-out = gather_to_rank0(local, dist, n_frames)
+rec = pack_records(*frames(lo, hi))
+packed = torch.from_numpy(np.frombuffer(rec + b"\\0" * 100, np.uint8).copy())          # the device buffer is larger than the record
+recs, sizes = gather_records(packed, len(rec), dist)
+assert sizes[rank] == len(rec)
 if rank == 0:
-    ref = [rec(f) for f in range(n_frames)]
-    assert np.array_equal(out["desc"].numpy(), np.stack([a for a, _, _ in ref]))
-    assert np.array_equal(out["count"].numpy(), np.array([b for _, b, _ in ref], np.int32))
-    assert np.array_equal(out["depth"].numpy(), np.stack([c for _, _, c in ref]))
-    print("GATHER_OK")
+    whole = pack_records(*frames(0, n_frames))                                          # what a 1-rank run of the same frames packs
+    got = merge_records([r.numpy().tobytes() for r in recs])
+    assert got == whole, "gathered records differ from the single-rank record"
+    p = parse_records(got)
+    assert p["n_pairs"] == n_frames and p["counts"][0] == 504 and len(p["kps"]) == p["counts"].sum() and p["bytes"] == len(whole)
+    print("GATHER_OK", len(whole), sizes)
 else:
-    assert out is None
+    assert recs is None
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
 def test_frame_sharded_gather_world2_gloo(tmp_path):
-    """N>1 path on CPU: 2 processes, gloo, 7 frames sharded 4+3; rank 0 must hold the same bytes as a 1-rank run."""
+    """N>1 path on CPU: 2 processes, gloo, 7 frames sharded 4+3, each rank packs the trimmed record of its frames (fixture rows) and
+    sends it to rank 0; the merged records must be byte-identical to the record of a 1-rank run (SURVEY 8(e) "Verification")."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     import socket

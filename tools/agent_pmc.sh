@@ -15,5 +15,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   i=$((i+1))
   rocprofv3 --kernel-trace --output-format csv --pmc $grp -d $O/g$i -o run -- python $R/tools/prof_lines.py $N > $O/g$i.log 2>&1 || echo "group $i failed: $grp"
 done
-python $R/tools/pmc_sum.py $O k_lsd_grow > $O/summary.txt 2>&1
+python $R/tools/pmc_sum.py $O k_lsd_grow > $O/summary.txt 2>&1; rm -rf $O/g[0-9]
 cat $O/summary.txt

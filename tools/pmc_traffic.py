@@ -1,6 +1,8 @@
 """FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes, KiB) -> per-kernel HBM traffic summary.
 python tools/pmc_traffic.py <fetch_dir> <write_dir> <images_per_launch> <out_prefix>"""
-import csv, glob, json, sys, collections
+import csv, glob, json, sys, collections, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bench import source_hash
 fd, wd, n_img, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 
 
@@ -24,6 +26,6 @@ for k in sorted(F, key=lambda k: -(F[k][0] + W.get(k, (0, 0))[0])):
     f, w = F[k][0], W.get(k, (0.0, 0))[0]
     kern[k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "bytes_per_image": (f + w) * 1024 / n_img}
     lines.append(f"{k}, {F[k][1]}, {f:.0f}, {w:.0f}, {(f + w) * 1024 / n_img:.0f}")
-json.dump({"images_per_launch": n_img, "kernels": kern}, open(out + ".json", "w"), indent=1)
+json.dump({"images_per_launch": n_img, "source_hash": source_hash(), "kernels": kern}, open(out + ".json", "w"), indent=1)
 open(out + ".txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:12]))
