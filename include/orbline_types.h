@@ -54,6 +54,10 @@ typedef struct olf_orb_params {
     int32_t nlevels;
     int32_t ini_th_fast;
     int32_t min_th_fast;
+    /* convention C.11: fixed-point Gaussian taps of the 7x7 sigma-2 blur.  0: every tap rounded on its own, [18,34,49,55,49,34,18],
+     * sum 257 (OpenCV 3.4.0-3.4.5, the range the reference most plausibly linked); 1: error-diffused taps that sum to 256 exactly
+     * (later releases' "bit-exact" kernel), [18,34,48,56,48,34,18] */
+    int32_t conv_gauss_sum256;
 } olf_orb_params;
 
 /* Lineextractor 11-argument ctor (include/LineExtractor.h:44-45) -- the LSD options
@@ -69,6 +73,17 @@ typedef struct olf_line_params {
     double  lsd_log_eps;
     double  lsd_density_th;
     int32_t lsd_n_bins;
+    /* conventions where the un-vendored OpenCV decides the result and its version is not pinned by the reference:
+     * C.11 conv_gauss_sum256: as in olf_orb_params, for LSD's sigma-0.6 blur and LBD's 5x5 sigma-1 blur.
+     * C.10 conv_resize_exact: LSD's x1.2 upsampling, 0: cv::resize INTER_LINEAR (11-bit coefficients); 1: INTER_LINEAR_EXACT (8-bit
+     *      coefficients, round-to-nearest at the end), which later 3.4.x releases of lsd.cpp call.
+     * C.9  conv_seed_order: order of the seeds INSIDE a gradient bin, 0: raster (the linked-list pseudo-ordering of the original LSD and of
+     *      OpenCV <= 3.2); 1: whatever std::sort(begin, end, norm descending) of libstdc++ leaves (OpenCV >= 3.3 sorts a vector of all pixels by
+     *      bin with the unstable std::sort).  Only the CPU oracle implements 1: the order is a property of the introsort implementation run on
+     *      the whole pixel sequence, which has no data-parallel equivalent -- olf_ctx_create refuses it with OLF_ERR_INVALID. */
+    int32_t conv_gauss_sum256;
+    int32_t conv_resize_exact;
+    int32_t conv_seed_order;
 } olf_line_params;
 
 /* Camera / matching scalars read on the path:

@@ -65,10 +65,10 @@ void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>
         const double sigma = (SCALE < 1) ? (SIGMA_SCALE / SCALE) : SIGMA_SCALE;
         const double sprec = 3;
         const unsigned int hk = (unsigned int)std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0)));
-        Image g = gaussian_blur_u8(image, gaussian_taps_q8(1 + 2 * hk, sigma));
+        Image g = gaussian_blur_u8(image, gaussian_taps_q8(1 + 2 * hk, sigma, P.conv_gauss_sum256));
         // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE): dsize = round(size*SCALE), scale = 1/SCALE
         const int dw = cvRound(image.w * SCALE), dh = cvRound(image.h * SCALE);
-        scaled = resize_linear_u8(g, dw, dh, 1. / SCALE, 1. / SCALE);
+        scaled = P.conv_resize_exact ? resize_linear_exact_u8(g, dw, dh, 1. / SCALE, 1. / SCALE) : resize_linear_u8(g, dw, dh, 1. / SCALE, 1. / SCALE);
     } else scaled = image;
     if (scaled_out) *scaled_out = scaled;
     LsdState S;
@@ -108,11 +108,24 @@ void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>
         int acc = 0;
         for (int b = N_BINS - 1; b >= 0; --b) { start[b] = acc; acc += cnt[b]; }
         S.order.assign(acc, 0);
-        for (int y = 0; y < H - 1; ++y)
-            for (int x = 0; x < W - 1; ++x) {
-                int b = bin[(size_t)y * W + x];
-                S.order[start[b]++] = y * W + x;
-            }
+        if (P.conv_seed_order == 1) {
+            // convention C.9, variant 1: OpenCV >= 3.3 pushes every pixel (x < w-1, y < h-1) as {point, bin} in raster order and calls
+            // std::sort(ordered_points.begin(), ordered_points.end(), compare_norm) with compare_norm(a, b) = a.norm > b.norm -- an unstable
+            // sort: the order inside a bin is libstdc++'s introsort order.  Same library, same sequence, same comparator here.
+            struct NormPoint { int addr, norm; };
+            std::vector<NormPoint> pts;
+            pts.reserve(acc);
+            for (int y = 0; y < H - 1; ++y)
+                for (int x = 0; x < W - 1; ++x) pts.push_back({y * W + x, bin[(size_t)y * W + x]});
+            std::sort(pts.begin(), pts.end(), [](const NormPoint& a, const NormPoint& b) { return a.norm > b.norm; });
+            for (size_t i = 0; i < pts.size(); ++i) S.order[i] = pts[i].addr;
+        } else {
+            for (int y = 0; y < H - 1; ++y)
+                for (int x = 0; x < W - 1; ++x) {
+                    int b = bin[(size_t)y * W + x];
+                    S.order[start[b]++] = y * W + x;
+                }
+        }
     }
     const double LOG_NT = 5 * (std::log10(double(W)) + std::log10(double(H))) / 2 + std::log10(11.0);
     const int min_reg_size = int(-LOG_NT / std::log10(p));
@@ -245,7 +258,7 @@ static void sobel3(const Image& src, std::vector<int16_t>& dxI, std::vector<int1
 }
 
 void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, std::vector<uint8_t>& desc,
-                 std::vector<float>* float_desc)
+                 std::vector<float>* float_desc, int conv_gauss_sum256 = 0)
 {
     const int n = (int)keylines.size();
     desc.assign((size_t)n * 32, 0);
@@ -263,7 +276,7 @@ void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, s
         invsigma2 = -1 / (2 * sigma * sigma);
         for (int i = 0; i < NUM_OF_BANDS * WIDTH_OF_BAND; ++i) { double dis = i - u; gaussCoefG[i] = std::exp(dis * dis * invsigma2); }
     }
-    Image blurred = gaussian_blur_u8(image, gaussian_taps_q8(5, 1.0));
+    Image blurred = gaussian_blur_u8(image, gaussian_taps_q8(5, 1.0, conv_gauss_sum256));
     std::vector<int16_t> dxImg, dyImg;
     sobel3(blurred, dxImg, dyImg);
     const short heightOfLSP = (short)(WIDTH_OF_BAND * NUM_OF_BANDS);
@@ -395,7 +408,7 @@ void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort,
         kls.resize(P.lsd_nfeatures);
         for (int i = 0; i < P.lsd_nfeatures; ++i) kls[i].class_id = i;
     }
-    lbd_compute(img, kls, desc, nullptr);
+    lbd_compute(img, kls, desc, nullptr, P.conv_gauss_sum256);
 }
 
 }  // namespace orc

@@ -8,8 +8,28 @@ namespace orc {
 // cv::getGaussianKernel(n, sigma>0, CV_32F): taps exp(-x^2/(2 sigma^2)) stored as float,
 // normalised by the double sum of the float taps; createSeparableLinearFilter then converts
 // them with convertTo(CV_32S, 256) (cvRound).  SURVEY App. A.3.
-std::vector<int> gaussian_taps_q8(int n, double sigma)
+// sum256 (convention C.11): the later "bit-exact" kernel instead -- taps computed in double, converted to 8 fractional bits with the
+// rounding error carried from tap to tap (outside in), the centre tap taking what is left of 256 (getGaussianKernelFixedPoint_ED).
+std::vector<int> gaussian_taps_q8(int n, double sigma, int sum256)
 {
+    if (sum256) {
+        std::vector<double> k(n);
+        double s = 0;
+        const double scale2X = -0.5 / (sigma * sigma);
+        for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = std::exp(scale2X * x * x); s += k[i]; }
+        std::vector<int> q(n);
+        double err = 0;
+        int sum = 0;
+        for (int i = 0; i < n / 2; ++i) {
+            const double adj = k[i] / s * 256.0 + err;
+            const int v = cvRound(adj);
+            err = adj - v;
+            q[i] = q[n - 1 - i] = v;
+            sum += v;
+        }
+        q[n / 2] = 256 - 2 * sum;
+        return q;
+    }
     std::vector<float> cf(n);
     double scale2X = -0.5 / (sigma * sigma), sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -46,6 +66,40 @@ Image gaussian_blur_u8(const Image& src, const std::vector<int>& taps)
             for (int k = 0; k < n; ++k) acc += taps[k] * tmp[(size_t)reflect101(y + k - r, h) * w + x];
             dst.at(x, y) = sat_u8((acc + 32768) >> 16);
         }
+    return dst;
+}
+
+// cv::resize INTER_LINEAR_EXACT, 8UC1 (resize.cpp resize_bitExact<uchar, ufixedpoint16>, recalled -- convention C.10): source position
+// scale * (d + 0.5) - 0.5 in (soft) double, offset = floor, the fractional part converted to 8 fractional bits (round to nearest), clamped at
+// both image edges; horizontal pass in 8.8 fixed point (exact), vertical pass 8.8 x 0.8 -> 8.16, one rounding (+ 2^15 >> 16).
+Image resize_linear_exact_u8(const Image& src, int dw, int dh, double scale_x, double scale_y)
+{
+    const int sw = src.w, sh = src.h;
+    auto coefs = [](int dn, int sn, double scale, std::vector<int>& ofs, std::vector<int>& c1) {
+        ofs.resize(dn); c1.resize(dn);
+        for (int d = 0; d < dn; ++d) {
+            const double f = scale * (d + 0.5) - 0.5;
+            int i = cvFloor(f);
+            int a = cvRound((f - i) * 256.0);
+            if (i < 0) { i = 0; a = 0; }
+            if (i >= sn - 1) { i = sn - 1; a = 0; }
+            ofs[d] = i; c1[d] = a;
+        }
+    };
+    std::vector<int> xo, xa, yo, ya;
+    coefs(dw, sw, scale_x, xo, xa);
+    coefs(dh, sh, scale_y, yo, ya);
+    Image dst(dw, dh);
+    for (int dy = 0; dy < dh; ++dy) {
+        const uint8_t* s0 = src.row(yo[dy]);
+        const uint8_t* s1 = src.row(std::min(yo[dy] + 1, sh - 1));
+        const int b1 = ya[dy], b0 = 256 - b1;
+        for (int dx = 0; dx < dw; ++dx) {
+            const int x0 = xo[dx], x1 = std::min(x0 + 1, sw - 1), a1 = xa[dx], a0 = 256 - a1;
+            const int h0 = s0[x0] * a0 + s0[x1] * a1, h1 = s1[x0] * a0 + s1[x1] * a1;      // 8.8
+            dst.at(dx, dy) = sat_u8((h0 * b0 + h1 * b1 + 32768) >> 16);
+        }
+    }
     return dst;
 }
 

@@ -52,7 +52,9 @@ static inline int reflect101(int p, int n)
 
 // cv::getGaussianKernel(n, sigma, CV_32F) followed by the 8-bit fixed-point conversion
 // (App. A.3): integer taps round(256*k).
-std::vector<int> gaussian_taps_q8(int n, double sigma);
+std::vector<int> gaussian_taps_q8(int n, double sigma, int sum256 = 0);
+// cv::resize(..., INTER_LINEAR_EXACT) for 8UC1 (convention C.10): 8-bit coefficients, exact 8.8 x 0.8 fixed point, one rounding at the end
+Image resize_linear_exact_u8(const Image& src, int dw, int dh, double scale_x, double scale_y);
 // cv::GaussianBlur on 8-bit single channel, BORDER_REFLECT_101, fixed point (App. A.3).
 Image gaussian_blur_u8(const Image& src, const std::vector<int>& taps);
 // cv::resize(..., INTER_LINEAR) for 8UC1 (App. A.2). scale_x/scale_y are the *source step

@@ -372,7 +372,7 @@ void orb_extract(const Image& img, const olf_orb_params& p, OrbResult& R)
     compute_keypoints_octree(T, R);
     R.kps.clear(); R.desc.clear();
     R.blurred.assign(T.nlevels, Image());
-    static const std::vector<int> taps = gaussian_taps_q8(7, 2.0);
+    const std::vector<int> taps = gaussian_taps_q8(7, 2.0, p.conv_gauss_sum256);
     for (int level = 0; level < T.nlevels; ++level) {
         std::vector<KP>& kps = R.level_kps[level];
         if (kps.empty()) continue;
@@ -489,5 +489,13 @@ int orc_gaussian_blur(const uint8_t* src, int w, int h, uint8_t* dst, int ksize,
 }
 
 float orc_fast_atan2(float y, float x) { return fastAtan2(y, x); }
+
+// the 8-bit fixed-point Gaussian taps under either convention C.11 variant
+int orc_gaussian_taps(int ksize, double sigma, int sum256, int* taps_out)
+{
+    std::vector<int> t = gaussian_taps_q8(ksize, sigma, sum256);
+    for (int i = 0; i < ksize; ++i) taps_out[i] = t[i];
+    return 0;
+}
 
 }  // extern "C"

@@ -28,14 +28,14 @@ assert KEYPOINT_DTYPE.itemsize == 28 and KEYLINE_DTYPE.itemsize == 68
 
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
-                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("conv_gauss_sum256", C.c_int32)]
 
 
 class LineParams(C.Structure):
     _fields_ = [("lsd_nfeatures", C.c_int32), ("min_line_length", C.c_double), ("lsd_refine", C.c_int32),
                 ("lsd_scale", C.c_double), ("lsd_sigma_scale", C.c_double), ("lsd_quant", C.c_double),
                 ("lsd_ang_th", C.c_double), ("lsd_log_eps", C.c_double), ("lsd_density_th", C.c_double),
-                ("lsd_n_bins", C.c_int32)]
+                ("lsd_n_bins", C.c_int32), ("conv_gauss_sum256", C.c_int32), ("conv_resize_exact", C.c_int32), ("conv_seed_order", C.c_int32)]
 
 
 class StereoParams(C.Structure):

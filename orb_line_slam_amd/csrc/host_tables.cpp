@@ -19,8 +19,27 @@ static inline int cv_round_d(double v) { return (int)lrint(v); }
 static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
 static inline int cv_ceil(double v) { int i = (int)v; return i + (i < v); }
 
-std::vector<int> gaussian_taps_q8(int n, double sigma)
+// sum256: convention C.11, the error-diffused "bit-exact" taps of later OpenCV releases (see include/orbline_types.h)
+std::vector<int> gaussian_taps_q8(int n, double sigma, int sum256)
 {
+    if (sum256) {
+        std::vector<double> k(n);
+        double s = 0;
+        const double scale2X = -0.5 / (sigma * sigma);
+        for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; k[i] = std::exp(scale2X * x * x); s += k[i]; }
+        std::vector<int> q(n);
+        double err = 0;
+        int sum = 0;
+        for (int i = 0; i < n / 2; ++i) {
+            const double adj = k[i] / s * 256.0 + err;
+            const int v = cv_round_d(adj);
+            err = adj - v;
+            q[i] = q[n - 1 - i] = v;
+            sum += v;
+        }
+        q[n / 2] = 256 - 2 * sum;
+        return q;
+    }
     std::vector<float> cf(n);
     double scale2X = -0.5 / (sigma * sigma), sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -52,6 +71,19 @@ void resize_axis_coefs(int sn, int dn, double scale, bool clamp_like_x, ResizeCo
         coef[d].a0 = (int16_t)std::min(std::max(a0, -32768), 32767);
         coef[d].a1 = (int16_t)std::min(std::max(a1, -32768), 32767);
         coef[d].pad = 0;
+    }
+}
+
+// cv::resize INTER_LINEAR_EXACT (convention C.10): 8-bit coefficients, both taps clamped into the image on either axis
+void resize_axis_coefs_exact(int sn, int dn, double scale, ResizeCoef* coef)
+{
+    for (int d = 0; d < dn; ++d) {
+        const double f = scale * (d + 0.5) - 0.5;
+        int i = cv_floor(f);
+        int a = cv_round_d((f - i) * 256.0);
+        if (i < 0) { i = 0; a = 0; }
+        if (i >= sn - 1) { i = sn - 1; a = 0; }
+        coef[d].ofs = (int16_t)i; coef[d].a0 = (int16_t)(256 - a); coef[d].a1 = (int16_t)a; coef[d].pad = 0;
     }
 }
 
@@ -96,7 +128,7 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
             ++v0;
         }
     }
-    std::vector<int> taps = gaussian_taps_q8(7, 2.0);
+    std::vector<int> taps = gaussian_taps_q8(7, 2.0, p.conv_gauss_sum256);
     for (int i = 0; i < 7; ++i) g.blurTaps[i] = taps[i];
 
     rx.clear(); ry.clear();
@@ -172,6 +204,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     LineGeom& g = geom;
     g = LineGeom();
     if (p.lsd_refine != 0) return OLF_ERR_INVALID;            // only LSD_REFINE_NONE is on the path
+    if (p.conv_seed_order != 0) return OLF_ERR_INVALID;       // the std::sort seed order (convention C.9, variant 1) exists in the CPU oracle only
     if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
     g.W = W; g.H = H; g.pitchW = (W + 63) & ~63;
@@ -207,11 +240,11 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
         const double sigma = (p.lsd_scale < 1) ? (p.lsd_sigma_scale / p.lsd_scale) : p.lsd_sigma_scale;
         const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
         if (hk > 3) return OLF_ERR_INVALID;   // kernels wider than 7 taps are not implemented
-        std::vector<int> t = gaussian_taps_q8(1 + 2 * hk, sigma);
+        std::vector<int> t = gaussian_taps_q8(1 + 2 * hk, sigma, p.conv_gauss_sum256);
         for (unsigned i = 0; i < t.size(); ++i) g.lsdTaps[3 - hk + i] = t[i];
     } else g.lsdTaps[3] = 256;               // identity: cv::LineSegmentDetector skips blur+resize at scale 1
     {
-        std::vector<int> t = gaussian_taps_q8(5, 1.0);
+        std::vector<int> t = gaussian_taps_q8(5, 1.0, p.conv_gauss_sum256);
         for (int i = 0; i < 5; ++i) g.lbdTaps[1 + i] = t[i];
     }
     {   // integer divisions are the reference's (binary_descriptor_custom.cpp:224-257)
@@ -228,9 +261,16 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     rx.resize(g.Ws); ry.resize(g.Hs);
     g.resizeTabX = 0; g.resizeTabY = 0;
     // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE, INTER_LINEAR): scale_x = 1/SCALE
-    resize_axis_coefs(W, g.Ws, 1. / p.lsd_scale, true, rx.data());
-    resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
-    g.resizeTiled = resize_tiled_fits(rx.data(), ry.data(), W, H, g.Ws, g.Hs) ? 1 : 0;
+    g.resizeExact = p.conv_resize_exact ? 1 : 0;
+    if (g.resizeExact) {
+        resize_axis_coefs_exact(W, g.Ws, 1. / p.lsd_scale, rx.data());
+        resize_axis_coefs_exact(H, g.Hs, 1. / p.lsd_scale, ry.data());
+        g.resizeTiled = 0;                                 // the tiled kernel implements INTER_LINEAR's arithmetic only
+    } else {
+        resize_axis_coefs(W, g.Ws, 1. / p.lsd_scale, true, rx.data());
+        resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
+        g.resizeTiled = resize_tiled_fits(rx.data(), ry.data(), W, H, g.Ws, g.Hs) ? 1 : 0;
+    }
     return OLF_OK;
 }
 

@@ -39,6 +39,7 @@ struct LineGeom {
     float gaussCoefG[63];
     int resizeTabX, resizeTabY;
     int resizeTiled;
+    int resizeExact;           // convention C.10: the upsampling is cv::resize INTER_LINEAR_EXACT (8-bit coefficients in rx / ry)
 };
 
 struct LineDeviceBufs {

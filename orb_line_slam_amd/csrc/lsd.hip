@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_lsd_upsample(const uint8_t* __restrict_
             const int sx = cx.ofs, sx1 = min(sx + 1, g.W - 1);
             const int h0 = S0[sx] * cx.a0 + S0[sx1] * cx.a1;
             const int h1 = S1[sx] * cx.a0 + S1[sx1] * cx.a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            // INTER_LINEAR: 11-bit coefficients, OpenCV's two-step shift; INTER_LINEAR_EXACT (C.10): 8.8 x 0.8 fixed point, one rounding
+            const int v = g.resizeExact ? (h0 * b0 + h1 * b1 + 32768) >> 16 : (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 0xff) << (8 * k);
         }
     }

@@ -85,7 +85,7 @@ struct OrbHostTables {
     int build(const olf_orb_params& p, int W, int H);
 };
 
-std::vector<int> gaussian_taps_q8(int n, double sigma);
+std::vector<int> gaussian_taps_q8(int n, double sigma, int sum256 = 0);
 // fills coef[0..dn) for a 1-D cv::resize(INTER_LINEAR) axis: sn source samples, step `scale`
 void resize_axis_coefs(int sn, int dn, double scale, bool clamp_like_x, ResizeCoef* coef);
 

@@ -51,7 +51,7 @@ def test_lbd_on_given_keylines(oracle):
 
 # BASELINE.json configs: C2 640x480 (1000 + 200), C3 KITTI 1242x375 (2000 + 500), C4 EuRoC 752x480, C5 1920x1080 (4000 + 1000)
 @pytest.mark.parametrize("w,h,nf,nl,fx,bf,npairs", [(640, 480, 1000, 200, 435.2047, 47.9064, 3), (1242, 375, 2000, 500, 718.856, 386.1448, 3),
-                                                    (752, 480, 1200, 300, 435.2047, 47.9064, 2), (1920, 1080, 4000, 1000, 1050.0, 126.0, 1)])
+                                                    (752, 480, 1200, 500, 435.2047, 47.9064, 2), (1920, 1080, 4000, 1000, 1050.0, 126.0, 1)])       # C4: Examples/PL/PL_EuRoC.yaml:92,158 (1200 ORB, 500 lines)
 def test_stereo_frames(oracle, w, h, nf, nl, fx, bf, npairs):
     p = oracle.full_params(nf, nl, fx, bf)
     fe = ola.StereoFrontEnd(p, w, h, max_pairs=npairs)
@@ -265,3 +265,47 @@ def test_offline_pipeline_equals_frames(oracle):
                 assert np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes(), (i, j, k)
         got += 1
     assert got == len(batches)
+
+
+def test_stereo_frame_against_committed_fixture():
+    """The HIP path against tests/golden/frame_320x240_seed11.npz directly (no oracle library in the loop): the committed outputs of the
+    whole feature path for one seeded stereo pair."""
+    import os, zlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frame_320x240_seed11.npz"))
+    left, right = synth.stereo_pair(11, 320, 240)
+    assert zlib.crc32(left.tobytes()) == int(g["crc_left"]) and zlib.crc32(right.tobytes()) == int(g["crc_right"])
+    from orb_line_slam_amd import _lib
+    p = _lib.default_params()
+    p.orb.nfeatures, p.line.lsd_nfeatures, p.stereo.fx, p.stereo.bf = 500, 100, 300.0, 40.0
+    fe = ola.StereoFrontEnd(p, 320, 240, max_pairs=1)
+    f = fe.frames(np.stack([left, right])).pair(0)
+    assert np.array_equal(f["mvKeys"], g["kpsL"]) and np.array_equal(f["mDescriptors"], g["descL"])
+    assert np.array_equal(f["mvuRight"].view(np.uint32), g["uRight"].view(np.uint32)) and np.array_equal(f["mvDepth"].view(np.uint32), g["depth"].view(np.uint32))
+    assert np.array_equal(f["mvKeys_Line"], g["klsL"]) and np.array_equal(f["mDescriptors_Line"], g["ldescL"])
+    assert np.array_equal(f["line_matches_12"], g["lm12"]) and np.array_equal(f["mvDisparity_l"].view(np.uint32), g["ldisp"].view(np.uint32))
+    assert np.array_equal(f["mvle_l"].view(np.uint64), g["lle"].view(np.uint64))
+
+
+@pytest.mark.parametrize("gauss256,exact", [(1, 0), (0, 1), (1, 1)])
+def test_opencv_version_conventions(oracle, gauss256, exact):
+    """Conventions C.10 / C.11 (which OpenCV 3.4.x patch level the reference linked decides them): the library follows the oracle under every
+    combination; the std::sort seed order (C.9 variant 1) exists in the oracle only and is refused."""
+    from orb_line_slam_amd import _lib
+    w, h = 640, 480
+    p = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    p.orb.conv_gauss_sum256 = p.line.conv_gauss_sum256 = gauss256
+    p.line.conv_resize_exact = exact
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=1)
+    imgs = synth.stereo_batch(77, 1, w, h)
+    g = fe.frames(imgs).pair(0)
+    o = oracle.stereo_points(imgs[0], imgs[1], p)
+    assert np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"])
+    assert np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
+    ol = oracle.line_extract(imgs[0], p.line)
+    _cmp_keylines(g["mvKeys_Line"], ol["kls"])
+    assert np.array_equal(g["mDescriptors_Line"], ol["desc"])
+    base = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    assert not np.array_equal(ol["desc"], oracle.line_extract(imgs[0], base.line)["desc"]) or not np.array_equal(o["descL"], oracle.stereo_points(imgs[0], imgs[1], base)["descL"])
+    p.line.conv_seed_order = 1
+    with pytest.raises(_lib.OlfError):
+        ola.StereoFrontEnd(p, w, h, max_pairs=1)

@@ -5,6 +5,7 @@ import os
 import zlib
 import numpy as np
 import pytest
+from orb_line_slam_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -212,3 +213,75 @@ def test_bow_oracle_vs_reference_containers(oracle, tmp_path):
             assert p2[n] == 0 and l2[n] == 0 and w2[n] == 0 and not d2[n].any()       # the reference's extra root child (convention C.8)
         assert T.transform(feats, 1)[1] == fv or final_newline     # without the phantom the result is the array-built one
     assert oracle.OracleVoc.load_text(tmp_path / "missing.txt") is None
+
+
+def test_gaussian_tap_conventions(oracle):
+    """Convention C.11: taps rounded one by one (OpenCV 3.4.0-3.4.5; the sigma-2 and sigma-1 kernels then sum to 257) or error-diffused to 256."""
+    import ctypes as C
+    t = (C.c_int * 7)()
+    want = {(7, 2.0, 0): [18, 34, 49, 55, 49, 34, 18], (7, 2.0, 1): [18, 34, 48, 56, 48, 34, 18], (5, 1.0, 0): [14, 63, 103, 63, 14],
+            (5, 1.0, 1): [14, 62, 104, 62, 14], (7, 0.6, 0): [0, 1, 42, 170, 42, 1, 0], (7, 0.6, 1): [0, 1, 42, 170, 42, 1, 0]}
+    for (k, sg, m), w in want.items():
+        oracle._L.orc_gaussian_taps(k, C.c_double(sg), m, t)
+        assert list(t)[:k] == w
+        assert m == 0 or sum(w) == 256
+
+
+def test_lsd_seed_order_convention_exposure(oracle):
+    """Convention C.9: OpenCV <= 3.2 visits the seeds of a gradient bin in raster order, OpenCV >= 3.3 in whatever order libstdc++'s unstable
+    std::sort leaves.  The oracle implements both (the library only the first); this pins how much of the result hangs on the choice:
+    on the synthetic images more than 9 of 10 segments are bit-identical under either order, and the two are not trivially equal."""
+    same = tot = 0
+    for seed in (3, 4):
+        left, _ = synth.stereo_pair(seed, 640, 480)
+        p = oracle.full_params(2000, 0)
+        a = oracle.line_extract(left, p.line)["kls"]
+        p.line.conv_seed_order = 1
+        b = oracle.line_extract(left, p.line)["kls"]
+        key = lambda k: set(map(bytes, np.stack([k[f] for f in ("startPointX", "startPointY", "endPointX", "endPointY")], 1)))
+        sa, sb = key(a), key(b)
+        same += len(sa & sb); tot += max(len(sa), len(sb))
+    assert 0.9 * tot < same < tot, (same, tot)
+
+
+def test_lsd_resize_convention_changes_only_the_working_image(oracle):
+    """Convention C.10: INTER_LINEAR_EXACT differs from INTER_LINEAR by at most one grey level per pixel of LSD's working image."""
+    left, _ = synth.stereo_pair(5, 320, 240)
+    p = oracle.full_params(1000, 0)
+    _, a = oracle.lsd_detect(left, p.line)
+    p.line.conv_resize_exact = 1
+    _, b = oracle.lsd_detect(left, p.line)
+    d = np.abs(a.astype(int) - b.astype(int))
+    assert a.shape == b.shape and d.max() <= 1 and 0 < (d > 0).mean() < 0.5
+
+
+def test_oracle_against_opencv_golden(oracle):
+    """The oracle against outputs of a real OpenCV 3.4 (tests/golden/opencv34_*.npz, made by tools/make_opencv_golden.py on a machine that has
+    it).  Skipped while the fixtures are absent: the image this repository is built in has no OpenCV, so parity stays UNPINNED until then."""
+    import glob
+    gdir = os.path.join(ROOT, "tests", "golden")
+    files = sorted(glob.glob(os.path.join(gdir, "opencv34_*.npz")))
+    if not files:
+        pytest.skip("no OpenCV fixtures committed (tools/make_opencv_golden.py needs a machine with OpenCV 3.4)")
+    left, _ = synth.stereo_pair(11, 320, 240)
+    big, _ = synth.stereo_pair(12, 640, 480)
+    for f in files:
+        g = np.load(f)
+        name = os.path.basename(f)
+        if name == "opencv34_resize.npz":
+            assert np.array_equal(oracle.resize_linear(left, g["down"].shape[1], g["down"].shape[0]), g["down"]), "INTER_LINEAR, A.2"
+            assert np.array_equal(oracle.resize_linear(left, g["up"].shape[1], g["up"].shape[0], 1 / 1.2, 1 / 1.2), g["up"]), "x1.2 INTER_LINEAR"
+        elif name == "opencv34_blur.npz":
+            for key, (k, sg) in {"s2": (7, 2.0), "s1": (5, 1.0), "s06": (7, 0.6)}.items():
+                assert np.array_equal(oracle.gaussian_blur(left, k, sg)[0], g[key]), "GaussianBlur sigma %g: convention C.11" % sg
+        elif name == "opencv34_atan2.npz":
+            got = np.array([[oracle.fast_atan2(float(a), float(b)) for a, b in zip(ry, rx)] for ry, rx in zip(g["y"], g["x"])], np.float32)
+            assert np.array_equal(got.view(np.uint32), g["deg"].view(np.uint32)), "fastAtan2, A.5"
+        elif name == "opencv34_sobel.npz":
+            dx, dy = oracle.sobel3(left)
+            assert np.array_equal(dx, g["dx"]) and np.array_equal(dy, g["dy"]), "Sobel, A.9"
+        elif name == "opencv34_lsd.npz":
+            p = oracle.full_params(1000, 0)
+            for key, img in (("small", left), ("big", big)):
+                segs, _ = oracle.lsd_detect(img, p.line)
+                assert np.array_equal(segs.view(np.uint32), g[key].view(np.uint32)), "LSD %s: conventions C.9 / C.10 / C.11" % key
