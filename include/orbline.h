@@ -112,6 +112,8 @@ int olf_orb_level_sizes(const olf_ctx* ctx, int32_t* widths, int32_t* heights);
 int olf_orb_capacity(const olf_ctx* ctx);
 /* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors), src/ORBextractor.cc:1045-1107,
  * for n_images images of width x height, row stride = width. */
+/* one image whose rows are row_stride bytes apart (a cv::Mat ROI: data, step) -- no host-side repacking */
+int olf_orb_extract_strided(olf_ctx* ctx, const uint8_t* image, size_t row_stride, olf_keypoint* kps, uint8_t* desc, int32_t* count);
 int olf_orb_extract_dev(olf_ctx* ctx, const uint8_t* d_images, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
                         int32_t* d_counts, void* stream);
 int olf_orb_extract(olf_ctx* ctx, const uint8_t* images, int n_images, olf_keypoint* kps, uint8_t* desc, int32_t* counts);
@@ -254,6 +256,7 @@ int olf_hamming_matrix(olf_ctx* ctx, const uint8_t* descA, int nA, const uint8_t
 int olf_line_capacity(const olf_ctx* ctx);
 /* Lineextractor::operator()(image, mask [ignored], keylines, descriptors_line): LSDDetectorC::detect with
  * the context's LSD options, top-N by response, BinaryDescriptor::compute (LBD). */
+int olf_line_extract_strided(olf_ctx* ctx, const uint8_t* image, size_t row_stride, olf_keyline* kls, uint8_t* ldesc, int32_t* lcount);
 int olf_line_extract_dev(olf_ctx* ctx, const uint8_t* d_images, int n_images, olf_keyline* d_kls, uint8_t* d_ldesc, int32_t* d_lcounts,
                          void* stream);
 int olf_line_extract(olf_ctx* ctx, const uint8_t* images, int n_images, olf_keyline* kls, uint8_t* ldesc, int32_t* lcounts);
@@ -291,6 +294,10 @@ typedef struct olf_frame_buffers {
  * device pointers for the _dev form, host pointers otherwise. */
 int olf_stereo_frames_dev(olf_ctx* ctx, const uint8_t* d_images, int n_pairs, const olf_frame_buffers* out, void* stream);
 int olf_stereo_frames(olf_ctx* ctx, const uint8_t* images, int n_pairs, const olf_frame_buffers* out);
+
+/* getLineCoords(x1, y1, x2, y2, line_coords), src/gridStructure.cpp:33-41: cells of the reference's Bresenham walk (src/LineIterator.cpp), host
+ * arithmetic.  xy receives up to cap (x, y) pairs, *n the number of cells. */
+int olf_line_coords(double x1, double y1, double x2, double y2, int32_t* xy, int cap, int32_t* n);
 
 /* ---- multi-GPU: the trimmed wire record of a batch ------------------------------------------------------------------
  * What a rank sends to rank 0 after a batch: header, counts, then only the rows in use of every array of olf_frame_buffers (layout in

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstring>
 #include <stdexcept>
+#include <type_traits>
 #include <map>
 #include <string>
 #include <utility>
@@ -39,8 +40,10 @@ struct Ctx {
     int w = 0, hgt = 0;
     Ctx() { olf_default_params(&p); }
     ~Ctx() { if (h) olf_ctx_destroy(h); }
-    olf_ctx* get(int width, int height)
+    olf_ctx* get(int width, int height, const olf_params* with = nullptr)
     {
+        // `with`: the full parameter block of a fused call (this object's own part plus the line / stereo parameters of its siblings)
+        if (with && std::memcmp(with, &p, sizeof(p)) != 0) { p = *with; if (h) olf_ctx_destroy(h); h = nullptr; }
         if (!h || w != width || hgt != height) {
             if (h) olf_ctx_destroy(h);
             h = nullptr;
@@ -66,13 +69,18 @@ public:
     // POD form: image w x h, row stride = w.  Mask is ignored, as in the reference.
     void operator()(const uint8_t* image, int w, int h, std::vector<olf_keypoint>& keypoints, std::vector<uint8_t>& descriptors)
     {
+        extract(image, w, h, (size_t)w, keypoints, descriptors);
+    }
+    // rows `stride` bytes apart (cv::Mat::step)
+    void extract(const uint8_t* image, int w, int h, size_t stride, std::vector<olf_keypoint>& keypoints, std::vector<uint8_t>& descriptors)
+    {
         keypoints.clear(); descriptors.clear();
         if (!image || w <= 0 || h <= 0) return;   // src/ORBextractor.cc:1048-1049
         olf_ctx* x = c.get(w, h);
         const int cap = olf_orb_capacity(x);
         keypoints.resize(cap); descriptors.resize((size_t)cap * OLF_DESC_BYTES);
         int32_t n = 0;
-        olf_detail::check(olf_orb_extract(x, image, 1, keypoints.data(), descriptors.data(), &n), "olf_orb_extract");
+        olf_detail::check(olf_orb_extract_strided(x, image, stride, keypoints.data(), descriptors.data(), &n), "olf_orb_extract");
         keypoints.resize(n); descriptors.resize((size_t)n * OLF_DESC_BYTES);
         olf_orb_scale_tables(x, scale_.data(), inv_.data(), s2_.data(), is2_.data(), nullptr);
     }
@@ -82,9 +90,8 @@ public:
         if (_image.empty()) return;
         cv::Mat image = _image.getMat();
         CV_Assert(image.type() == CV_8UC1);
-        cv::Mat cont = image.isContinuous() ? image : image.clone();
         std::vector<olf_keypoint> k; std::vector<uint8_t> d;
-        (*this)(cont.data, cont.cols, cont.rows, k, d);
+        extract(image.data, image.cols, image.rows, image.step, k, d);       // a ROI keeps its stride: no host-side clone
         keypoints.resize(k.size());
         if (!k.empty()) std::memcpy(keypoints.data(), k.data(), k.size() * sizeof(olf_keypoint));
         if (k.empty()) _descriptors.release();
@@ -116,7 +123,8 @@ public:
         if (h) *h = lh[level];
         return out;
     }
-    olf_ctx* context(int w, int h) { return c.get(w, h); }
+    olf_ctx* context(int w, int h, const olf_params* with = nullptr) { return c.get(w, h, with); }
+    const olf_params& params() const { return c.p; }
 
 private:
     void ensure()
@@ -145,28 +153,32 @@ public:
     }
     void operator()(const uint8_t* image, int w, int h, std::vector<olf_keyline>& keylines, std::vector<uint8_t>& descriptors)
     {
+        extract(image, w, h, (size_t)w, keylines, descriptors);
+    }
+    void extract(const uint8_t* image, int w, int h, size_t stride, std::vector<olf_keyline>& keylines, std::vector<uint8_t>& descriptors)
+    {
         keylines.clear(); descriptors.clear();
         if (bFLD || !image) return;                // src/LineExtractor.cc:68
         olf_ctx* x = c.get(w, h);
         const int cap = olf_line_capacity(x);
         keylines.resize(cap); descriptors.resize((size_t)cap * OLF_DESC_BYTES);
         int32_t n = 0;
-        olf_detail::check(olf_line_extract(x, image, 1, keylines.data(), descriptors.data(), &n), "olf_line_extract");
+        olf_detail::check(olf_line_extract_strided(x, image, stride, keylines.data(), descriptors.data(), &n), "olf_line_extract");
         keylines.resize(n); descriptors.resize((size_t)n * OLF_DESC_BYTES);
     }
 #ifdef ORBLINE_WITH_OPENCV
     void operator()(const cv::Mat& image, const cv::Mat& /*mask*/, std::vector<cv::line_descriptor::KeyLine>& keylines, cv::Mat& descriptors_line)
     {
         if (image.depth() != 0) throw std::runtime_error("Error, depth image!= 0");   // LSDDetector_custom.cpp:236-237
-        cv::Mat cont = image.isContinuous() ? image : image.clone();
         std::vector<olf_keyline> k; std::vector<uint8_t> d;
-        (*this)(cont.data, cont.cols, cont.rows, k, d);
+        extract(image.data, image.cols, image.rows, image.step, k, d);
         keylines.resize(k.size());
         if (!k.empty()) std::memcpy((void*)keylines.data(), k.data(), k.size() * sizeof(olf_keyline));
         descriptors_line = cv::Mat((int)k.size(), 32, CV_8UC1);
         if (!k.empty()) std::memcpy(descriptors_line.data, d.data(), d.size());
     }
 #endif
+    const olf_params& params() const { return c.p; }
 private:
     olf_detail::Ctx c;
     bool bFLD;
@@ -191,6 +203,13 @@ public:
     static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:39-41
     ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return distance(a, b); }
+
+    // ---- the reference's own signatures (include/ORBmatcher.h:44-66), templates over the reference's Frame / KeyFrame / MapPoint / cv::Mat;
+    // defined in orbline_reference_api.hpp (included at the end of this header): the call sites of Tracking.cc compile unchanged
+    template <class MatT, class = typename std::enable_if<std::is_class<MatT>::value>::type> static int DescriptorDistance(const MatT& a, const MatT& b);
+    template <class FrameT> int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono);
+    template <class FrameT, class MapPointT> int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3);
+    template <class KeyFrameT, class FrameT, class MapPointT> int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches);
 
     // The members of the reference's MapPoints read by SearchByProjection(Frame&, const vector<MapPoint*>&, th), gathered into arrays
     struct TrackedMapPoints {
@@ -350,3 +369,5 @@ private:
 typedef ORBVocabulary LineVocabulary;
 
 }  // namespace ORB_SLAM2
+
+#include "orbline_reference_api.hpp"

@@ -4,6 +4,8 @@
 #include "olf_internal.hpp"
 #include "line_internal.hpp"
 #include "../../include/orbline.h"
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <mutex>
 
@@ -45,6 +47,7 @@ struct olf_ctx {
     float* d_ldisp = nullptr;
     double* d_lle = nullptr;
     hipStream_t stream2 = nullptr;
+    bool has_tables = false;       // holds a reference on the device's shared LSD angle tables
     bool mark_front = false;
     hipEvent_t ev_front = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -81,6 +84,50 @@ static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
     *out = c->scratch[slot];
     return OLF_OK;
 }
+
+// The LSD angle / cos-sin tables depend on nothing but the packed gradient pair: one copy per device, shared by every context of the process
+// (a reference Frame is served by four extractor objects, each with a context of its own; include/orbline_adaptor.hpp).
+namespace {
+struct AngleTables { float* angDeg = nullptr; double2* cosSin = nullptr; float2* seedCS = nullptr; int refs = 0; };
+std::mutex g_tab_mu;
+std::map<int, AngleTables> g_tabs;
+
+int angle_tables_acquire(int device, LineDeviceBufs& l, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    AngleTables& t = g_tabs[device];
+    if (t.refs == 0) {
+        if (hipMalloc(&t.angDeg, sizeof(float) << 22) != hipSuccess || hipMalloc(&t.cosSin, sizeof(double2) << 22) != hipSuccess ||
+            hipMalloc(&t.seedCS, sizeof(float2) << 22) != hipSuccess) {
+            (void)hipFree(t.angDeg); (void)hipFree(t.cosSin); (void)hipFree(t.seedCS);
+            t = AngleTables();
+            set_error("hipMalloc failed (LSD angle tables)");
+            return OLF_ERR_HIP;
+        }
+        l.angDeg = t.angDeg; l.cosSin = t.cosSin; l.seedCS = t.seedCS;
+        if (launch_lsd_angle_table(l, s) != OLF_OK || hipStreamSynchronize(s) != hipSuccess) {
+            (void)hipFree(t.angDeg); (void)hipFree(t.cosSin); (void)hipFree(t.seedCS);
+            t = AngleTables();
+            set_error("LSD angle table build failed");
+            return OLF_ERR_HIP;
+        }
+    }
+    ++t.refs;
+    l.angDeg = t.angDeg; l.cosSin = t.cosSin; l.seedCS = t.seedCS;
+    return OLF_OK;
+}
+
+void angle_tables_release(int device)
+{
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto it = g_tabs.find(device);
+    if (it == g_tabs.end() || it->second.refs <= 0) return;
+    if (--it->second.refs == 0) {
+        (void)hipFree(it->second.angDeg); (void)hipFree(it->second.cosSin); (void)hipFree(it->second.seedCS);
+        g_tabs.erase(it);
+    }
+}
+}  // namespace
 
 namespace olf {
 int launch_pack_records(const olf_frame_buffers& fb, int n_pairs, int cap, int lcap, uint8_t* d_dst, size_t dst_capacity, int* d_rowOfs,
@@ -156,6 +203,7 @@ int olf_default_params(olf_params* p)
 void olf_ctx_destroy(olf_ctx* c)
 {
     if (!c) return;
+    if (c->has_tables) angle_tables_release(c->device);
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -221,7 +269,6 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     l.nChunks = 512 + lg.Ps / 32 + 64;
     A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
-    A(l.angDeg, (size_t)1 << 22); A(l.cosSin, (size_t)1 << 22); A(l.seedCS, (size_t)1 << 22);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
     {
@@ -242,7 +289,8 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (hipMemcpy(l.rx, c->line.rx.data(), c->line.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.ry, c->line.ry.data(), c->line.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.geom, &lg, sizeof(LineGeom), hipMemcpyHostToDevice) != hipSuccess) { set_error("line table upload failed"); return fail(OLF_ERR_HIP); }
-    if ((rc = launch_lsd_angle_table(l, c->stream)) != OLF_OK || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("LSD angle table build failed"); return fail(OLF_ERR_HIP); }
+    if ((rc = angle_tables_acquire(c->device, l, c->stream)) != OLF_OK) return fail(rc);
+    c->has_tables = true;
     *out = c;
     return OLF_OK;
 }
@@ -366,6 +414,19 @@ int olf_orb_extract(olf_ctx* c, const uint8_t* images, int n_images, olf_keypoin
     OLF_HIP_CHECK(hipMemcpyAsync(kps, c->d_kps, cap * n_images * sizeof(olf_keypoint), hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipMemcpyAsync(desc, c->d_desc, cap * n_images * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipMemcpyAsync(counts, c->d_counts, n_images * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int olf_orb_extract_strided(olf_ctx* c, const uint8_t* image, size_t row_stride, olf_keypoint* kps, uint8_t* desc, int32_t* count)
+{
+    if (!c || !image || !kps || !desc || !count || row_stride < (size_t)c->W) { set_error("olf_orb_extract_strided: bad argument"); return OLF_ERR_INVALID; }
+    const size_t cap = c->orb.geom.outCap;
+    OLF_HIP_CHECK(hipMemcpy2DAsync(c->d_images, c->W, image, row_stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_orb_extract_dev(c, c->d_images, 1, c->d_kps, c->d_desc, c->d_counts, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(count, c->d_counts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(kps, c->d_kps, cap * sizeof(olf_keypoint), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(desc, c->d_desc, cap * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return check_status(c);
 }
@@ -699,6 +760,19 @@ int olf_line_extract(olf_ctx* c, const uint8_t* images, int n_images, olf_keylin
     OLF_HIP_CHECK(hipMemcpyAsync(kls, c->d_kls, cap * n_images * sizeof(olf_keyline), hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipMemcpyAsync(ldesc, c->d_ldesc, cap * n_images * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipMemcpyAsync(lcounts, c->d_lcounts, n_images * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int olf_line_extract_strided(olf_ctx* c, const uint8_t* image, size_t row_stride, olf_keyline* kls, uint8_t* ldesc, int32_t* lcount)
+{
+    if (!c || !image || !kls || !ldesc || !lcount || row_stride < (size_t)c->W) { set_error("olf_line_extract_strided: bad argument"); return OLF_ERR_INVALID; }
+    const size_t cap = c->line.geom.outCap;
+    OLF_HIP_CHECK(hipMemcpy2DAsync(c->d_images, c->W, image, row_stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(olf_line_extract_dev(c, c->d_images, 1, c->d_kls, c->d_ldesc, c->d_lcounts, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(kls, c->d_kls, cap * sizeof(olf_keyline), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(ldesc, c->d_ldesc, cap * OLF_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(lcount, c->d_lcounts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return check_status(c);
 }

@@ -833,4 +833,29 @@ int olf_search_by_sim3(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_vi
     return OLF_OK;
 }
 
+// getLineCoords (src/gridStructure.cpp:33-41): the cells visited by the reference's double-precision Bresenham walk (src/LineIterator.cpp:34-77),
+// host arithmetic -- the same walk csrc/linematch.hip makes on the device for the stereo line matcher.  xy: (x, y) pairs; *n receives the
+// number of cells (which may exceed cap; only cap pairs are written).
+int olf_line_coords(double x1, double y1, double x2, double y2, int32_t* xy, int cap, int32_t* n)
+{
+    if (!xy || !n || cap < 0) { set_error("olf_line_coords: bad argument"); return OLF_ERR_INVALID; }
+    const bool steep = std::fabs(y2 - y1) > std::fabs(x2 - x1);
+    if (steep) { std::swap(x1, y1); std::swap(x2, y2); }
+    if (x1 > x2) { std::swap(x1, x2); std::swap(y1, y2); }
+    const double dx = x2 - x1, dy = std::fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int y = (int)y1, count = 0;
+    const int maxX = (int)x2;
+    for (int x = (int)x1; x <= maxX; ++x) {
+        if (count < cap) { xy[2 * count] = steep ? y : x; xy[2 * count + 1] = steep ? x : y; }
+        ++count;
+        error -= dy;
+        if (error < 0) { y += ystep; error += dx; }
+        if (x == 2147483647) break;
+    }
+    *n = count;
+    return OLF_OK;
+}
+
 }  // extern "C"

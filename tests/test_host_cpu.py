@@ -186,6 +186,22 @@ def test_cpp_adaptor_compiles_and_links(tmp_path):
     assert out.returncode == 0 and b"ADAPTOR_OK" in out.stdout, out.stdout
 
 
+def _build_reference_api(tmp_path):
+    exe = str(tmp_path / "reference_api_check")
+    libdir = os.path.join(ROOT, "orb_line_slam_amd", "csrc")
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "adaptor_reference_api.cpp"), "-L" + libdir,
+                    "-lorbline_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_reference_signatures_instantiate(tmp_path):
+    """include/orbline_reference_api.hpp: every template with the reference's own signature (ORBmatcher::SearchByProjection x2, SearchByBoW,
+    DescriptorDistance, match x2, matchNNR, distance, matchGrid x2, GridStructure, getLineCoords, StereoFrameFeatures) instantiates with
+    stand-ins that carry the reference's member names, links, and -- without a device -- throws instead of falling back."""
+    out = subprocess.run([_build_reference_api(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert out.returncode == 0 and b"REFERENCE_API_COMPILED" in out.stdout, out.stdout
+
+
 def test_keyframe_record_bytes(oracle):
     """Map::SaveKeyFrame's byte layout (SURVEY 8(f) rank 4): the host packer equals the oracle's field-by-field writes; unpack inverts it"""
     import ctypes as C

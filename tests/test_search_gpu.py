@@ -268,3 +268,13 @@ def test_search_by_sim3(oracle, th, s12):
     n_g, v1_g, v2_g = ola.ORBmatcher(0.75, True).SearchBySim3(kf1, kf2, mg, s12, R12, t12, th)
     assert n_g == n_o and np.array_equal(v1_g, v1_o) and np.array_equal(v2_g, v2_o) and np.array_equal(mg, m_o)
     assert (v1_g >= 0).sum() > 50 and (v2_g >= 0).sum() > 50
+
+
+def test_reference_signature_calls(tmp_path):
+    """The reference's own call signatures (include/orbline_reference_api.hpp) on a device: Frame / KeyFrame / MapPoint stand-ins through
+    SearchByProjection x2, SearchByBoW, match x3 and StereoFrameFeatures; every projected point must come back on its own key point."""
+    import os, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_cpu import _build_reference_api
+    out = subprocess.run([_build_reference_api(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and b"REFERENCE_API_OK" in out.stdout, out.stdout
