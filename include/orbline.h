@@ -126,6 +126,10 @@ int olf_orb_pyramid_level(olf_ctx* ctx, int image, int level, int blurred, uint8
 int olf_orb_debug_candidates(olf_ctx* ctx, int image, int level, int32_t* xys, int cap, int32_t* count);
 /* debug: the context's 64-int device status block (overflow flags in [0]; instrumented builds put cycle counters at [16..31]). */
 int olf_debug_status(olf_ctx* ctx, int32_t* out64);
+int olf_debug_status_n(olf_ctx* ctx, int32_t* out, int n);
+/* debug: the regions the last LSD growth logged for `image`, in detection order: (list start, pixel count) pairs and final region angles */
+int olf_debug_lsd_owner(olf_ctx* ctx, int image, uint32_t* out);      /* debug: owner words of the last growth, Ws*Hs */
+int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* angle, int cap, int32_t* count);     /* the first n (<= 256) words */
 /* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
  * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);

@@ -244,14 +244,14 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(b.cells, n * g.totalCells * g.cellCap); A(b.cellCount, n * g.totalCells);
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
-    A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 64);
+    A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 256);
     A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap); A(c->d_bestkey, ((n + 1) / 2) * g.outCap); A(c->d_rowperm, n * g.outCap);
     A(c->d_images, n * width * height); A(c->d_kps, n * g.outCap); A(c->d_desc, n * g.outCap * OLF_DESC_BYTES); A(c->d_counts, n);
 #undef A
     if (hipMemcpy(b.rx, c->orb.rx.data(), c->orb.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.ry, c->orb.ry.data(), c->orb.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(b.geom, &g, sizeof(OrbGeom), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(b.status, 0, 256) != hipSuccess) {
+        hipMemset(b.status, 0, 1024) != hipSuccess) {
         set_error("olf_ctx_create: table upload failed");
         return fail(OLF_ERR_HIP);
     }
@@ -266,8 +266,9 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n);
-    l.nChunks = 512 + lg.Ps / 32 + 64;
-    A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    l.nChunks = 1024 + lg.Ps / 32 + 64;
+    A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks); A(l.deg, n * lg.Ps);
+    { void* q = nullptr; if (hipMalloc(&q, n * (size_t)1024 * 32) != hipSuccess) { set_error("hipMalloc failed"); return fail(OLF_ERR_HIP); } c->allocs.push_back(q); l.rob = q; }
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
@@ -492,9 +493,45 @@ int olf_debug_copy_bandwidth(olf_ctx* c, size_t bytes, int reps, double* gbytes_
 int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
 {
     const bool pow2 = rob_entries > 0 && (rob_entries & (rob_entries - 1)) == 0;
-    if (!c || waves_per_image > 16 || (rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512))) { set_error("olf_debug_lsd_waves: bad argument"); return OLF_ERR_INVALID; }
+    if (!c || waves_per_image > 16 || waves_per_image < -2 || (waves_per_image != -2 && rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512)) ||
+        (waves_per_image == -2 && (rob_entries < 0 || rob_entries > 64))) {       // (lane growth: rob_entries = lanes that grow regions, 0 = all 64)
+        set_error("olf_debug_lsd_waves: bad argument"); return OLF_ERR_INVALID;
+    }
     c->lb.forceNW = waves_per_image;
     c->lb.forceE = rob_entries;
+    return OLF_OK;
+}
+
+// debug: the regions logged by the last growth for `image`, in detection order: (first chunk or list start, pixels, final region angle) triples
+int olf_debug_lsd_regions(olf_ctx* c, int image, int32_t* start_n /* [cap][2] */, double* angle, int cap, int32_t* count)
+{
+    if (!c || !start_n || !angle || !count || image < 0 || image >= c->max_images) return OLF_ERR_INVALID;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    int nr = 0;
+    OLF_HIP_CHECK(hipMemcpy(&nr, c->lb.regCount + image, sizeof(int), hipMemcpyDeviceToHost));
+    *count = nr;
+    struct Rec { int start, n; double angle; };
+    std::vector<Rec> r((size_t)std::min(nr, cap));
+    if (!r.empty())
+        OLF_HIP_CHECK(hipMemcpy(r.data(), reinterpret_cast<const Rec*>(c->lb.keysA) + (size_t)image * c->line.geom.maxRegions, r.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < r.size(); ++i) { start_n[2 * i] = r[i].start; start_n[2 * i + 1] = r[i].n; angle[i] = r[i].angle; }
+    return OLF_OK;
+}
+
+// debug: the owner words (seed rank << 10 | ROB slot, 0xffffffff = never claimed) the last multi-region growth left for `image` (Ws*Hs words)
+int olf_debug_lsd_owner(olf_ctx* c, int image, uint32_t* out)
+{
+    if (!c || !out || image < 0 || image >= c->max_images) return OLF_ERR_INVALID;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    OLF_HIP_CHECK(hipMemcpy(out, c->lb.owner + (size_t)image * c->line.geom.Ps, (size_t)c->line.geom.Ps * 4, hipMemcpyDeviceToHost));
+    return OLF_OK;
+}
+
+int olf_debug_status_n(olf_ctx* c, int32_t* out, int n)
+{
+    if (!c || !out || n < 1 || n > 256) return OLF_ERR_INVALID;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    OLF_HIP_CHECK(hipMemcpy(out, c->ob.status, (size_t)n * 4, hipMemcpyDeviceToHost));
     return OLF_OK;
 }
 

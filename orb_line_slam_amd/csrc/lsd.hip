@@ -816,8 +816,8 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     }
     hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
     hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
-                       b.region, b.angDeg, b.owner);
-    hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.region);
+                       b.deg, b.angDeg, b.owner);
+    hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.deg);
     const int per_chunk = lsd_sort_chunk_images(g.Ps);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, per_chunk, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
@@ -831,13 +831,15 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 }
 
 int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s);
+int launch_lsd_grow_lanes(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 
 // waves per image of the multi-wave growth: as many as keep the chip full (8 waves per SIMD x 1024 SIMDs) without leaving a small batch
 // to a handful of waves; 0 selects the one-wave agent of round 1 (kept for A/B measurements, OLF_LSD_NW=0)
 int lsd_grow_waves(int n_images)
 {
     static int forced = -2;
-    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? atoi(e) : -1; }
+    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? atoi(e) : -1; if (forced == -2) forced = -3; }
+    if (forced == -3) return -2;
     if (forced >= 0) return forced;
     if (n_images <= 512) return 16;
     if (n_images <= 2048) return 8;
@@ -847,8 +849,9 @@ int lsd_grow_waves(int n_images)
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    const int nw = b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images);
-    b.chained = nw > 0;
+    const int nw = b.forceNW >= 0 || b.forceNW == -2 ? b.forceNW : lsd_grow_waves(n_images);
+    b.chained = nw != 0;
+    if (nw == -2) return launch_lsd_grow_lanes(g, b, n_images, s);       // one wave per image, one lane per region (lsd_grow_lanes.hip)
     if (nw > 0) {
         static int envE = -1;
         if (envE < 0) { const char* e = getenv("OLF_LSD_ROB"); envE = e ? atoi(e) : 0; }

@@ -1,0 +1,21 @@
+import sys, ctypes as C, numpy as np, os
+sys.path.insert(0, '/root/repo')
+import orb_line_slam_amd as ola
+from orb_line_slam_amd import synth, _lib
+imgs = synth.stereo_batch(71, 1, 640, 480)
+ex = ola.Lineextractor(0, 0.025, max_images=2)
+ctx = ex._context(640, 480, 2)
+_lib.check(_lib.lib().olf_debug_lsd_waves(ctx.handle, -2, 0), "w")
+try:
+    k, d, c = ex.extract_batch(imgs[:1])
+    print("counts", c)
+except Exception as e:
+    print("exc", e)
+z = np.zeros(256, np.int32)
+_lib.lib().olf_debug_status_n(ctx.handle, z.ctypes.data_as(C.c_void_p), 256)
+names = ["head","tail","readyCur","dispNext","wm","nreg","nkeys","step","fatal","headState","headInval","headRank","reScan","headN"]
+print(dict(zip(names, z[16:30].tolist())))
+print("dbg commits, reassign, fresh, dispatches, finished, fails:", z[40:48].tolist())
+print("slots", z[64:128].tolist())
+print("k|i", [(int(v)&255, int(v)>>8) for v in z[128:192]])
+print("n", z[192:256].tolist())

@@ -292,8 +292,11 @@ int main(int argc, char** argv)
     printf("size histogram (log2 bucket: count):"); for (auto& kv : hist) printf(" %d:%d", kv.first, kv.second); printf("\n");
     long long pxw = 0; for (auto& r : seq) if (r.px.size() > 1) pxw += r.px.size();
     const int capArg = argc > 4 ? atoi(argv[4]) : 256;
-    for (int K : {7}) {
-        for (int nw : {1, 4, 16}) {
+    const int Karg = argc > 5 ? atoi(argv[5]) : 7;
+    const int nwArg = argc > 6 ? atoi(argv[6]) : 0;
+    for (int K : {Karg}) {
+        for (int nw : {1, 4, 16, 64}) {
+            if (nwArg && nw != nwArg) continue;
             for (int cap : {capArg}) {
                 Sim S(F, nw, K, cap, true);
                 S.run();
