@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3")
     ap.add_argument("--pairs", type=int, default=0, help="stereo pairs per GPU per step (0: the configuration's default)")
     ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic pairs per rank (tiled to --pairs)")
+    ap.add_argument("--order", choices=("shuffled", "tiled"), default="shuffled", help="how the batch is drawn from the distinct pairs")
     ap.add_argument("--scene", choices=("default", "long"), default="default", help="long: fewer, larger shapes -> key lines of about 0.08*W pixels (SURVEY App. D's model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
@@ -197,8 +198,11 @@ def main():
 
     def make_input(r):
         host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=args.scene)
-        reps = (B + nd - 1) // nd
-        return torch.from_numpy(np.tile(host, (reps, 1, 1))[:2 * B].copy()).to(dev)
+        # B pairs drawn from the nd distinct ones in a seeded random order (a plain tiling would put identical images at a fixed period,
+        # which lines them up with the hardware's round-robin placement of workgroups -- an artefact no real sequence has)
+        order = np.random.default_rng(1234 + r).permutation(np.arange(B) % nd) if args.order == "shuffled" else np.arange(B) % nd
+        idx = np.stack([2 * order, 2 * order + 1], 1).reshape(-1)
+        return torch.from_numpy(host[idx].copy()).to(dev)
     imgs = make_input(rank)
 
     def z(shape, dt):
@@ -335,7 +339,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} stereo, {cfg['nf']} ORB + {cfg['nl']} LBD per image, extract + stereo point/line match + "
                                    f"f2f LBD match + f2f dense ORB kNN match", "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
-                       "distinct_pairs": nd, "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
+                       "distinct_pairs": nd, "order": args.order, "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
                        "mean_line_pixels": round(mean_len, 1), "source_hash": sh},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
