@@ -65,6 +65,13 @@ int olf_cvt_gray_dev(olf_ctx* ctx, const uint8_t* d_src, int code, int n_images,
  * (shared by all images, e.g. one call per camera); dst: n_images images dst_w x dst_h.  Device pointers. */
 int olf_remap_linear_dev(olf_ctx* ctx, const uint8_t* d_src, int src_w, int src_h, const float* d_mapx, const float* d_mapy, int dst_w,
                          int dst_h, int n_images, uint8_t* d_dst, void* stream);
+/* cv::initUndistortRectifyMap(K, D, R, P(3x3), Size(w, h), CV_32F, M1, M2), Examples/PL/PL_stereo_euroc.cc:97-98: the two CV_32FC1 maps
+ * olf_remap_linear takes.  K, R, P: 3 x 3 row-major doubles (P = the left 3 x 3 block of the projection matrix); D: n_dist <= 8 distortion
+ * coefficients in OpenCV's order k1 k2 p1 p2 k3 k4 k5 k6.  Double arithmetic in the order of OpenCV 3.4's generic code (convention C.13). */
+int olf_init_undistort_rectify_map_dev(olf_ctx* ctx, const double* K, const double* D, int n_dist, const double* R, const double* P, int w, int h,
+                                       float* d_map1, float* d_map2, void* stream);
+int olf_init_undistort_rectify_map(olf_ctx* ctx, const double* K, const double* D, int n_dist, const double* R, const double* P, int w, int h,
+                                   float* map1, float* map2);
 /* host-buffer forms (copy, run, copy back, block) */
 int olf_cvt_gray(olf_ctx* ctx, const uint8_t* src, int code, int n_images, uint8_t* gray);
 int olf_remap_linear(olf_ctx* ctx, const uint8_t* src, int src_w, int src_h, const float* mapx, const float* mapy, int dst_w, int dst_h,

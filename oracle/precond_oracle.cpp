@@ -41,4 +41,43 @@ int orc_remap_linear(const uint8_t* src, int sw, int sh, const float* mapx, cons
     return 0;
 }
 
+// cv::initUndistortRectifyMap(K, D, R, P(3x3), size, CV_32FC1, map1, map2) -- Examples/PL/PL_stereo_euroc.cc:97-98 -- as OpenCV 3.4's
+// generic C++ path computes it (imgproc/undistort.cpp; recalled, not verified: convention C.13): everything in double;
+// iR = (P * R)^-1 with cv::invert's closed-form 3 x 3 adjugate (n <= 3 never reaches the LU code); per row the homogeneous source coordinates
+// start at (i*ir[1] + ir[2], i*ir[4] + ir[5], i*ir[7] + ir[8]) and ADVANCE by (ir[0], ir[3], ir[6]) per column -- a running sum, not a
+// product; radial (k1 k2 k3 / k4 k5 k6) and tangential (p1 p2) distortion, no thin-prism / tilt terms; one rounding to float at the end.
+// D: k1 k2 p1 p2 k3 k4 k5 k6 (nd of them, the rest zero).
+int orc_init_undistort_rectify_map(const double* K, const double* D, int nd, const double* R, const double* P, int w, int h, float* map1, float* map2)
+{
+    double Ar_R[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Ar_R[3 * r + c] = P[3 * r] * R[c] + P[3 * r + 1] * R[3 + c] + P[3 * r + 2] * R[6 + c];
+    const double* m = Ar_R;
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0.) return -1;
+    d = 1. / d;
+    double ir[9];
+    ir[0] = (m[4] * m[8] - m[5] * m[7]) * d; ir[1] = (m[2] * m[7] - m[1] * m[8]) * d; ir[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+    ir[3] = (m[5] * m[6] - m[3] * m[8]) * d; ir[4] = (m[0] * m[8] - m[2] * m[6]) * d; ir[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+    ir[6] = (m[3] * m[7] - m[4] * m[6]) * d; ir[7] = (m[1] * m[6] - m[0] * m[7]) * d; ir[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nd && i < 8; ++i) k[i] = D[i];
+    const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    for (int i = 0; i < h; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2));
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy);
+            map1[(size_t)i * w + j] = (float)(fx * xd + u0);
+            map2[(size_t)i * w + j] = (float)(fy * yd + v0);
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

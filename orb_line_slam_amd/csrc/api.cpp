@@ -689,6 +689,44 @@ int olf_cvt_gray_dev(olf_ctx* c, const uint8_t* d_src, int code, int n_images, u
     return launch_cvt_gray(d_src, d_gray, c->W, c->H, code, n_images, stream ? (hipStream_t)stream : c->stream);
 }
 
+int olf_init_undistort_rectify_map_dev(olf_ctx* c, const double* K, const double* D, int n_dist, const double* R, const double* P, int w, int h,
+                                       float* d_map1, float* d_map2, void* stream)
+{
+    if (!c || !K || !R || !P || !d_map1 || !d_map2 || w < 1 || h < 1 || n_dist < 0 || n_dist > 8 || (n_dist && !D)) {
+        set_error("olf_init_undistort_rectify_map_dev: bad argument (up to 8 distortion coefficients k1 k2 p1 p2 k3 k4 k5 k6)"); return OLF_ERR_INVALID;
+    }
+    OLF_TRY(check_device(c, "olf_init_undistort_rectify_map_dev"));
+    // iR = (P * R)^-1 in double: cv::invert's closed form for 3 x 3 (convention C.13)
+    double m[9];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) m[3 * r + q] = P[3 * r] * R[q] + P[3 * r + 1] * R[3 + q] + P[3 * r + 2] * R[6 + q];
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0.) { set_error("olf_init_undistort_rectify_map_dev: P * R is singular"); return OLF_ERR_INVALID; }
+    d = 1. / d;
+    double ir[9];
+    ir[0] = (m[4] * m[8] - m[5] * m[7]) * d; ir[1] = (m[2] * m[7] - m[1] * m[8]) * d; ir[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+    ir[3] = (m[5] * m[6] - m[3] * m[8]) * d; ir[4] = (m[0] * m[8] - m[2] * m[6]) * d; ir[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+    ir[6] = (m[3] * m[7] - m[4] * m[6]) * d; ir[7] = (m[1] * m[6] - m[0] * m[7]) * d; ir[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist; ++i) k[i] = D[i];
+    return launch_init_rectify_map(ir, k, K[0], K[4], K[2], K[5], w, h, d_map1, d_map2, stream ? (hipStream_t)stream : c->stream);
+}
+
+int olf_init_undistort_rectify_map(olf_ctx* c, const double* K, const double* D, int n_dist, const double* R, const double* P, int w, int h, float* map1, float* map2)
+{
+    if (!c || !map1 || !map2 || w < 1 || h < 1) { set_error("olf_init_undistort_rectify_map: bad argument"); return OLF_ERR_INVALID; }
+    void* st = nullptr;
+    const size_t bm = (size_t)w * h * sizeof(float);
+    OLF_TRY(scratch_get(c, 2, 2 * bm + 64, &st));
+    float* d1 = static_cast<float*>(st);
+    float* d2 = d1 + (size_t)w * h;
+    OLF_TRY(olf_init_undistort_rectify_map_dev(c, K, D, n_dist, R, P, w, h, d1, d2, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(map1, d1, bm, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(map2, d2, bm, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 int olf_remap_linear_dev(olf_ctx* c, const uint8_t* d_src, int sw, int sh, const float* d_mapx, const float* d_mapy, int dw, int dh, int n_images,
                          uint8_t* d_dst, void* stream)
 {

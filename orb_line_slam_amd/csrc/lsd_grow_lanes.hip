@@ -39,6 +39,12 @@ enum { LS_EMPTY = 0, LS_READY = 1, LS_PARKED = 2, LS_GROWING = 3, LS_DONE = 4, L
 struct LnRec { int rank; uint32_t seed; float deg, sx, sy; int n; double ang; };      // 32 bytes, one per ROB slot and image (global memory)
 
 __device__ __forceinline__ int lu(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return (uint32_t)lu((int)v);
+}
 
 // three consecutive words at a 4-byte aligned address
 struct W3 { uint32_t a, b, c; };
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
     int head = 0, tail = 0, readyCur = 0, dispNext = 0, nreg = 0, idleSteps = 0;
     uint32_t wm = 0;
     bool reScan = false, fatal = false;
+    uint32_t minBlk = LN_FREE;      // lower bound of the ranks the parked / stolen-from entries wait for: the ROB is only searched for re-runs once the watermark has passed it
     // lane state
     int slot = -1, n = 0, i = 0, k = 8, cur = 0, rchunk = 0, ex = 0, ey = 0, prevState = LS_READY;
     uint32_t T = 0, rank = 0, seedw = 0;
@@ -151,14 +158,17 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
         // ---- (2) work for idle lanes: re-runs (older) first, then fresh seeds, then the next window of keys -----------------------------
         const bool worker = lane < maxLanes;               // (debug: fewer than 64 lanes grow regions)
         unsigned long long idleM = __ballot(slot < 0 && worker);
-        if (idleM && reScan) {
+        if (idleM && reScan && (wm > minBlk || minBlk == LN_RETRY)) {
             bool left = false;
+            uint32_t newMin = LN_FREE;
             // (the whole ROB: an entry that was parked when it was dispatched may lie beyond the cursor of the fresh seeds)
             for (int base = head; base < tail && idleM; base += 64) {
                 const int idx = base + lane, sl = idx & mask;
                 const int st = idx < tail ? eState[sl] : (int)LS_EMPTY;
                 const uint32_t bl = eInval[sl];
-                const bool el = (st == LS_PARKED || st == LS_DONE) && (bl < wm || bl == LN_RETRY);
+                const bool waiting = (st == LS_PARKED || st == LS_DONE) && bl != LN_FREE;
+                const bool el = waiting && (bl < wm || bl == LN_RETRY);
+                newMin = min(newMin, (waiting && !el) ? bl : LN_FREE);
                 const unsigned long long em = __ballot(el);
                 if (!em) continue;
                 if (el) s_tmp[__popcll(em & ((1ull << lane) - 1ull))] = sl | (st << 16);
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
                 idleM = __ballot(slot < 0 && worker);
                 __builtin_amdgcn_wave_barrier();
             }
-            if (!left && idleM) reScan = false;
+            if (!left && idleM) { reScan = false; minBlk = wave_min(newMin); }      // a complete pass: what is still waiting, waits for at least this
         }
         for (int pass = 0; pass < 2 && idleM; ++pass) {
             // fresh seeds: READY entries at or after readyCur
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
                     eInval[s] = inv;
                     eState[s] = st;
                 }
+                { const uint32_t pb = wave_min(live && eState[(tail + __popcll(m & ((1ull << lane) - 1ull))) & mask] == LS_PARKED ? eInval[(tail + __popcll(m & ((1ull << lane) - 1ull))) & mask] : LN_FREE); if (pb < minBlk) { minBlk = pb; reScan = true; } }
                 tail += (int)__popcll(m); DBG(3, 1);
                 dispNext = min(dispNext + 64, nkeys);
                 if (head == tail) { wm = (uint32_t)dispNext; }
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // ---- (4) one transition per growing lane -------------------------------------------------------------------------------------
-        bool fail = false, seedLost = false;
+        bool fail = false, seedLost = false, told = false;
         uint32_t blocker = LN_FREE;
         const bool active = slot >= 0;
         if (active) {
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
             else if (pMine == 1) {
                 // the claim issued one step ago: an older region had taken the pixel in between -> the decisions since were made on a pixel that was
                 // not available: yield; a younger region's pixel is ours now, and that region is told
-                if (pOld != LN_FREE && pOld > T) __hip_atomic_fetch_min(eInval + (pOld & mask), rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pOld != LN_FREE && pOld > T) { __hip_atomic_fetch_min(eInval + (pOld & mask), rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); told = true; }
                 if (pOld <= T) { fail = true; blocker = pOld == T ? LN_RETRY : (pOld >> LN_SLOT_BITS); seedLost = pSeed && pOld != T; }
                 pMine = 0;
             }
@@ -409,7 +420,8 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
             if (park) { eInval[slot] = blocker; eState[slot] = LS_PARKED; }
             if (dead) eState[slot] = LS_DEAD;
             const unsigned long long pm = __ballot(park);
-            if (pm && __ballot(park && (blocker < wm || blocker == LN_RETRY))) reScan = true;
+            if (pm) { const uint32_t pb = wave_min(park ? (blocker == LN_RETRY ? 0u : blocker) : LN_FREE); if (pb < minBlk) minBlk = pb; reScan = true; }
+            if (__ballot(told)) { const uint32_t tb = wave_min(told ? rank : LN_FREE); if (tb < minBlk) minBlk = tb; reScan = true; }
             if (fail) slot = -1;
         }
         __builtin_amdgcn_wave_barrier();

@@ -126,6 +126,8 @@ int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, i
 
 // precond.hip
 int launch_cvt_gray(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n_images, hipStream_t s);
+int launch_init_rectify_map(const double* ir9, const double* k8, double fx, double fy, double u0, double v0, int w, int h, float* d_map1, float* d_map2,
+                            hipStream_t s);
 int launch_remap_linear(const uint8_t* src, int sw, int sh, const float* mapx, const float* mapy, int dw, int dh, uint8_t* dst, int n_images,
                         hipStream_t s);
 

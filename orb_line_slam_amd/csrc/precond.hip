@@ -47,6 +47,44 @@ __global__ __launch_bounds__(256) void k_remap_linear(const uint8_t* __restrict_
     dst[img * (size_t)dw * dh + i] = (uint8_t)min(max(v, 0), 255);
 }
 
+// cv::initUndistortRectifyMap, CV_32FC1 maps (Examples/PL/PL_stereo_euroc.cc:97-98): one thread per image ROW, because the source coordinates
+// are a running double sum along the row in OpenCV's code (x += ir[0] per column) -- the maps are computed once per sequence, so the row
+// loop costs nothing that matters, and it keeps the sums in the reference's order.  No FMA contraction, IEEE divisions.
+struct RectifyPrm { double ir[9]; double k[8]; double fx, fy, u0, v0; };
+__global__ __launch_bounds__(64) void k_init_rectify_map(RectifyPrm q, int w, int h, float* __restrict__ map1, float* __restrict__ map2)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= h) return;
+    const double k1 = q.k[0], k2 = q.k[1], p1 = q.k[2], p2 = q.k[3], k3 = q.k[4], k4 = q.k[5], k5 = q.k[6], k6 = q.k[7];
+    double _x = __dadd_rn(__dmul_rn((double)i, q.ir[1]), q.ir[2]), _y = __dadd_rn(__dmul_rn((double)i, q.ir[4]), q.ir[5]),
+           _w = __dadd_rn(__dmul_rn((double)i, q.ir[7]), q.ir[8]);
+    for (int j = 0; j < w; ++j) {
+        const double ww = __ddiv_rn(1., _w), x = __dmul_rn(_x, ww), y = __dmul_rn(_y, ww);
+        const double x2 = __dmul_rn(x, x), y2 = __dmul_rn(y, y);
+        const double r2 = __dadd_rn(x2, y2), _2xy = __dmul_rn(__dmul_rn(2., x), y);
+        const double num = __dadd_rn(1., __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(k3, r2), k2), r2), k1), r2));
+        const double den = __dadd_rn(1., __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(k6, r2), k5), r2), k4), r2));
+        const double kr = __ddiv_rn(num, den);
+        const double xd = __dadd_rn(__dadd_rn(__dmul_rn(x, kr), __dmul_rn(p1, _2xy)), __dmul_rn(p2, __dadd_rn(r2, __dmul_rn(2., x2))));
+        const double yd = __dadd_rn(__dadd_rn(__dmul_rn(y, kr), __dmul_rn(p1, __dadd_rn(r2, __dmul_rn(2., y2)))), __dmul_rn(p2, _2xy));
+        map1[(size_t)i * w + j] = (float)__dadd_rn(__dmul_rn(q.fx, xd), q.u0);
+        map2[(size_t)i * w + j] = (float)__dadd_rn(__dmul_rn(q.fy, yd), q.v0);
+        _x = __dadd_rn(_x, q.ir[0]); _y = __dadd_rn(_y, q.ir[3]); _w = __dadd_rn(_w, q.ir[6]);
+    }
+}
+
+int launch_init_rectify_map(const double* ir9, const double* k8, double fx, double fy, double u0, double v0, int w, int h, float* d_map1, float* d_map2,
+                            hipStream_t s)
+{
+    RectifyPrm q;
+    for (int i = 0; i < 9; ++i) q.ir[i] = ir9[i];
+    for (int i = 0; i < 8; ++i) q.k[i] = k8[i];
+    q.fx = fx; q.fy = fy; q.u0 = u0; q.v0 = v0;
+    hipLaunchKernelGGL(k_init_rectify_map, dim3((h + 63) / 64), dim3(64), 0, s, q, w, h, d_map1, d_map2);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 int launch_cvt_gray(const uint8_t* src, uint8_t* dst, int w, int h, int code, int n_images, hipStream_t s)
 {
     const int npx = w * h;

@@ -40,3 +40,19 @@ def remap(images, map1, map2, context=None):
     out = np.zeros((n, dh, dw), np.uint8)
     check(lib().olf_remap_linear(c.handle, ptr(images), w, h, ptr(map1), ptr(map2), dw, dh, n, ptr(out)), "olf_remap_linear")
     return out
+
+
+def initUndistortRectifyMap(K, D, R, P, size, context=None):
+    """cv::initUndistortRectifyMap(K, D, R, P[:3, :3], size, CV_32F) -> (map1, map2) float32 of shape (height, width); size = (width, height)
+    like cv::Size.  Examples/PL/PL_stereo_euroc.cc:97-98."""
+    import ctypes as C
+    w, h = int(size[0]), int(size[1])
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3); R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    P = np.ascontiguousarray(np.asarray(P, np.float64)[:3, :3])
+    D = np.ascontiguousarray(np.asarray(D, np.float64).reshape(-1))
+    c = _ctx(context, max(w, 640), max(h, 480))
+    m1, m2 = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    L = lib()
+    L.olf_init_undistort_rectify_map.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.olf_init_undistort_rectify_map(c.handle, ptr(K), ptr(D), len(D), ptr(R), ptr(P), w, h, ptr(m1), ptr(m2)), "olf_init_undistort_rectify_map")
+    return m1, m2

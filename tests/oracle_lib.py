@@ -481,3 +481,12 @@ def is_in_frustum(f, mp, viewing_cos_limit):
     _L.orc_is_in_frustum(_p(arrs[0]), _p(cam), _p(sf), len(sf), _logsf(sf), mp.n, _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
                          C.c_float(viewing_cos_limit), _p(inv), _p(lvl), _p(cosv), _p(proj))
     return inv.astype(bool), lvl, cosv, proj
+
+
+def init_undistort_rectify_map(K, D, R, P, w, h):
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3); R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    P = np.ascontiguousarray(np.asarray(P, np.float64)[:3, :3]); D = np.ascontiguousarray(np.asarray(D, np.float64).reshape(-1))
+    m1, m2 = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    rc = _L.orc_init_undistort_rectify_map(_p(K), _p(D), len(D), _p(R), _p(P), w, h, _p(m1), _p(m2))
+    assert rc == 0, rc
+    return m1, m2

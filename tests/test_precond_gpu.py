@@ -34,3 +34,33 @@ def test_remap_euroc_like(oracle):
     assert np.array_equal(out[1], oracle.remap_linear(right, mapx, mapy))
     ident = precond.remap(left[None], xs, ys)
     assert np.array_equal(ident[0], left)                  # identity maps reproduce the image
+
+
+def test_init_undistort_rectify_map_euroc(oracle):
+    """cv::initUndistortRectifyMap with the EuRoC calibration of Examples/PL/PL_EuRoC.yaml (LEFT / RIGHT .K .D .R .P): both maps bit-identical
+    to the oracle, and the rectified image through remap() equals the oracle's."""
+    cams = {
+        "left": (np.array([458.654, 0, 367.215, 0, 457.296, 248.375, 0, 0, 1.0]), np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0]),
+                 np.array([0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847, 0.007055629199258132,
+                           -0.008089410156878961, -0.007044357138835809, 0.9999424675829176]),
+                 np.array([435.2046959714599, 0, 367.4517211914062, 0, 0, 435.2046959714599, 252.2008514404297, 0, 0, 0, 1, 0]).reshape(3, 4)),
+        "right": (np.array([457.587, 0, 379.999, 0, 456.134, 255.238, 0, 0, 1.0]), np.array([-0.28368365, 0.07451284, -0.00010473, -3.555907e-05, 0.0]),
+                  np.array([0.9999633526194376, -0.003625811871560086, 0.007755443660172947, 0.003680398547259526, 0.9999684752771629, -0.007035845251224894,
+                            -0.007729688520722713, 0.007064130529506649, 0.999945173484644]),
+                  np.array([435.2046959714599, 0, 367.4517211914062, -47.90639384423901, 0, 435.2046959714599, 252.2008514404297, 0, 0, 0, 1, 0]).reshape(3, 4)),
+    }
+    w, h = 752, 480
+    left, right = synth.stereo_pair(3, w, h)
+    for name, img in (("left", left), ("right", right)):
+        K, D, R, P = cams[name]
+        m1, m2 = precond.initUndistortRectifyMap(K, D, R, P, (w, h))
+        o1, o2 = oracle.init_undistort_rectify_map(K, D, R, P, w, h)
+        assert np.array_equal(m1.view(np.uint32), o1.view(np.uint32)) and np.array_equal(m2.view(np.uint32), o2.view(np.uint32)), name
+        assert abs(float(m1[240, 376]) - 376) < 30 and abs(float(m2[240, 376]) - 240) < 30          # a rectification, not garbage
+        assert np.array_equal(precond.remap(img[None], m1, m2)[0], oracle.remap_linear(img, o1, o2))
+    # rational model (k4..k6) and no distortion at all
+    K, _, R, P = cams["left"]
+    for D in (np.array([0.1, -0.05, 0.001, -0.002, 0.01, 0.02, -0.01, 0.003]), np.zeros(0)):
+        m1, m2 = precond.initUndistortRectifyMap(K, D, R, P, (320, 240))
+        o1, o2 = oracle.init_undistort_rectify_map(K, D, R, P, 320, 240)
+        assert np.array_equal(m1.view(np.uint32), o1.view(np.uint32)) and np.array_equal(m2.view(np.uint32), o2.view(np.uint32))

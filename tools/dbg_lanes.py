@@ -2,9 +2,9 @@ import sys, ctypes as C, numpy as np, os
 sys.path.insert(0, '/root/repo')
 import orb_line_slam_amd as ola
 from orb_line_slam_amd import synth, _lib
-imgs = synth.stereo_batch(71, 1, 640, 480)
+imgs = synth.stereo_batch(7000, 1, 1242, 375)
 ex = ola.Lineextractor(0, 0.025, max_images=2)
-ctx = ex._context(640, 480, 2)
+ctx = ex._context(1242, 375, 2)
 _lib.check(_lib.lib().olf_debug_lsd_waves(ctx.handle, -2, 0), "w")
 try:
     k, d, c = ex.extract_batch(imgs[:1])
