@@ -88,7 +88,7 @@ static int scratch_get(olf_ctx* c, int slot, size_t bytes, void** out)
 // The LSD angle / cos-sin tables depend on nothing but the packed gradient pair: one copy per device, shared by every context of the process
 // (a reference Frame is served by four extractor objects, each with a context of its own; include/orbline_adaptor.hpp).
 namespace {
-struct AngleTables { float* angDeg = nullptr; double2* cosSin = nullptr; float2* seedCS = nullptr; int refs = 0; };
+struct AngleTables { float* angDeg = nullptr; void* angEnt = nullptr; int refs = 0; };
 std::mutex g_tab_mu;
 std::map<int, AngleTables> g_tabs;
 
@@ -97,23 +97,22 @@ int angle_tables_acquire(int device, LineDeviceBufs& l, hipStream_t s)
     std::lock_guard<std::mutex> lk(g_tab_mu);
     AngleTables& t = g_tabs[device];
     if (t.refs == 0) {
-        if (hipMalloc(&t.angDeg, sizeof(float) << 22) != hipSuccess || hipMalloc(&t.cosSin, sizeof(double2) << 22) != hipSuccess ||
-            hipMalloc(&t.seedCS, sizeof(float2) << 22) != hipSuccess) {
-            (void)hipFree(t.angDeg); (void)hipFree(t.cosSin); (void)hipFree(t.seedCS);
+        if (hipMalloc(&t.angDeg, sizeof(float) << 22) != hipSuccess || hipMalloc(&t.angEnt, (size_t)32 << 22) != hipSuccess) {
+            (void)hipFree(t.angDeg); (void)hipFree(t.angEnt);
             t = AngleTables();
             set_error("hipMalloc failed (LSD angle tables)");
             return OLF_ERR_HIP;
         }
-        l.angDeg = t.angDeg; l.cosSin = t.cosSin; l.seedCS = t.seedCS;
+        l.angDeg = t.angDeg; l.angEnt = t.angEnt;
         if (launch_lsd_angle_table(l, s) != OLF_OK || hipStreamSynchronize(s) != hipSuccess) {
-            (void)hipFree(t.angDeg); (void)hipFree(t.cosSin); (void)hipFree(t.seedCS);
+            (void)hipFree(t.angDeg); (void)hipFree(t.angEnt);
             t = AngleTables();
             set_error("LSD angle table build failed");
             return OLF_ERR_HIP;
         }
     }
     ++t.refs;
-    l.angDeg = t.angDeg; l.cosSin = t.cosSin; l.seedCS = t.seedCS;
+    l.angDeg = t.angDeg; l.angEnt = t.angEnt;
     return OLF_OK;
 }
 
@@ -123,7 +122,7 @@ void angle_tables_release(int device)
     auto it = g_tabs.find(device);
     if (it == g_tabs.end() || it->second.refs <= 0) return;
     if (--it->second.refs == 0) {
-        (void)hipFree(it->second.angDeg); (void)hipFree(it->second.cosSin); (void)hipFree(it->second.seedCS);
+        (void)hipFree(it->second.angDeg); (void)hipFree(it->second.angEnt);
         g_tabs.erase(it);
     }
 }

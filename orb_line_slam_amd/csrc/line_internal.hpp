@@ -12,7 +12,7 @@
 //   lbdBlur  : u8  H x pitchW      GaussianBlur(5x5, sigma 1)                              (LBD)
 //   dxdy     : u32 H x W           packed Sobel (dx, dy) int16 pair                        (LBD)
 //   rowSums  : float4 nLines x 63  per support-region row: (pgdL, ngdL, pgdO, ngdO)        (LBD)
-// Per context (image independent): angDeg / cosSin / seedCS, 2^22 entries each (see LineDeviceBufs).
+// Per context (image independent): angDeg (4 B) and angEnt (32 B), 2^22 entries each (see LineDeviceBufs).
 #pragma once
 #include "olf_internal.hpp"
 
@@ -67,8 +67,7 @@ struct LineDeviceBufs {
     size_t sortTempBytes = 0;
     int* status = nullptr;
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
-    double2* cosSin = nullptr;     // [2^22] cos / sin of that angle as the reference evaluates them for an added pixel (float-rounded argument)
-    float2* seedCS = nullptr;      // [2^22] (float)cos / (float)sin of the unrounded angle: the sums a region starts with
+    void* angEnt = nullptr;        // [2^22] AngEnt (lsd_device.hpp): angle in radians, cos / sin as an added pixel, the sums a seed starts with -- 32 B
     uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
     uint32_t* deg = nullptr;       // [n][Ps] level-line angle (degrees, float bits) of every defined pixel (k_lsd_keys; read by k_lsd_iso and the lane growth)
     void* rob = nullptr;           // [n][1024] 32-byte reorder-buffer records of the lane growth (lsd_grow_lanes.hip)

@@ -281,7 +281,7 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 // context over the packed 22-bit (gx:11 | gy:11) field of the gradient word -- 84 MB, image independent, shared by every agent; real
 // images touch a small, L2 / Infinity-Cache resident part of it.  This takes fastAtan2 and the double sincos out of the agent's
 // per-iteration instruction stream (the agent is VALU-issue bound), at the price of one more dependent load.
-__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, double2* __restrict__ cosSin, float2* __restrict__ seedCS)
+__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, AngEnt* __restrict__ ent)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int gx = unpack_gx(i), gy = unpack_gy(i);
@@ -290,16 +290,16 @@ __global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ ang
     double sn, cs;
     sincos_2pi((double)(float)ang, &sn, &cs);
     angDeg[i] = deg;
-    cosSin[i] = make_double2(cs, sn);
     // region_grow starts its sums at float(cos(reg_angle)), float(sin(reg_angle)) with the seed's angle as a double
     double s0, c0;
     sincos_2pi(ang, &s0, &c0);
-    seedCS[i] = make_float2((float)c0, (float)s0);
+    AngEnt e; e.cs = cs; e.sn = sn; e.ang = ang; e.seed = make_float2((float)c0, (float)s0);
+    ent[i] = e;
 }
 
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, b.cosSin, b.seedCS);
+    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, reinterpret_cast<AngEnt*>(b.angEnt));
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
@@ -353,8 +353,7 @@ constexpr int PEND = 512;    // hash table of pixels whose USED store may not be
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
-                                                 int* __restrict__ status, const float* __restrict__ angDeg,
-                                                 const double2* __restrict__ cosSin, const float2* __restrict__ seedCS)
+                                                 int* __restrict__ status, const AngEnt* __restrict__ ent)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
@@ -373,6 +372,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
     long long st_mem = 0, st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
+    long long st_win = 0, st_seedl = 0, st_regl = 0, st_acc = 0, st_isos = 0, st_logged = 0;
 #endif
 #ifdef OLF_TIMING2
     long long p_ring = 0, p_gather = 0, p_table = 0, p_chain = 0, p_commit = 0, p_n = 0, ps;
@@ -403,12 +403,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
         const uint32_t wseed = valid ? grad[addr] : kUsed;
         const bool isoSeed = (wseed & kIso) != 0;
+#ifdef OLF_STATS
+        ++st_win; st_seedl += __popcll(__ballot(valid)); st_isos += __popcll(__ballot(valid && isoSeed));
+#endif
         unsigned long long mask = __ballot(valid && !(wseed & kUsed) && s_pend[addr & (PEND - 1)] != addr);
         // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
         // are per-(gx, gy) table entries
-        float seedDeg = 0.f;
+        double seedAng = 0;
         float2 seedSum = make_float2(0.f, 0.f);
-        if (((mask >> lane) & 1ull) && !isoSeed) { seedDeg = angDeg[wseed & 0x3fffffu]; seedSum = seedCS[wseed & 0x3fffffu]; }
+        if (((mask >> lane) & 1ull) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
             {
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int n = 1;
             // the seed's word as loaded with the window: only its USED bit can have changed since, and the mask says it has not
             const uint32_t pseed = (uint32_t)rlane((int)wseed, l);
-            double reg_angle = d_mul((double)__int_as_float(rlane(__float_as_int(seedDeg), l)), kDegToRads);
+            double reg_angle = rlane_d(seedAng, l);
             float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
@@ -472,10 +475,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 double ang = 0, cs = 0, sn = 0;
                 PSTAMP(p_gather);
                 if (cand) {
-                    const uint32_t ti = pw & 0x3fffffu;
-                    ang = d_mul((double)angDeg[ti], kDegToRads);
-                    const double2 t = cosSin[ti];
-                    cs = t.x; sn = t.y;
+                    const AngEnt* t = ent + (pw & 0x3fffffu);      // one 32-byte sector per candidate
+                    cs = t->cs; sn = t->sn; ang = t->ang;
                 }
                 // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
@@ -595,6 +596,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             { long long t1 = __builtin_readcyclecounter(); t_rect += t1 - t0; t0 = t1; }
 #endif
             // seeds later in this 64-key window may have been consumed by the region just grown
+#ifdef OLF_STATS
+            st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(__ballot(valid && lane > l));
+#endif
             if (n == 1) mask &= mask - 1;
             else mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
         }
@@ -609,7 +613,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
 #ifdef OLF_STATS
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big;
-        o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem; }
+        o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem;
+        o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; }
 #endif
     if (lane == 0) regCount[img] = nreg;
 }
@@ -859,7 +864,7 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         return launch_lsd_grow_mw(g, b, n_images, nw, E, s);
     }
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS);
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt));
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

@@ -15,6 +15,11 @@ __device__ __forceinline__ int unpack_gy(uint32_t p) { return ((int)(p << 10)) >
 
 // one grown region that is large enough to be fitted: its pixels are region[start .. start + n) in growth order
 struct RegionRec { int start, n; double angle; };
+// One entry of the per-context angle table (index: the packed gradient pair gx:11 | gy:11 of a grad word), 32 bytes = one HBM sector:
+// everything region_grow needs from a pixel.  ang = fastAtan2(gx, -gy) * DEG2RAD as a double; cs / sn = cos / sin of the float-rounded
+// angle (what an added pixel contributes to the sums); seed = (float)cos / (float)sin of the double angle (the sums a region starts with).
+struct AngEnt { double cs, sn, ang; float2 seed; };
+static_assert(sizeof(AngEnt) == 32, "AngEnt is one 32-byte sector");
 __device__ __forceinline__ uint32_t pack_g(int gx, int gy) { return ((uint32_t)gx & 0x7ffu) | (((uint32_t)gy & 0x7ffu) << 11); }
 
 __device__ __forceinline__ double shfl_d(double v, int l)

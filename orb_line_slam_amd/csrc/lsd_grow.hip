@@ -203,7 +203,7 @@ __device__ __forceinline__ void mw_notify(const MwCtx& c, uint32_t victim, uint3
 // next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do.
 // The loads (keys, seed words, owners, the seeds' table entries) are done before the lock is taken, the lock only covers the insertion;
 // isolated seeds (k_lsd_iso) are claimed right here, 64 at a time, and enter the ROB as finished one-pixel regions.
-__device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, const float* __restrict__ angDeg, const float2* __restrict__ seedCS)
+__device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, const float* __restrict__ angDeg, const AngEnt* __restrict__ ent)
 {
     const int dn0 = cv.dispNext;
     if (dn0 >= c.nkeys) return 0;
@@ -216,7 +216,7 @@ __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, cons
     const bool iso = (w & kIso) != 0;
     float deg = 0.f;
     float2 ss = make_float2(0.f, 0.f);
-    if (valid && !iso) { deg = angDeg[w & 0x3fffffu]; ss = seedCS[w & 0x3fffffu]; }    // region_grow starts at the seed's angle and at (cos, sin) of it
+    if (valid && !iso) { deg = angDeg[w & 0x3fffffu]; ss = ent[w & 0x3fffffu].seed; }    // region_grow starts at the seed's angle and at (cos, sin) of it
     if (!try_lock(c.ctl + C_LOCKDISP, c.lane)) return 1;
     const MwCtl cl = mw_ctl(c.ctl);
     const int dn = cl.dispNext, t = cl.tail, h = cl.head;
@@ -292,8 +292,7 @@ __device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* pre
 #define RUN_PROF_ARGS
 #define RUN_PROF_PASS
 #endif
-__device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int wv, double prec, double precWrap, const float* __restrict__ angDeg,
-                                       const double2* __restrict__ cosSin RUN_PROF_ARGS)
+__device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int wv, double prec, double precWrap, const AngEnt* __restrict__ ent RUN_PROF_ARGS)
 {
     PROF_CNT(PF_NRUN);
     const int lane = c.lane, Ws = c.Ws, Hs = c.Hs;
@@ -391,9 +390,9 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         double ang = 0, cs = 0, sn = 0;
         if (cand) {
             const uint32_t ti = pw & 0x3fffffu;
-            ang = d_mul((double)angDeg[ti], kDegToRads);
-            const double2 t = cosSin[ti];
-            cs = t.x; sn = t.y;
+            const AngEnt* t = ent + ti;
+            ang = t->ang;
+            cs = t->cs; sn = t->sn;
         }
         unsigned long long cm = __ballot(cand);
         const unsigned long long conM = __ballot(con);
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
                                                       const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
-                                                      const double2* __restrict__ cosSin, const float2* __restrict__ seedCS, int E, int nChunks)
+                                                      const AngEnt* __restrict__ ent, int E, int nChunks)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -577,8 +576,8 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         int prev = ST_READY;
         const int slot = mw_pick(c, cv, &prev);
         PROF(PF_PICK);
-        if (slot >= 0) { idle = 0; mw_run(c, slot, prev, wv, prec, precWrap, angDeg, cosSin RUN_PROF_PASS); continue; }
-        const int dsp = mw_dispatch(c, cv, angDeg, seedCS);
+        if (slot >= 0) { idle = 0; mw_run(c, slot, prev, wv, prec, precWrap, ent RUN_PROF_PASS); continue; }
+        const int dsp = mw_dispatch(c, cv, angDeg, ent);
         PROF(PF_DISPATCH);
         if (dsp) continue;
         // nothing to run, nothing to dispatch: finished, or waiting for other waves' regions
@@ -604,7 +603,7 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
     static bool attr_set = false;
     if (!attr_set) { OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
     hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS, E, b.nChunks);
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E, b.nChunks);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

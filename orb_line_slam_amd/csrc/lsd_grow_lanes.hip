@@ -66,8 +66,8 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
                                                         const uint32_t* __restrict__ degAll, const uint32_t* __restrict__ keysAll,
                                                         const int* __restrict__ keyCount, uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll,
                                                         LnRec* __restrict__ robAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
-                                                        int* __restrict__ status, const float* __restrict__ angDeg, const double2* __restrict__ cosSin,
-                                                        const float2* __restrict__ seedCS, int nChunks, int maxLanes)
+                                                        int* __restrict__ status, const float* __restrict__ angDeg, const AngEnt* __restrict__ ent,
+                                                        int nChunks, int maxLanes)
 {
     __shared__ int eState[LN_E];
     __shared__ uint32_t eInval[LN_E];          // DONE: lowest rank that stole from the region (FREE: none); PARKED: rank of the region it waits for
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
                     LnRec r;
                     r.rank = rk; r.seed = (uint32_t)addr | (iso ? 0x80000000u : 0u); r.n = 0; r.ang = 0;
                     r.deg = iso ? 0.f : angDeg[w & 0x3fffffu];
-                    const float2 ss = iso ? make_float2(0.f, 0.f) : seedCS[w & 0x3fffffu];
+                    const float2 ss = iso ? make_float2(0.f, 0.f) : ent[w & 0x3fffffu].seed;
                     r.sx = ss.x; r.sy = ss.y;
                     rob[s] = r;
                     int st = LS_READY;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow_lanes(const LineGeom* __restric
                     uint32_t ti = nbGxgy[0];
 #pragma unroll
                     for (int j = 1; j < 8; ++j) ti = js == j ? nbGxgy[j] : ti;
-                    const double2 t = cosSin[ti];
+                    const AngEnt* tp = ent + ti; const double2 t = make_double2(tp->cs, tp->sn);
                     sumdx = (float)d_add((double)sumdx, t.x);
                     sumdy = (float)d_add((double)sumdy, t.y);
                     reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
@@ -464,7 +464,7 @@ int launch_lsd_grow_lanes(const LineGeom& g, LineDeviceBufs& b, int n_images, hi
 {
     const int maxLanes = b.forceE > 0 && b.forceE <= 64 ? b.forceE : 64;
     hipLaunchKernelGGL(k_lsd_grow_lanes, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.owner, b.deg, b.keysB, b.keyCount, b.region, b.links,
-                       reinterpret_cast<LnRec*>(b.rob), reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, b.cosSin, b.seedCS, b.nChunks, maxLanes);
+                       reinterpret_cast<LnRec*>(b.rob), reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), b.nChunks, maxLanes);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

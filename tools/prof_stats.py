@@ -3,6 +3,7 @@ import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__fil
 import orb_line_slam_amd as ola
 from orb_line_slam_amd import synth, _lib
 n = 64
+os.environ['OLF_LSD_NW'] = '0'
 imgs = synth.stereo_batch(7000, 16, 1242, 375)
 imgs = np.tile(imgs, (n // 32 + 1, 1, 1))[:n].copy()
 if len(sys.argv) > 1 and sys.argv[1] == "tri":      # 40-pixel bands of one gradient direction: regions of thousands of pixels
@@ -15,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "wide":     # 1.5 grey levels / pixel wi
     kw = dict(lsd_quant=0.3, lsd_scale=2.0)
 ex = ola.Lineextractor(500, 0.025, max_images=n, **kw)
 k, d, c = ex.extract_batch(imgs)
-out = np.zeros(64, np.int32)
-_lib.lib().olf_debug_status(ex._ctx.handle, out.ctypes.data_as(C.c_void_p))
-t = out[16:46].view(np.int64)
-print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions", "iters_fifo_from_memory"], t.tolist())))
+out = np.zeros(128, np.int32)
+_lib.lib().olf_debug_status_n(ex._ctx.handle, out.ctypes.data_as(C.c_void_p), 128)
+t = out[16:60].view(np.int64)
+print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions", "iters_fifo_from_memory", "nkeys", "windows_entered", "seed_lanes_gathered", "regather_lanes", "pixels_in_regions", "iso_seeds", "pixels_logged"], t.tolist())))
