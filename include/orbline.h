@@ -205,6 +205,11 @@ typedef struct olf_frame_view {
  * received (-1 = none); cur->mp_valid / mp_obs are updated; *nmatches = the reference's return value. */
 int olf_search_by_projection(olf_ctx* ctx, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
                              int32_t* matches, int32_t* nmatches);
+/* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize),
+ * src/ORBmatcher.cc:407-522 (monocular map initialisation).  Only keys / desc / n / the image bounds of the views are read.
+ * prev_matched: f1->n (x, y) pairs, updated in place with the matched F2 positions; matches12[i1] = F2 index or -1. */
+int olf_search_for_initialization(olf_ctx* ctx, const olf_frame_view* f1, const olf_frame_view* f2, float* prev_matched, int window_size,
+                                  float nnratio, int check_orientation, int32_t* matches12, int32_t* nmatches);
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290
  * (Tracking::TrackReferenceKeyFrame / Relocalization).  matched[iF] = index of the key-frame feature whose map point feature iF of F
  * received (-1 = none). */

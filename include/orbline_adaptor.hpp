@@ -210,6 +210,8 @@ public:
     template <class FrameT> int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono);
     template <class FrameT, class MapPointT> int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3);
     template <class KeyFrameT, class FrameT, class MapPointT> int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches);
+    template <class FrameT, class Point2fT> int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Point2fT>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                                                        int windowSize = 10);
 
     // The members of the reference's MapPoints read by SearchByProjection(Frame&, const vector<MapPoint*>&, th), gathered into arrays
     struct TrackedMapPoints {
@@ -238,6 +240,18 @@ public:
         const TrackedMapPoints& m = vpMapPoints;
         olf_detail::check(olf_search_local_map(ctx, &F, m.n, m.mbTrackInView, m.isBad, m.mnTrackScaleLevel, m.mTrackViewCos, m.mTrackProjXYR,
                                                m.descriptor, m.observed, th, mfNNratio, matches.data(), &n), "olf_search_local_map");
+        return n;
+    }
+    // int SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize = 10),
+    // src/ORBmatcher.cc:407-522; vbPrevMatched as F1.n (x, y) pairs, updated in place
+    int SearchForInitialization(olf_ctx* ctx, const olf_frame_view& F1, const olf_frame_view& F2, float* vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10) const
+    {
+        vnMatches12.assign(F1.n, -1);
+        static_assert(sizeof(int) == sizeof(int32_t), "vnMatches12 is written as int32_t");
+        int32_t n = 0;
+        olf_detail::check(olf_search_for_initialization(ctx, &F1, &F2, vbPrevMatched, windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n),
+                          "olf_search_for_initialization");
         return n;
     }
     // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290

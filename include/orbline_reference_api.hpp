@@ -172,6 +172,17 @@ template <class FrameT, class MapPointT> int ORBmatcher::SearchByProjection(Fram
     }
 }
 
+// int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10),
+// src/ORBmatcher.cc:407-522 (Tracking::MonocularInitialization, src/Tracking.cc:628)
+template <class FrameT, class Point2fT> int ORBmatcher::SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Point2fT>& vbPrevMatched,
+                                                                                  std::vector<int>& vnMatches12, int windowSize)
+{
+    static_assert(sizeof(Point2fT) == 2 * sizeof(float), "cv::Point2f is two floats");
+    olf_detail::FrameGather<FrameT> f1(F1, false), f2(F2, false);
+    if ((int)vbPrevMatched.size() < F1.N) throw std::runtime_error("SearchForInitialization: vbPrevMatched shorter than F1.mvKeysUn");
+    return SearchForInitialization(olf_detail::thread_ctx(), f1.v, f2.v, reinterpret_cast<float*>(vbPrevMatched.data()), vnMatches12, windowSize);
+}
+
 // int SearchByBoW(KeyFrame* pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290
 template <class KeyFrameT, class FrameT, class MapPointT> int ORBmatcher::SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches)
 {

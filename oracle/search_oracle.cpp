@@ -164,6 +164,61 @@ int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc
     return nmatches;
 }
 
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:407-522; prevMatched: (x, y) per F1 key point, updated in place
+int orc_search_for_initialization(const olf_keypoint* keys1, const uint8_t* desc1, int n1, const olf_keypoint* keys2, const uint8_t* desc2, int n2,
+                                  const float* cam9, float* prevMatched, int windowSize, float nnratio, int checkOri, int* vnMatches12)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = keys2; G.N = n2; G.c = c; G.build();
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const olf_keypoint kp1 = keys1[i1];
+        const int level1 = kp1.octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = G.area(prevMatched[2 * i1], prevMatched[2 * i1 + 1], windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* d1 = desc1 + 32 * (size_t)i1;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            const int dist = hamming256(d1, desc2 + 32 * i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = keys1[i1].angle - keys2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) { prevMatched[2 * i1] = keys2[vnMatches12[i1]].x; prevMatched[2 * i1 + 1] = keys2[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
 // feature vectors as CSR: node ids ascending (std::map order), offsets, indices
 int orc_search_by_bow(const olf_keypoint* kfKeys, const uint8_t* kfDesc, const uint8_t* kf_mp_valid, const uint8_t* kf_mp_bad, const int* kfNodes,
                       const int* kfOffs, const int* kfIdx, int kfNNodes, const olf_keypoint* fKeys, const uint8_t* fDesc, int fN, const int* fNodes,

@@ -128,6 +128,8 @@ def lib():
         L.olf_match_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_by_projection.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.olf_search_by_bow.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_for_initialization.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_void_p, C.c_int, C.c_float, C.c_int,
+                                                    C.c_void_p, C.c_void_p]
         V = C.POINTER(FrameViewC)
         L.olf_is_in_frustum.argtypes = [V, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 4
         L.olf_search_by_projection_kf.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -10,6 +10,7 @@
 // Float expressions are written as the reference writes them (src/ORBmatcher.cc, float unless a double literal promotes them); cv::Mat
 // products of CV_32F operands accumulate in double and round once; the library is built with -ffp-contract=off.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -218,6 +219,60 @@ int olf_search_by_projection(olf_ctx* c, const olf_frame_view* cur, const olf_fr
             for (int j : rotHist[b]) { cur->mp_valid[j] = 0; matches[j] = -1; n--; }
         }
     }
+    *nmatches = n;
+    return OLF_OK;
+}
+
+int olf_search_for_initialization(olf_ctx* c, const olf_frame_view* f1, const olf_frame_view* f2, float* prev_matched, int window_size, float nnratio,
+                                  int check_orientation, int32_t* matches12, int32_t* nmatches)
+{
+    if (!c || bad_view(f1, false) || bad_view(f2, false) || !matches12 || !nmatches || (f1->n && !prev_matched)) {
+        set_error("olf_search_for_initialization: bad argument"); return OLF_ERR_INVALID;
+    }
+    for (int i = 0; i < f1->n; ++i) matches12[i] = -1;
+    *nmatches = 0;
+    // candidate lists: GetFeaturesInArea(vbPrevMatched[i1], windowSize, level1, level1) for the level-0 key points of F1   (:421-429)
+    const Grid grid(*f2);
+    Batch q;
+    for (int i1 = 0; i1 < f1->n; ++i1) {
+        const int level1 = f1->keys[i1].octave;
+        if (level1 > 0) continue;
+        if (!grid.area(prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1, q.cand)) continue;
+        q.add(i1, f1->desc + 32 * (size_t)i1);
+    }
+    OLF_TRY(q.run(c, f2->desc, f2->n));
+    // the resolution depends on the matches made so far (vMatchedDistance): replayed in F1 order                             (:431-486)
+    std::vector<int> matchedDistance((size_t)f2->n, INT_MAX), matches21((size_t)f2->n, -1);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int n = 0;
+    for (size_t k = 0; k < q.owner.size(); ++k) {
+        const int i1 = q.owner[k];
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
+            const int i2 = q.cand[p], dist = q.dist[p];
+            if (matchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; n--; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDistance[bestIdx2] = bestDist;
+            n++;
+            if (check_orientation) rotHist[rot_bin(f1->keys[i1].angle, f2->keys[bestIdx2].angle)].push_back(i1);
+        }
+    }
+    if (check_orientation) {
+        int ind1, ind2, ind3;
+        three_maxima(rotHist, ind1, ind2, ind3);
+        for (int b = 0; b < HISTO_LENGTH; b++) {
+            if (b == ind1 || b == ind2 || b == ind3) continue;
+            for (int idx1 : rotHist[b]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; n--; }
+        }
+    }
+    for (int i1 = 0; i1 < f1->n; ++i1)                                                       // "Update prev matched"          (:516-519)
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = f2->keys[matches12[i1]].x; prev_matched[2 * i1 + 1] = f2->keys[matches12[i1]].y; }
     *nmatches = n;
     return OLF_OK;
 }

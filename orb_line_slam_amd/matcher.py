@@ -270,6 +270,21 @@ def _search_by_projection(self, CurrentFrame, LastFrame, th, bMono):
     return int(n[0]), matches
 
 
+def _search_for_initialization(self, F1, F2, vbPrevMatched, windowSize=10):
+    """int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12,
+    int windowSize), src/ORBmatcher.cc:407-522 (monocular initialisation) -> olf_search_for_initialization.  vbPrevMatched: float32 [N1, 2],
+    updated in place like the reference's vector.  Returns (nmatches, vnMatches12)."""
+    keep = []
+    f1, f2 = _view_c(F1, keep), _view_c(F2, keep)
+    if not (isinstance(vbPrevMatched, np.ndarray) and vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags.c_contiguous
+            and vbPrevMatched.shape == (F1.N, 2)):
+        raise ValueError("vbPrevMatched: contiguous float32 array of shape (F1.N, 2)")
+    m, n = np.full(F1.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_for_initialization(_ctx(self._context).handle, f1, f2, ptr(vbPrevMatched), int(windowSize), float(self.mfNNratio),
+                                              int(bool(self.mbCheckOrientation)), ptr(m), ptr(n)), "olf_search_for_initialization")
+    return int(n[0]), m
+
+
 def _search_by_bow(self, pKF, F):
     """int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:161-290 ->
     olf_search_by_bow.  Returns (nmatches, vpMapPointMatches) with vpMapPointMatches[iF] = KF feature index whose map point was matched
@@ -486,6 +501,7 @@ def _search_by_sim3(self, pKF1, pKF2, vpMatches12, s12, R12, t12, th):
 
 
 ORBmatcher.SearchForTriangulation = _search_for_triangulation
+ORBmatcher.SearchForInitialization = _search_for_initialization
 ORBmatcher.FuseSearchSim3 = _fuse_search_sim3
 ORBmatcher.SearchBySim3 = _search_by_sim3
 ORBmatcher.FuseSearch = _fuse_search

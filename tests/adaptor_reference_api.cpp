@@ -168,6 +168,21 @@ int main()
         if (nb <= 0 || (int)bowMatches.size() != n) return 14;
         for (int i = 0; i < n; ++i) if (bowMatches[i] && bowMatches[i] != &pool[i]) return 15;
     }
+    // int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize) src/Tracking.cc:628
+    {
+        struct Point2f { float x, y; };
+        Frame ini; fill_frame(ini, n);
+        ini.mvKeysUn = cur.mvKeysUn; ini.mDescriptors = cur.mDescriptors;
+        std::vector<Point2f> prev(n);
+        for (int i = 0; i < n; ++i) { prev[i].x = cur.mvKeysUn[i].x + 1.f; prev[i].y = cur.mvKeysUn[i].y - 1.f; }
+        std::vector<int> ini12;
+        int ni = -1;
+        try { ni = matcher.SearchForInitialization(ini, cur, prev, ini12, 100); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+        if (gpu) {
+            if (ni <= 0 || (int)ini12.size() != n) return 30;
+            for (int i = 0; i < n; ++i) if (ini12[i] >= 0 && (ini12[i] != i || prev[i].x != cur.mvKeysUn[i].x || cur.mvKeysUn[i].octave > 0)) return 31;
+        }
+    }
     // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b); int distance(const cv::Mat&, const cv::Mat&)     (host, no device)
     Mat zero(1, 32, 0), ones(1, 32, 0);
     for (int b = 0; b < 32; ++b) ones.data[b] = 0xff;
@@ -226,8 +241,8 @@ int main()
         Mat small(100, 100, 0);
         try { ORB_SLAM2::StereoFrameFeatures(F, L, small); return 26; } catch (const std::runtime_error&) {}      // size mismatch throws, src/Frame.cc:145-146
     }
-    if (!gpu && thrown != 7) { std::printf("no device: %d of 7 device calls threw\n", thrown); return 30; }
-    if (gpu && thrown != 0) return 31;
+    if (!gpu && thrown != 8) { std::printf("no device: %d of 8 device calls threw\n", thrown); return 40; }
+    if (gpu && thrown != 0) return 41;
     std::printf(gpu ? "REFERENCE_API_OK %d %d %d\n" : "REFERENCE_API_COMPILED %d %d %d\n", nm, nl, nb);
     return 0;
 }

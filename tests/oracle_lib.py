@@ -218,6 +218,19 @@ def search_by_projection(cur, last, th, bMono=False, checkOri=True):
     return n, matches
 
 
+def search_for_initialization(f1, f2, prev_matched, window_size, nnratio, checkOri=True):
+    """f1/f2: FrameView -> (nmatches, vnMatches12, updated vbPrevMatched)"""
+    cam = np.array([f2.fx, f2.fy, f2.cx, f2.cy, f2.mbf, f2.mnMinX, f2.mnMaxX, f2.mnMinY, f2.mnMaxY], np.float32)
+    a = np.ascontiguousarray
+    arrs = [a(f1.mvKeysUn), a(f1.mDescriptors), a(f2.mvKeysUn), a(f2.mDescriptors)]
+    pm = a(np.asarray(prev_matched, np.float32)).copy()
+    m = np.full(f1.N, -1, np.int32)
+    _L.orc_search_for_initialization.restype = C.c_int
+    n = _L.orc_search_for_initialization(_p(arrs[0]), _p(arrs[1]), f1.N, _p(arrs[2]), _p(arrs[3]), f2.N, _p(cam), _p(pm), int(window_size),
+                                         C.c_float(nnratio), int(checkOri), _p(m))
+    return n, m, pm
+
+
 def _featvec_csr(fv):
     nodes = np.array(sorted(fv), np.int32)
     offs = np.zeros(len(nodes) + 1, np.int32)

@@ -49,6 +49,26 @@ def test_search_by_projection(oracle, th, bMono):
     assert n2 == n2o and np.array_equal(m2, m2o)
 
 
+@pytest.mark.parametrize("window,ratio", [(100, 0.9), (30, 0.7), (10, 0.9)])
+def test_search_for_initialization(oracle, window, ratio):
+    """SearchForInitialization (monocular initialisation, src/ORBmatcher.cc:407-522): level-0 key points only, greedy with re-assignment
+    (vMatchedDistance / vnMatches21), vbPrevMatched updated in place"""
+    f1, f2 = _frames(oracle, seed=47)
+    prev = np.ascontiguousarray(np.stack([f1.mvKeysUn["x"], f1.mvKeysUn["y"]], axis=1).astype(np.float32))
+    for check in (True, False):
+        n_o, m_o, pm_o = oracle.search_for_initialization(f1, f2, prev, window, ratio, checkOri=check)
+        pm_g = prev.copy()
+        n_g, m_g = ola.ORBmatcher(ratio, check).SearchForInitialization(f1, f2, pm_g, window)
+        assert n_g == n_o and np.array_equal(m_g, m_o) and np.array_equal(pm_g, pm_o)
+        assert n_g == int((m_g >= 0).sum())
+    assert n_g > (20 if window >= 30 else 0)
+    # second call seeded with the updated positions, as Tracking::MonocularInitialization does frame after frame
+    n_o2, m_o2, pm_o2 = oracle.search_for_initialization(f1, f2, pm_o, window, ratio, checkOri=False)
+    pm_g2 = pm_g.copy()
+    n_g2, m_g2 = ola.ORBmatcher(ratio, False).SearchForInitialization(f1, f2, pm_g2, window)
+    assert n_g2 == n_o2 and np.array_equal(m_g2, m_o2) and np.array_equal(pm_g2, pm_o2)
+
+
 def test_search_by_bow(oracle):
     last, cur = _frames(oracle, seed=43)
     # synthetic feature vectors (the vocabulary blobs are missing from the reference checkout, SURVEY F8): node = coarse image cell
