@@ -266,8 +266,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n);
     l.nChunks = 1024 + lg.Ps / 32 + 64;
-    A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks); A(l.deg, n * lg.Ps);
-    { void* q = nullptr; if (hipMalloc(&q, n * (size_t)1024 * 32) != hipSuccess) { set_error("hipMalloc failed"); return fail(OLF_ERR_HIP); } c->allocs.push_back(q); l.rob = q; }
+    A(l.region, n * (size_t)l.nChunks * 32); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
@@ -492,8 +491,7 @@ int olf_debug_copy_bandwidth(olf_ctx* c, size_t bytes, int reps, double* gbytes_
 int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
 {
     const bool pow2 = rob_entries > 0 && (rob_entries & (rob_entries - 1)) == 0;
-    if (!c || waves_per_image > 16 || waves_per_image < -2 || (waves_per_image != -2 && rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512)) ||
-        (waves_per_image == -2 && (rob_entries < 0 || rob_entries > 64))) {       // (lane growth: rob_entries = lanes that grow regions, 0 = all 64)
+    if (!c || waves_per_image > 16 || waves_per_image < -1 || (rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512))) {
         set_error("olf_debug_lsd_waves: bad argument"); return OLF_ERR_INVALID;
     }
     c->lb.forceNW = waves_per_image;

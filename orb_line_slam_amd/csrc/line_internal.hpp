@@ -69,8 +69,6 @@ struct LineDeviceBufs {
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
     void* angEnt = nullptr;        // [2^22] AngEnt (lsd_device.hpp): angle in radians, cos / sin as an added pixel, the sums a seed starts with -- 32 B
     uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
-    uint32_t* deg = nullptr;       // [n][Ps] level-line angle (degrees, float bits) of every defined pixel (k_lsd_keys; read by k_lsd_iso and the lane growth)
-    void* rob = nullptr;           // [n][1024] 32-byte reorder-buffer records of the lane growth (lsd_grow_lanes.hip)
     int* links = nullptr;          // [n][nChunks] next chunk of a region's pixel list (-1: last)
     int nChunks = 0;               // 32-pixel chunks per image in `region` (ids < 1024: the ROB slots' own chunks, then the pool)
     int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic

@@ -128,102 +128,107 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
     }
 }
 
-// ll_angle, second half: bin of every defined pixel -> sort key.  The keys are emitted in raster order (each wave compacts a contiguous
-// quarter of the chunk, chunk bases come from k_lsd_grad's per-chunk counts), so the pseudo-ordering only has to order the 10 bin
-// bits with a stable sort: equal bins stay in raster order, which is the reference's list order.
-__global__ __launch_bounds__(256) void k_lsd_keys(const uint32_t* __restrict__ grad, const LineGeom* __restrict__ gp,
+// ll_angle, second half, and the isolated-seed test, in one pass over the gradient words.
+//
+// Keys: bin of every defined pixel -> sort key.  The keys are emitted in raster order (each wave compacts a contiguous quarter of the chunk,
+// chunk bases come from k_lsd_grad's per-chunk counts), so the pseudo-ordering only has to order the 10 bin bits with a stable sort: equal
+// bins stay in raster order, which is the reference's list order.
+//
+// Isolated seeds: a seed whose 8 neighbours are all undefined or not aligned with the seed's own angle can never grow: its region is the seed
+// alone (region_grow tests every neighbour against reg_angle == the seed angle and nothing is ever added), whatever has been used before.
+// That is a static property of the gradient field; it is flagged here (bit ISO of the gradient word) so that the sequential growth can retire
+// such seeds without running a growth step.
+//
+// The block first evaluates the level-line angle (fastAtan2(gx, -gy), degrees) of every pixel of its chunk and of one image row (+1 pixel)
+// either side into LDS -- the neighbours' angles come from there, not from a second pass over memory -- and blocks are numbered so that
+// the chunks of an image follow each other on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own): the
+// halo rows are then L2 hits.
+constexpr float kDegUndef = -1000.f;
+template <bool OWNER>
+__global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
-                                                  int* __restrict__ keyCount, uint32_t* __restrict__ degbuf, const float* __restrict__ angDeg,
-                                                  uint32_t* __restrict__ owner)
+                                                  int* __restrict__ keyCount, uint32_t* __restrict__ owner, const float* __restrict__ angDeg,
+                                                  int nChunks, int total)
 {
     constexpr int SPAN = LG_CHUNK / 4;
-    __shared__ uint32_t s_keys[LG_CHUNK];
+    extern __shared__ float s_deg[];           // [LG_CHUNK + 2 * Ws + 2]
+    __shared__ uint16_t s_list[LG_CHUNK];      // the chunk's defined pixels (offset in the chunk), per wave quarter, raster order
     __shared__ int s_wcnt[4], s_base;
     const LineGeom& g = *gp;
-    const int img = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // XCD-aware numbering: blocks L, L + 8, L + 16, ... (one XCD) take consecutive (image, chunk) pairs
+    const int L = blockIdx.x, per = total >> 3;
+    const int V = L < per * 8 ? (L & 7) * per + (L >> 3) : L;
+    const int img = V / nChunks, chunk = V - img * nChunks;
+    const int Ws = g.Ws, Hs = g.Hs, Ps = g.Ps;
+    uint32_t* grad = gradAll + (size_t)img * Ps;
+    const int c0 = chunk * LG_CHUNK;
+    const int lo = max(0, c0 - Ws - 1), hi = min(Ps, c0 + LG_CHUNK + Ws + 1);
     if (threadIdx.x == 0) s_base = 0;
+    // (eight independent loads in flight per thread, then their eight table lookups: the pass is latency bound otherwise)
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 8 * 256) {
+        uint32_t p[8];
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = i0 + u * 256 < hi ? grad[i0 + u * 256] : kNotDef;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * 256 < hi) s_deg[i0 + u * 256 - lo] = d[u];
+    }
     __syncthreads();
     {   // keys of the chunks before this one
         int part = 0;
-        for (int c = threadIdx.x; c < (int)blockIdx.x; c += 256) part += chunkCnt[(size_t)img * gridDim.x + c];
+        for (int c = threadIdx.x; c < chunk; c += 256) part += chunkCnt[(size_t)img * nChunks + c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0 && part) atomicAdd(&s_base, part);
     }
+    {   // the defined pixels of this wave's quarter, compacted in raster order
+        int wc = 0;
+        for (int k = 0; k < SPAN / 64; ++k) {
+            const int li = wv * SPAN + k * 64 + lane;
+            const bool def = c0 + li < Ps && s_deg[c0 + li - lo] != kDegUndef;
+            const unsigned long long m = __ballot(def);
+            if (def) s_list[wv * SPAN + wc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+            wc += __popcll(m);
+        }
+        if (lane == 0) s_wcnt[wv] = wc;
+    }
+    __syncthreads();
+    const int n0 = s_wcnt[0], n1 = n0 + s_wcnt[1], n2 = n1 + s_wcnt[2], n3 = n2 + s_wcnt[3];
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
-    int wc = 0;
-#pragma unroll 4
-    for (int k = 0; k < SPAN / 64; ++k) {
-        const int idx = blockIdx.x * LG_CHUNK + wv * SPAN + k * 64 + lane;
-        bool def = false;
-        uint32_t key = 0;
-        if (idx < g.Ps) {
-            const uint32_t p = grad[(size_t)img * g.Ps + idx];
-            if (!(p & kNotDef)) {
-                const int gx = unpack_gx(p), gy = unpack_gy(p);
-                const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
-                const int bin = (int)(norm * bin_coef);
-                key = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
-                def = true;
-                // level-line angle (degrees) of the defined pixel, kept for k_lsd_iso in the (not yet used) FIFO buffer
-                degbuf[(size_t)img * g.Ps + idx] = __float_as_uint(angDeg[p & 0x3fffffu]);      // fastAtan2(gx, -gy), tabulated per context
-                owner[(size_t)img * g.Ps + idx] = 0xffffffffu;                                   // nobody has claimed the pixel (lsd_grow.hip)
-            }
+    uint32_t* kout = keys + (size_t)img * Ps + s_base;
+    // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
+    for (int t = threadIdx.x; t < n3; t += 256) {
+        const int w = (t >= n0) + (t >= n1) + (t >= n2);
+        const int li = s_list[w * SPAN + t - (w == 0 ? 0 : w == 1 ? n0 : w == 2 ? n1 : n2)];
+        const int idx = c0 + li;
+        const uint32_t p = grad[idx];
+        const int gx = unpack_gx(p), gy = unpack_gy(p);
+        const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+        const int bin = (int)(norm * bin_coef);
+        const int y = idx / Ws, x = idx - y * Ws;
+        const double a0 = d_mul((double)s_deg[idx - lo], kDegToRads);
+        bool iso = true;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (q == 4) continue;
+            const int dx = (q % 3) - 1, dy = (q / 3) - 1;
+            if (x + dx < 0 || x + dx >= Ws || y + dy < 0 || y + dy >= Hs) continue;
+            const float dn = s_deg[idx - lo + dy * Ws + dx];
+            if (dn == kDegUndef) continue;
+            double n_theta = d_sub(a0, d_mul((double)dn, kDegToRads));
+            if (n_theta < 0) n_theta = -n_theta;
+            if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
+            if (n_theta <= g.prec) iso = false;
         }
-        const unsigned long long m = __ballot(def);
-        if (def) s_keys[wv * SPAN + wc + __popcll(m & ((1ull << lane) - 1ull))] = key;
-        wc += __popcll(m);
+        if (iso) grad[idx] = p | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
+        if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
+        kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
     }
-    if (lane == 0) s_wcnt[wv] = wc;
-    __syncthreads();
-    int base = s_base;
-    for (int v = 0; v < wv; ++v) base += s_wcnt[v];
-    for (int i = lane; i < wc; i += 64) keys[(size_t)img * g.Ps + base + i] = s_keys[wv * SPAN + i];
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-}
-
-// A seed whose 8 neighbours are all undefined or not aligned with the seed's own angle can never grow: its region is
-// the seed alone (region_grow tests every neighbour against reg_angle == the seed angle and nothing is ever added), whatever
-// has been used before.  That is a static property of the gradient field; it is flagged here, in parallel, so that the
-// sequential agent can retire such seeds without running a growth step.
-__global__ __launch_bounds__(256) void k_lsd_iso(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
-                                                 const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
-                                                 const uint32_t* __restrict__ degbuf)
-{
-    const LineGeom& g = *gp;
-    const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;      // dense over the defined pixels (the key list)
-    if (i >= keyCount[img * 32]) return;
-    uint32_t* grad = gradAll + (size_t)img * g.Ps;
-    const uint32_t* deg = degbuf + (size_t)img * g.Ps;
-    const int idx = (int)(keysAll[(size_t)img * g.Ps + i] & 0x3fffffu);
-    const int y = idx / g.Ws, x = idx - y * g.Ws;
-    // all 16 neighbour loads (gradient word + angle) are issued before anything is tested: the kernel is latency bound, and the angle
-    // buffer is valid memory for every pixel (its value is simply unused where the pixel is undefined)
-    uint32_t nw[8], nd[8];
-    bool inb[8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        if (k == 4) continue;
-        const int q = k < 4 ? k : k - 1;
-        const int xx = x + (k % 3) - 1, yy = y + (k / 3) - 1;
-        inb[q] = xx >= 0 && yy >= 0 && xx < g.Ws && yy < g.Hs;
-        const int na = inb[q] ? yy * g.Ws + xx : idx;
-        nw[q] = grad[na];
-        nd[q] = deg[na];
-    }
-    const double a0 = d_mul((double)__uint_as_float(deg[idx]), kDegToRads);
-    bool iso = true;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        if (!inb[q] || (nw[q] & kNotDef)) continue;
-        const double a = d_mul((double)__uint_as_float(nd[q]), kDegToRads);
-        double n_theta = d_sub(a0, a);
-        if (n_theta < 0) n_theta = -n_theta;
-        if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
-        if (n_theta <= g.prec) iso = false;
-    }
-    if (iso) grad[idx] |= kIso;      // neighbours only read the NOTDEF bit of this word
+    if (chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
 
 // segment offsets for the sort; the batch is sorted in chunks of `per_chunk` images (32-bit key offsets inside a chunk)
@@ -805,6 +810,10 @@ size_t lsd_sort_temp_bytes(size_t total_keys, int n_segments)
     return bytes;
 }
 
+int lsd_grow_waves(int n_images);
+// the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
+static int lsd_grow_path(const LineDeviceBufs& b, int n_images) { return b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
+
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
     OLF_HIP_CHECK(hipMemsetAsync(b.maxN, 0, (size_t)n_images * 32 * sizeof(int), s));
@@ -820,9 +829,15 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }
     hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
-    hipLaunchKernelGGL(k_lsd_keys, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount,
-                       b.deg, b.angDeg, b.owner);
-    hipLaunchKernelGGL(k_lsd_iso, dim3((g.Ps + 255) / 256, n_images), dim3(256), 0, s, b.grad, b.geom, b.keysA, b.keyCount, b.deg);
+    {
+        const int nChunks = (g.Ps + LG_CHUNK - 1) / LG_CHUNK, total = nChunks * n_images;
+        const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
+        if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
+        if (lsd_grow_path(b, n_images) != 0)
+            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+        else
+            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+    }
     const int per_chunk = lsd_sort_chunk_images(g.Ps);
     hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, per_chunk, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
@@ -836,15 +851,13 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
 }
 
 int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s);
-int launch_lsd_grow_lanes(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 
 // waves per image of the multi-wave growth: as many as keep the chip full (8 waves per SIMD x 1024 SIMDs) without leaving a small batch
 // to a handful of waves; 0 selects the one-wave agent of round 1 (kept for A/B measurements, OLF_LSD_NW=0)
 int lsd_grow_waves(int n_images)
 {
     static int forced = -2;
-    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? atoi(e) : -1; if (forced == -2) forced = -3; }
-    if (forced == -3) return -2;
+    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? std::max(-1, std::min(16, atoi(e))) : -1; }
     if (forced >= 0) return forced;
     if (n_images <= 512) return 16;
     if (n_images <= 2048) return 8;
@@ -854,9 +867,8 @@ int lsd_grow_waves(int n_images)
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    const int nw = b.forceNW >= 0 || b.forceNW == -2 ? b.forceNW : lsd_grow_waves(n_images);
+    const int nw = lsd_grow_path(b, n_images);
     b.chained = nw != 0;
-    if (nw == -2) return launch_lsd_grow_lanes(g, b, n_images, s);       // one wave per image, one lane per region (lsd_grow_lanes.hip)
     if (nw > 0) {
         static int envE = -1;
         if (envE < 0) { const char* e = getenv("OLF_LSD_ROB"); envE = e ? atoi(e) : 0; }

@@ -12,7 +12,7 @@ for n in sizes:
     fe = ola.StereoFrontEnd(p, W, H, max_pairs=n)
     imgs = np.tile(base, ((n + 31) // 32, 1, 1))[:2 * n].copy()
     row = []
-    for nw in [int(x) for x in os.environ.get('OLF_SWEEP_NW', '0,-2,1,2,4,8,16').split(',')]:
+    for nw in [int(x) for x in os.environ.get('OLF_SWEEP_NW', '0,1,2,4,8,16').split(',')]:
         _lib.check(_lib.lib().olf_debug_lsd_waves(fe.ctx.handle, nw, 0), "olf_debug_lsd_waves")
         fe.frames(imgs)
         fe.ctx.profile(True)

@@ -3,7 +3,7 @@
 #   bash tools/variant_run.sh OLF_STATS 'python tools/prof_stats.py' [tail lines]
 R=/root/repo; C=$R/orb_line_slam_amd/csrc
 make -s -C $C -j8 2>&1 | grep -E "error" 
-mkdir -p /tmp/_prod; cp $C/liborbline_hip.so $C/lsd.o $C/lsd_grow.o $C/lsd_grow_lanes.o /tmp/_prod/
-( cd $C && for f in lsd lsd_grow lsd_grow_lanes; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$1 -x hip -c $f.hip -o $f.o 2>&1 | grep -E "error"; done; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liborbline_hip.so *.o )
+mkdir -p /tmp/_prod; cp $C/liborbline_hip.so $C/lsd.o $C/lsd_grow.o /tmp/_prod/
+( cd $C && for f in lsd lsd_grow; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$1 -x hip -c $f.hip -o $f.o 2>&1 | grep -E "error"; done; /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o liborbline_hip.so *.o )
 ( cd $R && timeout 1500 /usr/local/graft/bin/gpurun --timeout 600 -- "$2" 2>&1 | grep -v "^\[gpurun\] send" | tail -${3:-6} )
-cp /tmp/_prod/liborbline_hip.so /tmp/_prod/lsd.o /tmp/_prod/lsd_grow.o /tmp/_prod/lsd_grow_lanes.o $C/; touch $C/*.o $C/liborbline_hip.so
+cp /tmp/_prod/liborbline_hip.so /tmp/_prod/lsd.o /tmp/_prod/lsd_grow.o $C/; touch $C/*.o $C/liborbline_hip.so
