@@ -165,16 +165,17 @@ __global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll
     const int c0 = chunk * LG_CHUNK;
     const int lo = max(0, c0 - Ws - 1), hi = min(Ps, c0 + LG_CHUNK + Ws + 1);
     if (threadIdx.x == 0) s_base = 0;
-    // (eight independent loads in flight per thread, then their eight table lookups: the pass is latency bound otherwise)
-    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 8 * 256) {
-        uint32_t p[8];
-        float d[8];
+    // (NB independent loads in flight per thread, then their table lookups: the pass is latency bound otherwise)
+    constexpr int NB = 8;
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * 256) {
+        uint32_t p[NB];
+        float d[NB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = i0 + u * 256 < hi ? grad[i0 + u * 256] : kNotDef;
+        for (int u = 0; u < NB; ++u) p[u] = i0 + u * 256 < hi ? grad[i0 + u * 256] : kNotDef;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
+        for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u * 256 < hi) s_deg[i0 + u * 256 - lo] = d[u];
+        for (int u = 0; u < NB; ++u) if (i0 + u * 256 < hi) s_deg[i0 + u * 256 - lo] = d[u];
     }
     __syncthreads();
     {   // keys of the chunks before this one
@@ -367,7 +368,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const int Ws = g.Ws, Hs = g.Hs;
     uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
-    uint32_t* reg = regionAll + (size_t)img * g.Ps;
+    // the pixel log: (x | y << 16, gradient word) per pixel -- k_lsd_rect needs the gradient norm of every region pixel and reads it from here
+    // instead of gathering the word again
+    uint2* reg = reinterpret_cast<uint2*>(regionAll) + (size_t)img * g.Ps;
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec, precWrap = g.precWrap;
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             double reg_angle = rlane_d(seedAng, l);
             float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
             MARK_USED(seed, pseed);
-            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = pk; }
+            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = make_uint2(pk, pseed); }
             __builtin_amdgcn_wave_barrier();
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); t_seed += t1 - t0; t0 = t1; }
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
 #endif
                 bool cand = lane < 63 && e < nb && k != 4;
-                const uint32_t rp = (n - i > RING) ? reg[rbase + i + (cand ? e : 0)] : s_ring[(i + e) & (RING - 1)];
+                const uint32_t rp = (n - i > RING) ? reg[rbase + i + (cand ? e : 0)].x : s_ring[(i + e) & (RING - 1)];
                 const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                 cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
                 const int a = cand ? yy * Ws + xx : 0;
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
                         grad[a] = pw | kUsed;
                         s_ring[idx & (RING - 1)] = (uint32_t)xy;
-                        reg[rbase + idx] = (uint32_t)xy;
+                        reg[rbase + idx] = make_uint2((uint32_t)xy, pw);
                         s_pend[slot] = a;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -643,12 +646,13 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     if (r >= regCount[img]) return;
     const uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
-    const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : regionAll + (size_t)img * g.Ps + rr.start;
+    const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : nullptr;
+    const uint2* log2 = CHAINED ? nullptr : reinterpret_cast<const uint2*>(regionAll) + (size_t)img * g.Ps + rr.start;      // (pixel, gradient word) pairs of the one-wave agent
     const int* links = CHAINED ? linksAll + (size_t)img * nChunks : nullptr;
     const int n = rr.n, Ws = g.Ws;
     int cid = rr.start, nxt = -1;
     // U pixels of the list starting at position q0 (U divides the chunk size)
-#define RECT_BLOCK(q0) (CHAINED ? px_list + (size_t)cid * 32 + ((q0) & 31) : px_list + (q0))
+#define RECT_BLOCK(q0) (px_list + (size_t)cid * 32 + ((q0) & 31))
 #define RECT_STEP(q0) do { if (CHAINED) { if (((q0) & 31) == 0) { if (q0) cid = nxt; nxt = links[cid]; } } } while (0)
     // both passes are chains of dependent loads (pixel list -> gradient word); 8 pixels are fetched per step so that the loads of a
     // step are in flight together, the additions stay strictly in growth order
@@ -656,12 +660,17 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     double x = 0, y = 0, sum = 0;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U], p[U];
-        RECT_STEP(q0);
-        const uint32_t* blk = RECT_BLOCK(q0);
+        if (CHAINED) {
+            RECT_STEP(q0);
+            const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
+            for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+            for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint2 e = q0 + u < n ? log2[q0 + u] : make_uint2(0u, 0u); rp[u] = e.x; p[u] = e.y; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (q0 + u < n) {
@@ -679,12 +688,17 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     cid = rr.start;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U], p[U];
-        RECT_STEP(q0);
-        const uint32_t* blk = RECT_BLOCK(q0);
+        if (CHAINED) {
+            RECT_STEP(q0);
+            const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
+            for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+            for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint2 e = q0 + u < n ? log2[q0 + u] : make_uint2(0u, 0u); rp[u] = e.x; p[u] = e.y; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (q0 + u < n) {
@@ -716,10 +730,15 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
     cid = rr.start;
     for (int q0 = 0; q0 < n; q0 += U) {
         uint32_t rp[U];
-        RECT_STEP(q0);
-        const uint32_t* blk = RECT_BLOCK(q0);
+        if (CHAINED) {
+            RECT_STEP(q0);
+            const uint32_t* blk = RECT_BLOCK(q0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
+            for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? log2[q0 + u].x : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (q0 + u < n) {
