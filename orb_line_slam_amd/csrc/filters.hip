@@ -137,6 +137,59 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
     return OLF_OK;
 }
 
+// cv::GaussianBlur with 9 .. 15 taps (same fixed-point arithmetic as k_sep7: 8-bit tap fractions, 16-bit row sums, one rounding at the end,
+// BORDER_REFLECT_101): LSD's blur when it reduces the image a lot (lsd_scale < 0.74) -- no configuration of the reference does, so this is a
+// plain tiled kernel, not a tuned one.  64 x 16 output tile, row sums of the tile + radius rows above and below in LDS.
+struct TapsWide { int r; int t[15]; };
+__global__ __launch_bounds__(256) void k_sep_wide(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, uint8_t* __restrict__ dst,
+                                                  size_t dstImgStride, int dstPitch, int W, int H, TapsWide taps)
+{
+    constexpr int TW = 64, TH = 16, RMAX = 7;
+    __shared__ uint16_t s_h[TH + 2 * RMAX][TW];
+    const int r = taps.r, n = 2 * r + 1;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const uint8_t* in = src + (size_t)blockIdx.z * srcImgStride;
+    uint8_t* out = dst + (size_t)blockIdx.z * dstImgStride;
+    for (int i = threadIdx.x; i < (TH + 2 * r) * TW; i += 256) {
+        const int ry = i / TW, cx = i - ry * TW, x = x0 + cx;
+        int yy = y0 - r + ry;
+        if (yy < 0) yy = -yy;
+        if (yy >= H) yy = 2 * (H - 1) - yy;
+        int acc = 0;
+        if (x < W && yy >= 0 && yy < H) {
+            const uint8_t* row = in + (size_t)yy * srcPitch;
+            for (int k = 0; k < n; ++k) {
+                int xx = x + k - r;
+                if (xx < 0) xx = -xx;
+                if (xx >= W) xx = 2 * (W - 1) - xx;
+                acc += taps.t[k] * (int)row[xx];
+            }
+        }
+        s_h[ry][cx] = (uint16_t)acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ty = i / TW, cx = i - ty * TW, x = x0 + cx, y = y0 + ty;
+        if (x >= W || y >= H) continue;
+        int acc = 0;
+        for (int k = 0; k < n; ++k) acc += taps.t[k] * (int)s_h[ty + k][cx];
+        const int v = (acc + 32768) >> 16;
+        out[(size_t)y * dstPitch + x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+}
+
+int launch_sep_wide(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
+                    const int* taps, int r, int n_images, hipStream_t s)
+{
+    if (r < 1 || r > 7 || 2 * r >= W || 2 * r >= H) { set_error("launch_sep_wide: radius"); return OLF_ERR_INVALID; }
+    TapsWide t; t.r = r;
+    for (int i = 0; i < 15; ++i) t.t[i] = i < 2 * r + 1 ? taps[i] : 0;
+    hipLaunchKernelGGL(k_sep_wide, dim3((W + 63) / 64, (H + 15) / 16, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride,
+                       dstPitch, W, H, t);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // cv::resize(INTER_LINEAR) for 8UC1 with host-built coefficient tables, LDS tiled:
 // a block produces 256 x 8 output pixels; the source rows/columns it needs are staged once with word loads,

@@ -236,12 +236,15 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.nFeatures = p.lsd_nfeatures;
     g.outCap = p.lsd_nfeatures > 0 ? p.lsd_nfeatures : g.maxDetect;
     for (int i = 0; i < 7; ++i) { g.lsdTaps[i] = 0; g.lbdTaps[i] = 0; }
+    g.lsdWideR = 0;
+    for (int i = 0; i < 15; ++i) g.lsdWide[i] = 0;
     if (p.lsd_scale != 1) {
         const double sigma = (p.lsd_scale < 1) ? (p.lsd_sigma_scale / p.lsd_scale) : p.lsd_sigma_scale;
         const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
-        if (hk > 3) return OLF_ERR_INVALID;   // kernels wider than 7 taps are not implemented
+        if (hk > 7 || (int)(2 * hk) >= std::min(W, H)) return OLF_ERR_INVALID;   // kernels wider than 15 taps (lsd_scale < 0.32 at the default sigma) are not implemented
         std::vector<int> t = gaussian_taps_q8(1 + 2 * hk, sigma, p.conv_gauss_sum256);
-        for (unsigned i = 0; i < t.size(); ++i) g.lsdTaps[3 - hk + i] = t[i];
+        if (hk > 3) { g.lsdWideR = (int)hk; for (unsigned i = 0; i < t.size(); ++i) g.lsdWide[i] = t[i]; }      // the general kernel (k_sep_wide)
+        else for (unsigned i = 0; i < t.size(); ++i) g.lsdTaps[3 - hk + i] = t[i];
     } else g.lsdTaps[3] = 256;               // identity: cv::LineSegmentDetector skips blur+resize at scale 1
     {
         std::vector<int> t = gaussian_taps_q8(5, 1.0, p.conv_gauss_sum256);

@@ -34,6 +34,8 @@ struct LineGeom {
     int nFeatures;             // lsd_nfeatures (0 = keep all)
     int outCap;                // key lines returned per image
     int lsdTaps[7];            // sigma 0.6 (7x7)
+    int lsdWideR;              // > 3: LSD's blur is wider than 7 taps (lsd_scale < 0.74 or a large lsd_sigma_scale): radius, taps in lsdWide
+    int lsdWide[15];
     int lbdTaps[7];            // sigma 1 (5x5, zero padded to 7)
     float gaussCoefL[21];      // (float) of the reference's double weights
     float gaussCoefG[63];

@@ -28,6 +28,7 @@ __device__ __forceinline__ int refl101(int p, int n)
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
                       const LineGeom& g, int which, int n_images, hipStream_t s)
 {
+    if (!which && g.lsdWideR > 3) return launch_sep_wide(src, srcStride, srcPitch, dst, dstStride, dstPitch, W, H, g.lsdWide, g.lsdWideR, n_images, s);
     return launch_sep7(src, srcStride, srcPitch, dst, dstStride, dstPitch, W, H, which ? g.lbdTaps : g.lsdTaps, n_images, s);
 }
 

@@ -119,6 +119,8 @@ int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, 
 struct Taps7 { int t[7]; };
 int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
                 const int* taps7, int n_images, hipStream_t s);
+int launch_sep_wide(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
+                    const int* taps, int r, int n_images, hipStream_t s);
 
 bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int sh, int dw, int dh);
 int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,

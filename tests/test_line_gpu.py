@@ -204,6 +204,8 @@ def test_stereo_frames_odd_sizes(oracle, w, h):
     ((1500, 1.5, 4, 25, 10), dict(lsd_nfeatures=0, min_line_length=0.05, lsd_ang_th=20.0, lsd_n_bins=512)),      # keep all lines
     ((300, 1.1, 6, 12, 5), dict(lsd_nfeatures=80, lsd_scale=1.0, lsd_quant=1.5)),                                  # no LSD rescale
     ((800, 1.2, 8, 30, 15), dict(lsd_nfeatures=150, lsd_scale=0.8, lsd_sigma_scale=0.6, lsd_density_th=0.7)),       # OpenCV's default LSD scale
+    ((600, 1.2, 8, 20, 7), dict(lsd_nfeatures=100, lsd_scale=0.8, lsd_sigma_scale=0.75)),                           # 9-tap LSD blur (k_sep_wide)
+    ((600, 1.2, 8, 20, 7), dict(lsd_nfeatures=0, lsd_scale=0.5, lsd_sigma_scale=0.75, min_line_length=0.02)),       # 13-tap blur, half-size working image
 ])
 def test_stereo_frames_parameter_sets(oracle, orb, line):
     """non-default ORBextractor / Config parameters: other pyramid geometry, thresholds, LSD scale (incl. down-scaling) and bins"""
@@ -227,7 +229,7 @@ def test_stereo_frames_parameter_sets(oracle, orb, line):
         assert np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
         m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
         assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
-        assert len(ol["kls"]) > 20
+        assert len(ol["kls"]) > (20 if line.get("lsd_scale", 1.2) >= 0.8 else 5)
 
 
 def test_context_reuse_across_batches(oracle):
