@@ -49,6 +49,7 @@ struct olf_ctx {
     hipStream_t stream2 = nullptr;
     bool has_tables = false;       // holds a reference on the device's shared LSD angle tables
     bool mark_front = false;
+    bool wait_front_after_pyramid = false;      // fused entry: the ORB stream waits for the LSD front after its own pyramid (below)
     hipEvent_t ev_front = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
@@ -207,7 +208,6 @@ void olf_ctx_destroy(olf_ctx* c)
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
-    if (c->lb.sortTemp) (void)hipFree(c->lb.sortTemp);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -264,7 +264,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     LineDeviceBufs& l = c->lb;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
-    A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.segBegin, n); A(l.segEnd, n);
+    A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
     l.nChunks = 1024 + lg.Ps / 32 + 64;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     A(l.region, n * std::max((size_t)l.nChunks * 32, (size_t)2 * lg.Ps)); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
@@ -281,11 +281,6 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     }
 #undef A
     l.status = b.status;
-    {
-        const size_t chunk = std::min<size_t>(n, (size_t)lsd_sort_chunk_images(lg.Ps));
-        l.sortTempBytes = lsd_sort_temp_bytes(chunk * lg.Ps, (int)chunk);
-    }
-    if (hipMalloc(&l.sortTemp, std::max<size_t>(l.sortTempBytes, 256)) != hipSuccess) { set_error("hipMalloc(sort temp) failed"); return fail(OLF_ERR_HIP); }
     if (hipMemcpy(l.rx, c->line.rx.data(), c->line.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.ry, c->line.ry.data(), c->line.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.geom, &lg, sizeof(LineGeom), hipMemcpyHostToDevice) != hipSuccess) { set_error("line table upload failed"); return fail(OLF_ERR_HIP); }
@@ -383,6 +378,7 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
     const OrbGeom& g = c->orb.geom;
     c->last_n_images = n_images;
     { StageScope t(c, s, ST_ORB_PYRAMID); OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s)); }
+    if (c->wait_front_after_pyramid) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_FAST); OLF_TRY(launch_orb_fast(g, c->ob, n_images, s)); }
     { StageScope t(c, s, ST_ORB_OCTREE); OLF_TRY(launch_orb_octree(g, c->ob, n_images, s)); }
     { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
@@ -942,8 +938,11 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     OLF_TRY(rcl);
     OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
     OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
-    if (sched & 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
-    OLF_TRY(olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s));
+    if (sched == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    c->wait_front_after_pyramid = sched == 3;
+    const int rco = olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s);
+    c->wait_front_after_pyramid = false;
+    OLF_TRY(rco);
     OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     return OLF_OK;

@@ -53,8 +53,6 @@ struct LineDeviceBufs {
     int* keyCount = nullptr;       // [n] defined-pixel count
     int* maxN = nullptr;           // [n] max gx^2+gy^2 over defined pixels
     int* chunkCnt = nullptr;       // [n][ceil(Ps / 4096)] defined pixels per gradient chunk (raster-ordered key emission)
-    unsigned* segBegin = nullptr;  // [n] segment offsets for the sort
-    unsigned* segEnd = nullptr;
     uint32_t* region = nullptr;
     olf_keyline* rawLines = nullptr;
     int* rawCount = nullptr;
@@ -65,8 +63,8 @@ struct LineDeviceBufs {
     ResizeCoef* rx = nullptr;
     ResizeCoef* ry = nullptr;
     LineGeom* geom = nullptr;
-    void* sortTemp = nullptr;
-    size_t sortTempBytes = 0;
+    uint32_t* sortHist = nullptr;  // [n][ceil(Ps / 8192)][32] radix sort of the keys (lsd_sort.hip): per-chunk digit histograms -> prefixes
+    uint32_t* sortBase = nullptr;  // [n][32] where each digit value's bucket starts
     int* status = nullptr;
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
     void* angEnt = nullptr;        // [2^22] AngEnt (lsd_device.hpp): angle in radians, cos / sin as an added pixel, the sums a seed starts with -- 32 B
@@ -94,8 +92,7 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
                       const LineGeom& g, int which, int n_images, hipStream_t s);
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
-int lsd_sort_chunk_images(int Ps);
-size_t lsd_sort_temp_bytes(size_t total_keys, int n_segments);
+int lsd_sort_max_chunks(int Ps);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);
 int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_desc,

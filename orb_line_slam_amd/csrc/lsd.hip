@@ -13,7 +13,6 @@
 // Regions that are large enough are logged and fitted afterwards, in parallel, by k_lsd_rect / k_lsd_emit (region2rect + KeyLine).
 // Parallelism comes from the batch: thousands of images in flight, up to 8 agents per SIMD.
 #include "lsd_device.hpp"
-#include <rocprim/rocprim.hpp>
 
 namespace olf {
 
@@ -233,13 +232,6 @@ __global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll
     if (chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
 
-// segment offsets for the sort; the batch is sorted in chunks of `per_chunk` images (32-bit key offsets inside a chunk)
-__global__ void k_lsd_segs(const int* __restrict__ keyCount, int Ps, int n, int per_chunk, unsigned* __restrict__ b, unsigned* __restrict__ e)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { b[i] = (unsigned)(i % per_chunk) * (unsigned)Ps; e[i] = b[i] + (unsigned)keyCount[i * 32]; }
-}
-
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ double grad_angle(int gx, int gy) { return d_mul((double)dev_fastAtan2((float)gx, (float)(-gy)), kDegToRads); }
@@ -341,8 +333,6 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
-
-int lsd_sort_chunk_images(int Ps);
 
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 16 agents share a CU with other kernels)
 constexpr int PEND = 512;    // hash table of pixels whose USED store may not be visible to a load yet
@@ -819,16 +809,7 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
 }
 
 // ---------------------------------------------------------------------------------------------
-// images per sort call: the segmented sort addresses its keys with 32 bits
-int lsd_sort_chunk_images(int Ps) { return std::max(1, (int)(0xffffffffull / (unsigned long long)Ps) - 1); }
-
-size_t lsd_sort_temp_bytes(size_t total_keys, int n_segments)
-{
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_keys(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)total_keys,
-                                             (unsigned)n_segments, (unsigned*)nullptr, (unsigned*)nullptr, 22, 32, (hipStream_t)0);
-    return bytes;
-}
+int launch_lsd_sort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 
 int lsd_grow_waves(int n_images);
 // the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
@@ -854,19 +835,12 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
         if (lsd_grow_path(b, n_images) != 0)
-            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
         else
-            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
     }
-    const int per_chunk = lsd_sort_chunk_images(g.Ps);
-    hipLaunchKernelGGL(k_lsd_segs, dim3((n_images + 255) / 256), dim3(256), 0, s, b.keyCount, g.Ps, n_images, per_chunk, b.segBegin, b.segEnd);
     OLF_HIP_CHECK(hipGetLastError());
-    for (int i0 = 0; i0 < n_images; i0 += per_chunk) {
-        const int cnt = std::min(per_chunk, n_images - i0);
-        size_t tb = b.sortTempBytes;
-        OLF_HIP_CHECK(rocprim::segmented_radix_sort_keys(b.sortTemp, tb, b.keysA + (size_t)i0 * g.Ps, b.keysB + (size_t)i0 * g.Ps,
-                                                          (unsigned)((size_t)cnt * g.Ps), (unsigned)cnt, b.segBegin + i0, b.segEnd + i0, 22, 32, s));
-    }
+    { int rc = launch_lsd_sort(g, b, n_images, s); if (rc != OLF_OK) return rc; }
     return OLF_OK;
 }
 
