@@ -20,7 +20,7 @@ python $R/tools/timeline.py /tmp/ks > $O/${T}_timeline_two_streams.txt 2>&1
 rm -rf /tmp/ks1; OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /tmp/ks1.log 2>&1
 cp $(ls /tmp/ks1/*kernel_stats.csv | head -1) $O/${T}_bench_C3_one_stream_kernel_stats.csv
 rm -rf /tmp/pb
-OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
+OLF_LSD_NW=0 OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
 python $R/tools/pmc_budget.py /tmp/pb 1024 > $O/${T}_valu_budget_per_kernel.txt 2>&1
 OLF_ONE_STREAM=1 python $R/tools/grow_sweep.py 1 8 128 512 1024 2048 3072 > $O/${T}_grow_sweep.txt 2>&1
 python $R/tools/soak.py $SOAK > $O/${T}_soak.txt 2>&1; tail -2 $O/${T}_soak.txt

@@ -75,7 +75,10 @@ for it in range(N):
         g = fe.frames(imgs).pair(0)
     except _lib.OlfError as e:
         rejected += 1
-        reasons["at run time: " + str(e).split(": ")[-1][:70]] = reasons.get("at run time: " + str(e).split(": ")[-1][:70], 0) + 1
+        import re
+        m = re.search(r"flags=(\d+)", str(e))
+        why = {"8": "LSD region / raw segment / pixel-list capacity (pure noise at a large lsd_scale)"}.get(m.group(1), "flags=" + m.group(1)) if m else str(e)[-70:]
+        reasons["at run time: " + why] = reasons.get("at run time: " + why, 0) + 1
         print("rejected at run time", desc, "--", str(e)[:100], flush=True)
         continue
     o = oracle.stereo_points(imgs[0], imgs[1], p, cap=p.orb.nfeatures + 2064)
