@@ -228,7 +228,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     c->params = *p; c->W = width; c->H = height; c->max_images = max_images;
     int rc = c->orb.build(p->orb, width, height);
     if (rc != OLF_OK) {
-        set_error(rc == OLF_ERR_CAPACITY ? "olf_ctx_create: more than 2040 key points on one pyramid level (nfeatures too large for this scale factor / level count)"
+        set_error(rc == OLF_ERR_CAPACITY ? "olf_ctx_create: more than 32760 key points on one pyramid level (nfeatures too large for this scale factor / level count)"
                                          : "olf_ctx_create: image size / ORB parameters not supported (every pyramid level needs at least 62 x 62 pixels and a landscape cell grid)");
         delete c; return rc;
     }
@@ -242,6 +242,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(b.pyr, n * g.pyrBytes); A(b.blur, n * g.pyrBytes);
     A(b.cells, n * g.totalCells * g.cellCap); A(b.cellCount, n * g.totalCells);
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
+    if (g.maxNodes > 2048) A(b.octSpill, n * g.nlevels * octree_lds_bytes(g.maxNodes));
     A(b.lvlKp, n * g.kpTotal); A(b.lvlCount, n * g.nlevels); A(b.lvlAngle, n * g.kpTotal);
     A(b.rx, c->orb.rx.size() + 1); A(b.ry, c->orb.ry.size() + 1); A(b.geom, 1); A(b.status, 256);
     A(c->d_uright, ((n + 1) / 2) * g.outCap); A(c->d_depth, ((n + 1) / 2) * g.outCap); A(c->d_sad, ((n + 1) / 2) * g.outCap); A(c->d_bestkey, ((n + 1) / 2) * g.outCap); A(c->d_rowperm, n * g.outCap);

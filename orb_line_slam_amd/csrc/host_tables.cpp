@@ -190,8 +190,8 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
     while (mn < maxKp) mn <<= 1;
     g.maxNodes = mn;
     // k_octree keeps a level's node list in LDS (orb_octree.hip, octree_lds_bytes: 66 bytes per node + 16 KB): 2048 nodes fit the 160 KB,
-    // i.e. at most 2040 key points on one level
-    if (mn > 2048) return OLF_ERR_CAPACITY;
+    // i.e. up to 2040 key points on one level; larger levels spill the lists to global memory (node ids are 16-bit: at most 32768 nodes)
+    if (mn > 32768) return OLF_ERR_CAPACITY;
     return OLF_OK;
 }
 

@@ -105,12 +105,14 @@ struct OrbDeviceBufs {
     ResizeCoef* ry = nullptr;
     OrbGeom* geom = nullptr;      // device copy
     int* status = nullptr;        // device error flags (capacity overflow etc.)
+    unsigned char* octSpill = nullptr;   // [max_images][nlevels][octree_lds_bytes(maxNodes)] only when maxNodes > 2048 (orb_octree.hip)
 };
 
 // kernel launchers (orb_*.hip)
 int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* d_in, int n_images, hipStream_t s);
 int launch_orb_fast(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
 int launch_orb_octree(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
+size_t octree_lds_bytes(int M);
 int launch_orb_blur(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s);
 int launch_orb_describe(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, olf_keypoint* d_kps, uint8_t* d_desc,
                         int* d_counts, int out_cap, hipStream_t s);

@@ -57,12 +57,18 @@ __device__ __forceinline__ int quadrant(const NodeRec& n, int x, int y, int& hx,
     return (x < n.ulx + hx ? 0 : 1) + (y < n.uly + hy ? 0 : 2);
 }
 
+// SPILL: the working arrays of a level with more than 2048 nodes (more than 2040 key points on one level: nfeatures in the tens of
+// thousands) do not fit the 160 KB of LDS; that instance keeps them in a per-(image, level) slice of global memory instead -- same code, the
+// workgroup is on one CU, so __syncthreads() orders its global accesses like its LDS ones.  No reference configuration comes near it.
+template <bool SPILL>
 __global__ __launch_bounds__(256) void k_octree(const OrbGeom* __restrict__ gp, const uint32_t* __restrict__ cells,
                                                 const int* __restrict__ cellCount, uint32_t* __restrict__ cand,
                                                 uint16_t* __restrict__ candNode, int* __restrict__ candCount,
-                                                uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status)
+                                                uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
+                                                unsigned char* __restrict__ spill, size_t spillBytes)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char lds_smem[];
+    unsigned char* smem = SPILL ? spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * spillBytes : lds_smem;
     const OrbGeom& g = *gp;
     const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const LevelGeom& L = g.lv[level];
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbGeom* __restrict__ gp, 
             for (int i = tid; i < M; i += 256) {
                 uint32_t k = 0;
                 if (i < Lsz && curCnt[i] > 1) {
-                    k = ((uint32_t)min(curCnt[i], 0xfffff) << 12) | curSeq[i];
+                    k = ((uint32_t)min(curCnt[i], 0xffff) << 16) | curSeq[i];      // (a level holds at most 65535 candidates; creation indices < M <= 32768)
                     seqToNode[curSeq[i]] = (unsigned short)i;
                 }
                 sortKey[i] = k;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbGeom* __restrict__ gp, 
             __syncthreads();
             int cntE = 0;
             for (int i = tid; i < M; i += 256)
-                if (sortKey[i] != 0) { procNode[i] = seqToNode[sortKey[i] & 0xfff]; ++cntE; }
+                if (sortKey[i] != 0) { procNode[i] = seqToNode[sortKey[i] & 0xffff]; ++cntE; }
             atomicAdd(&sh[0], cntE);
             __syncthreads();
             E = sh[0];
@@ -318,11 +324,17 @@ size_t octree_lds_bytes(int M)
 int launch_orb_octree(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipStream_t s)
 {
     const size_t lds = octree_lds_bytes(g.maxNodes);
+    if (g.maxNodes > 2048) {
+        hipLaunchKernelGGL(k_octree<true>, dim3(g.nlevels, n_images), dim3(256), 0, s, b.geom, b.cells, b.cellCount, b.cand, b.candNode,
+                           b.candCount, b.lvlKp, b.lvlCount, b.status, b.octSpill, lds);
+        OLF_HIP_CHECK(hipGetLastError());
+        return OLF_OK;
+    }
     // the attribute belongs to the (function, device) pair: set it on whichever device this launch goes to
     if (lds > 64 * 1024)
-        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    hipLaunchKernelGGL(k_octree, dim3(g.nlevels, n_images), dim3(256), lds, s, b.geom, b.cells, b.cellCount, b.cand, b.candNode,
-                       b.candCount, b.lvlKp, b.lvlCount, b.status);
+        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    hipLaunchKernelGGL(k_octree<false>, dim3(g.nlevels, n_images), dim3(256), lds, s, b.geom, b.cells, b.cellCount, b.cand, b.candNode,
+                       b.candCount, b.lvlKp, b.lvlCount, b.status, nullptr, 0);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

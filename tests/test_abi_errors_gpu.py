@@ -23,11 +23,15 @@ def test_bad_arguments_are_reported():
     bad = _lib.default_params(); bad.orb.scale_factor = 1.0
     assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) != OLF_OK                                 # the pyramid needs a factor > 1
     bad = _lib.default_params(); bad.line.lsd_scale = 0.3
-    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) != OLF_OK                                 # LSD blur wider than 7 taps
-    bad = _lib.default_params(); bad.orb.nfeatures = 13000
-    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) == OLF_ERR_CAPACITY                       # > 2040 key points on level 0
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) != OLF_OK                                 # LSD blur wider than 15 taps
+    bad = _lib.default_params(); bad.orb.nfeatures = 13000                                                 # > 2040 key points on level 0: the octree spills to
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) == OLF_OK                                  # global memory (tests/test_orb_gpu.py)
+    L.olf_ctx_destroy(h)
+    bad = _lib.default_params(); bad.orb.nfeatures = 250000
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) == OLF_ERR_CAPACITY                       # > 32760 key points on level 0 (16-bit node ids)
     bad = _lib.default_params(); bad.orb.nfeatures = 2500; bad.orb.nlevels = 1
-    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) == OLF_ERR_CAPACITY
+    assert L.olf_ctx_create(C.byref(bad), 640, 480, 1, C.byref(h)) == OLF_OK                                  # (round 1 refused this: 2500 key points on one level)
+    L.olf_ctx_destroy(h)
     ctx = _lib.Context(p, 640, 480, 2)
     img = np.zeros((4, 480, 640), np.uint8)
     cap, lcap = ctx.orb_capacity, ctx.line_capacity

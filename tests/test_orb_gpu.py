@@ -74,3 +74,17 @@ def test_orb_noise_and_1080p(oracle):
     o = oracle.orb_extract(left, oracle.orb_params(4000), cap=5000)
     _compare(gk, gd, o["kps"], o["desc"])
     assert len(gk) >= 3900
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl", [(1242, 375, 4500, 2.0, 2), (640, 480, 9000, 1.5, 3)])
+def test_orb_levels_beyond_the_lds_octree(oracle, w, h, nf, sf, nl):
+    """more than 2040 key points on one pyramid level (few levels, a large nfeatures): the octree lists spill to global memory; noise so that
+    the quota is actually reached"""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[: h // 2] = synth.stereo_pair(3, w, h)[0][: h // 2]
+    ex = ola.ORBextractor(nf, sf, nl, 20, 7)
+    gk, gd = ex(img)
+    o = oracle.orb_extract(img, oracle.orb_params(nf, sf, nl, 20, 7), cap=nf + 4096)
+    _compare(gk, gd, o["kps"], o["desc"])
+    assert (np.bincount(gk["octave"], minlength=nl) > 2040).any()
