@@ -144,16 +144,17 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // the chunks of an image follow each other on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own): the
 // halo rows are then L2 hits.
 constexpr float kDegUndef = -1000.f;
+constexpr int KEYS_THREADS = 512;      // 8 waves share the 36 KB of LDS a chunk needs: 4 blocks = 32 waves per CU (256 threads: 14.9 ms per 6144 images, 512: 11.5, 1024: 15.5)
 template <bool OWNER>
-__global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
+__global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
                                                   int* __restrict__ keyCount, uint32_t* __restrict__ owner, const float* __restrict__ angDeg,
                                                   int nChunks, int total)
 {
-    constexpr int SPAN = LG_CHUNK / 4;
+    constexpr int NWV = KEYS_THREADS / 64, SPAN = LG_CHUNK / NWV;
     extern __shared__ float s_deg[];           // [LG_CHUNK + 2 * Ws + 2]
     __shared__ uint16_t s_list[LG_CHUNK];      // the chunk's defined pixels (offset in the chunk), per wave quarter, raster order
-    __shared__ int s_wcnt[4], s_base;
+    __shared__ int s_wcnt[NWV], s_base;
     const LineGeom& g = *gp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware numbering: blocks L, L + 8, L + 16, ... (one XCD) take consecutive (image, chunk) pairs
@@ -167,20 +168,20 @@ __global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll
     if (threadIdx.x == 0) s_base = 0;
     // (NB independent loads in flight per thread, then their table lookups: the pass is latency bound otherwise)
     constexpr int NB = 8;
-    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * 256) {
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * KEYS_THREADS) {
         uint32_t p[NB];
         float d[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) p[u] = i0 + u * 256 < hi ? grad[i0 + u * 256] : kNotDef;
+        for (int u = 0; u < NB; ++u) p[u] = i0 + u * KEYS_THREADS < hi ? grad[i0 + u * KEYS_THREADS] : kNotDef;
 #pragma unroll
         for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
 #pragma unroll
-        for (int u = 0; u < NB; ++u) if (i0 + u * 256 < hi) s_deg[i0 + u * 256 - lo] = d[u];
+        for (int u = 0; u < NB; ++u) if (i0 + u * KEYS_THREADS < hi) s_deg[i0 + u * KEYS_THREADS - lo] = d[u];
     }
     __syncthreads();
     {   // keys of the chunks before this one
         int part = 0;
-        for (int c = threadIdx.x; c < chunk; c += 256) part += chunkCnt[(size_t)img * nChunks + c];
+        for (int c = threadIdx.x; c < chunk; c += KEYS_THREADS) part += chunkCnt[(size_t)img * nChunks + c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0 && part) atomicAdd(&s_base, part);
@@ -197,14 +198,20 @@ __global__ __launch_bounds__(256) void k_lsd_keys(uint32_t* __restrict__ gradAll
         if (lane == 0) s_wcnt[wv] = wc;
     }
     __syncthreads();
-    const int n0 = s_wcnt[0], n1 = n0 + s_wcnt[1], n2 = n1 + s_wcnt[2], n3 = n2 + s_wcnt[3];
+    int nEnd[NWV];      // end of each wave's run in the dense order
+    { int acc = 0;
+#pragma unroll
+      for (int v = 0; v < NWV; ++v) { acc += s_wcnt[v]; nEnd[v] = acc; } }
+    const int n3 = nEnd[NWV - 1];
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
     // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
-    for (int t = threadIdx.x; t < n3; t += 256) {
-        const int w = (t >= n0) + (t >= n1) + (t >= n2);
-        const int li = s_list[w * SPAN + t - (w == 0 ? 0 : w == 1 ? n0 : w == 2 ? n1 : n2)];
+    for (int t = threadIdx.x; t < n3; t += KEYS_THREADS) {
+        int w = 0, before = 0;
+#pragma unroll
+        for (int v = 0; v < NWV - 1; ++v) if (t >= nEnd[v]) { w = v + 1; before = nEnd[v]; }
+        const int li = s_list[w * SPAN + t - before];
         const int idx = c0 + li;
         const uint32_t p = grad[idx];
         const int gx = unpack_gx(p), gy = unpack_gy(p);
@@ -835,9 +842,9 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
         if (lsd_grow_path(b, n_images) != 0)
-            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
         else
-            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(256), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
     }
     OLF_HIP_CHECK(hipGetLastError());
     { int rc = launch_lsd_sort(g, b, n_images, s); if (rc != OLF_OK) return rc; }
