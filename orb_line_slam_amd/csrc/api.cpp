@@ -269,7 +269,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     l.nChunks = 1024 + lg.Ps / 32 + 64;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     A(l.region, n * std::max((size_t)l.nChunks * 32, (size_t)2 * lg.Ps)); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
-    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.W * lg.H);
+    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
     {

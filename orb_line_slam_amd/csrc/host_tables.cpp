@@ -207,7 +207,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     if (p.conv_seed_order != 0) return OLF_ERR_INVALID;       // the std::sort seed order (convention C.9, variant 1) exists in the CPU oracle only
     if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
-    g.W = W; g.H = H; g.pitchW = (W + 63) & ~63;
+    g.W = W; g.H = H; g.pitchW = (W + 63) & ~63; g.pitchD = (W + 3) & ~3;
     g.scale = p.lsd_scale;
     g.Ws = cv_round_d(W * p.lsd_scale); g.Hs = cv_round_d(H * p.lsd_scale);
     g.pitchS = (g.Ws + 63) & ~63;

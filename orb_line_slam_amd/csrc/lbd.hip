@@ -65,41 +65,45 @@ __global__ __launch_bounds__(256) void k_line_select(const LineGeom* __restrict_
 // cv::Sobel(CV_16S, ksize 3, BORDER_REFLECT_101) of the sigma-1 blurred image, dx and dy packed
 __global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ blur, uint32_t* __restrict__ dxdy, const LineGeom* __restrict__ gp)
 {
-    // 4 pixels per thread: three rows x three aligned 32-bit words (the pixels' word and its two neighbours) instead of 32 byte loads;
-    // rows are pitch-padded to 64 bytes, so the word loads never leave the row.  BORDER_REFLECT_101 at the image frame (cv::Sobel).
+    // 8 pixels per thread: three rows x four aligned 32-bit words (the pixels' two words and one neighbour either side) instead of 48 byte loads,
+    // two 16-byte stores (the rows of dxdy are padded to a multiple of 4 pixels).  Input rows are pitch-padded to 64 bytes, so the word loads
+    // never leave the row.  BORDER_REFLECT_101 at the image frame (cv::Sobel).
     const LineGeom& g = *gp;
     const int img = blockIdx.y;
-    const int wq = (g.W + 3) >> 2;
+    const int wo = (g.W + 7) >> 3;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= wq * g.H) return;
-    const int y = t / wq, x0 = (t - y * wq) * 4;
+    if (t >= wo * g.H) return;
+    const int y = t / wo, x0 = (t - y * wo) * 8;
     const uint8_t* b = blur + (size_t)img * g.pitchW * g.H;
     const int ym = y == 0 ? 1 : y - 1, yp = y == g.H - 1 ? g.H - 2 : y + 1;
-    int v[3][6];            // rows (ym, y, yp) x columns x0-1 .. x0+4
+    int v[3][10];            // rows (ym, y, yp) x columns x0-1 .. x0+8
     const int rows[3] = {ym, y, yp};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const uint8_t* row = b + (size_t)rows[r] * g.pitchW;
         const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + x0);
-        const uint32_t w0 = x0 > 0 ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : 0u;
         const uint32_t w2 = x0 + 4 < g.pitchW ? *reinterpret_cast<const uint32_t*>(row + x0 + 4) : 0u;
+        const uint32_t w0 = x0 > 0 ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : 0u;
+        const uint32_t w3 = x0 + 8 < g.pitchW ? *reinterpret_cast<const uint32_t*>(row + x0 + 8) : 0u;
         v[r][0] = (int)(w0 >> 24);
-        v[r][1] = (int)(w1 & 0xffu); v[r][2] = (int)((w1 >> 8) & 0xffu); v[r][3] = (int)((w1 >> 16) & 0xffu); v[r][4] = (int)(w1 >> 24);
-        v[r][5] = (int)(w2 & 0xffu);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[r][1 + k] = (int)((w1 >> (8 * k)) & 0xffu); v[r][5 + k] = (int)((w2 >> (8 * k)) & 0xffu); }
+        v[r][9] = (int)(w3 & 0xffu);
         if (x0 == 0) v[r][0] = v[r][2];                                  // x = 0: x-1 -> 1
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 8; ++k)
             if (x0 + k == g.W - 1) v[r][k + 2] = v[r][k];                // x = W-1: x+1 -> W-2
     }
-    uint32_t* out = dxdy + (size_t)img * g.W * g.H + (size_t)y * g.W + x0;
+    uint32_t o[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (x0 + k < g.W) {
-            const int dx = (v[0][k + 2] - v[0][k]) + 2 * (v[1][k + 2] - v[1][k]) + (v[2][k + 2] - v[2][k]);
-            const int dy = (v[2][k] + 2 * v[2][k + 1] + v[2][k + 2]) - (v[0][k] + 2 * v[0][k + 1] + v[0][k + 2]);
-            out[k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
-        }
+    for (int k = 0; k < 8; ++k) {
+        const int dx = (v[0][k + 2] - v[0][k]) + 2 * (v[1][k + 2] - v[1][k]) + (v[2][k + 2] - v[2][k]);
+        const int dy = (v[2][k] + 2 * v[2][k + 1] + v[2][k + 2]) - (v[0][k] + 2 * v[0][k + 1] + v[0][k + 2]);
+        o[k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
     }
+    uint32_t* out = dxdy + (size_t)img * g.pitchD * g.H + (size_t)y * g.pitchD + x0;      // 16-byte aligned: pitchD and x0 are multiples of 4
+    if (x0 < g.pitchD) *reinterpret_cast<uint4*>(out) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (x0 + 4 < g.pitchD) *reinterpret_cast<uint4*>(out + 4) = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // one thread per (line, support-region row): the four weighted row sums of computeLBD (:1143-1196)
@@ -113,12 +117,13 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
     const int li = t / 63, hID = t - li * 63;
     if (li >= counts[img]) return;
     const olf_keyline kl = kls[(size_t)img * g.outCap + li];
-    const uint32_t* dxdy = dxdyAll + (size_t)img * g.W * g.H;
+    const uint32_t* dxdy = dxdyAll + (size_t)img * g.pitchD * g.H;
     const short heightOfLSP = 63;
     const short lengthOfLSP = (short)kl.numOfPixels;
     const short halfWidth = (short)((lengthOfLSP - 1) / 2);
     const short halfHeight = (short)((heightOfLSP - 1) / 2);
-    const short realWidth = (short)g.W, imageWidth = (short)(g.W - 1), imageHeight = (short)(g.H - 1);
+    const int realWidth = g.pitchD;      // row stride of the gradient image (the reference's realWidth, padded to a multiple of 4 pixels)
+    const short imageWidth = (short)(g.W - 1), imageHeight = (short)(g.H - 1);
     const float midX = (float)(0.5 * (double)f_add(kl.sPointInOctaveX, kl.ePointInOctaveX));
     const float midY = (float)(0.5 * (double)f_add(kl.sPointInOctaveY, kl.ePointInOctaveY));
     const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);   // convention C.6
@@ -269,7 +274,7 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
                        d_counts);
     // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel)
     OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
-    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 3) >> 2) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
                        reinterpret_cast<float4*>(b.rowSums));
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
@@ -283,7 +288,7 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
                     uint8_t* d_desc, const int* d_counts, hipStream_t s)
 {
     OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
-    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 3) >> 2) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
                        reinterpret_cast<float4*>(b.rowSums));
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),

@@ -33,6 +33,7 @@ struct LineGeom {
     int maxRegions;            // capacity of the per-image region log (a logged region owns >= minRegSize pixels of its own)
     int nFeatures;             // lsd_nfeatures (0 = keep all)
     int outCap;                // key lines returned per image
+    int pitchD;                // row stride of dxdy in pixels: W rounded up to a multiple of 4 (16-byte stores)
     int lsdTaps[7];            // sigma 0.6 (7x7)
     int lsdWideR;              // > 3: LSD's blur is wider than 7 taps (lsd_scale < 0.74 or a large lsd_sigma_scale): radius, taps in lsdWide
     int lsdWide[15];
