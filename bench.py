@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="stereo pairs per GPU per step (0: the configuration's default)")
     ap.add_argument("--distinct", type=int, default=512, help="distinct synthetic pairs per rank (tiled to --pairs)")
     ap.add_argument("--order", choices=("shuffled", "tiled"), default="shuffled", help="how the batch is drawn from the distinct pairs")
-    ap.add_argument("--scene", choices=("default", "long"), default="default", help="long: fewer, larger shapes -> key lines of about 0.08*W pixels (SURVEY App. D's model)")
+    ap.add_argument("--scene", choices=("default", "long", "bars"), default="default", help="long: fewer, larger shapes; bars: long thin bars -> key lines of about 0.08*W pixels (SURVEY App. D model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)

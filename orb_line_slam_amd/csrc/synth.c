@@ -122,6 +122,28 @@ static void make_scene(uint8_t* scene, int W, int H, uint64_t seed, int kind)
         }
         return;
     }
+    if (kind == 2) {
+        /* "bars": one long thin anti-aliased bar per cell of a jittered grid, nearly horizontal so that bars do not cross (a crossing cuts
+         * both edges), two long straight edges each: the 500 strongest segments then average close to 0.08 * W pixels -- the line length
+         * SURVEY App. D's byte model assumes for a KITTI frame -- and small blobs in the gaps between the bar rows feed the corner detector */
+        const int cw = W / 9, ch = 15;
+        for (int cy0 = ch / 2; cy0 + ch / 2 <= H; cy0 += ch)
+            for (int cx0 = ((cy0 / ch) & 1) * (cw / 2); cx0 < W; cx0 += cw) {
+                int cx = cx0 + cw / 2 + rng_range(&r, -6, 6), cy = cy0 + rng_range(&r, -1, 1);
+                int a = 64, b = rng_range(&r, -2, 2);
+                int hl = rng_range(&r, (cw * 36) / 100, (cw * 46) / 100), hw = 2;
+                int base = scene[(size_t)(cy < H ? cy : H - 1) * W + (cx < W ? cx : W - 1)];
+                int g = base > 128 ? rng_range(&r, 0, base - 70) : rng_range(&r, base + 70, 255);
+                paint_rect_aa(scene, W, H, cx, cy, a, b, hl, hw, g);
+                for (int q = 0; q < 3; ++q) {           /* blobs on the boundary between this row of cells and the next */
+                    int bx = cx0 + rng_range(&r, 0, cw - 1), by = cy0 + ch / 2 + rng_range(&r, -1, 0);
+                    int ba = rng_range(&r, -64, 64), bb = rng_range(&r, -64, 64);
+                    int bg = rng_range(&r, 0, 255);
+                    if (bx < W && by < H) paint_rect(scene, W, H, bx, by, ba, bb, rng_range(&r, 1, 2), rng_range(&r, 1, 2), bg);
+                }
+            }
+        return;
+    }
     for (int k = 0; k < K; ++k) {                       /* rotated rectangles */
         int cx = rng_range(&r, 0, W - 1), cy = rng_range(&r, 0, H - 1);
         int a = rng_range(&r, -64, 64), b = rng_range(&r, -64, 64);
@@ -157,7 +179,7 @@ static void add_noise(uint8_t* dst, const uint8_t* src, int n, rng_t* r)
 /* left/right: W*H bytes each, row-major, stride W.  Returns 0, or -1 on bad arguments. */
 int olf_synth_stereo_scene(uint64_t seed, int W, int H, int kind, uint8_t* left, uint8_t* right)
 {
-    if (W < 64 || H < 64 || !left || !right || kind < 0 || kind > 1) return -1;
+    if (W < 64 || H < 64 || !left || !right || kind < 0 || kind > 2) return -1;
     uint8_t* scene = (uint8_t*)malloc((size_t)W * H);
     uint8_t* shifted = (uint8_t*)malloc((size_t)W * H);
     if (!scene || !shifted) { free(scene); free(shifted); return -1; }

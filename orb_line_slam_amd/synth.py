@@ -23,7 +23,7 @@ def _lib():
     return _syn
 
 
-SCENES = {"default": 0, "long": 1}     # long: fewer, larger shapes -> segments of about 0.08 * W pixels (SURVEY App. D's model of a KITTI frame)
+SCENES = {"default": 0, "long": 1, "bars": 2}     # long: fewer, larger shapes -> segments of about 0.08 * W pixels (SURVEY App. D's model of a KITTI frame)
 
 
 def stereo_pair(seed, width, height, scene="default"):

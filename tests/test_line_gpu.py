@@ -311,3 +311,18 @@ def test_opencv_version_conventions(oracle, gauss256, exact):
     p.line.conv_seed_order = 1
     with pytest.raises(_lib.OlfError):
         ola.StereoFrontEnd(p, w, h, max_pairs=1)
+
+
+def test_line_extract_long_line_scene(oracle):
+    """the 'bars' synthetic scene (key lines of about 0.08 * W pixels, the length SURVEY App. D models for a KITTI frame): LBD support regions
+    three times longer than in the default scene, region2rect over regions of several hundred pixels"""
+    w, h = 1242, 375
+    p = oracle.full_params(2000, 500)
+    ex = ola.Lineextractor(500, 0.025)
+    left, right = synth.stereo_pair(5, w, h, scene="bars")
+    for img in (left, right):
+        gk, gd = ex(img)
+        o = oracle.line_extract(img, p.line)
+        _cmp_keylines(gk, o["kls"])
+        assert np.array_equal(gd, o["desc"])
+        assert gk["numOfPixels"].mean() > 90

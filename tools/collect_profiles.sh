@@ -13,7 +13,7 @@ cp $O/${T}_pmc_hbm_traffic.json $R/profiles/      # bench.py reads roofline.traf
 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_C3.json; cut -c1-160 $O/${T}_bench_C3.json
 OLF_ONE_STREAM=1 python $R/bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_one_stream.json
 for c in C2 C4 C5; do python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_$c.json; done
-python $R/bench.py --scene long --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_long_scene.json
+python $R/bench.py --scene bars --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_long_scene.json
 rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /tmp/ks.log 2>&1
 cp $(ls /tmp/ks/*kernel_stats.csv | head -1) $O/${T}_bench_C3_kernel_stats.csv
 python $R/tools/timeline.py /tmp/ks > $O/${T}_timeline_two_streams.txt 2>&1
