@@ -857,8 +857,7 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
 // to a handful of waves; 0 selects the one-wave agent of round 1 (kept for A/B measurements, OLF_LSD_NW=0)
 int lsd_grow_waves(int n_images)
 {
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("OLF_LSD_NW"); forced = e ? std::max(-1, std::min(16, atoi(e))) : -1; }
+    static const int forced = [] { const char* e = getenv("OLF_LSD_NW"); return e ? std::max(-1, std::min(16, atoi(e))) : -1; }();
     if (forced >= 0) return forced;
     if (n_images <= 512) return 16;
     if (n_images <= 2048) return 8;
@@ -871,8 +870,8 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     const int nw = lsd_grow_path(b, n_images);
     b.chained = nw != 0;
     if (nw > 0) {
-        static int envE = -1;
-        if (envE < 0) { const char* e = getenv("OLF_LSD_ROB"); envE = e ? atoi(e) : 0; }
+        // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
+        static const int envE = [] { const char* e = getenv("OLF_LSD_ROB"); const int v = e ? atoi(e) : 0; return (v == 128 || v == 256 || v == 512) ? v : 0; }();
         const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
         return launch_lsd_grow_mw(g, b, n_images, nw, E, s);
     }

@@ -600,8 +600,9 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
 int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s)
 {
     const size_t lds = lsd_grow_mw_lds_bytes(nw, E);
-    static bool attr_set = false;
-    if (!attr_set) { OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow_mw), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+    // at most 46 KB (16 waves, 512 entries): below the 64 KB a launch may ask for without a function attribute (which would have to be set per
+    // device -- a process-wide "already set" flag is wrong with several GPUs in one process)
+    if (lds > 64 * 1024) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
     hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                        reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E, b.nChunks);
     OLF_HIP_CHECK(hipGetLastError());
