@@ -83,6 +83,20 @@ int olf_remap_linear(olf_ctx* ctx, const uint8_t* src, int src_w, int src_h, con
  * median distance to the others (first minimum), -1 for an empty list.  Host buffers; at most 1024 observations per landmark. */
 int olf_distinctive_descriptors(olf_ctx* ctx, const uint8_t* desc, const int32_t* offs, int n_points, int32_t* best);
 
+/* ---- key-frame feature record of the binary map file -----------------------------------------
+ * void Map::SaveKeyFrame(ofstream &f, KeyFrame* kf), src/Map.cc:283-373 / KeyFrame* Map::LoadKeyFrame(ifstream &f, ...), :376-531,
+ * for the members the feature path produces: byte-exact what f.write((char*)&member, sizeof(member)) writes member by member.
+ * Host code (no device needed), like the reference's.  *_ids: NULL = no MapPoint / MapLine anywhere (ULONG_MAX is written). */
+size_t olf_kf_record_bytes(int n_keys, int n_lines);
+int olf_kf_record_pack(uint64_t frame_id, uint64_t kf_id, double timestamp, const float* t3, const float* quat4, int n_keys,
+                       const olf_keypoint* keys, const float* uright, const float* depth, const uint8_t* desc, const uint64_t* mappoint_ids,
+                       int n_lines, const olf_keyline* lines, const float* disparity2, const double* le3, const uint8_t* ldesc,
+                       const uint64_t* mapline_ids, uint8_t* out, size_t capacity, size_t* written);
+int olf_kf_record_counts(const uint8_t* buf, size_t len, int32_t* n_keys, int32_t* n_lines, size_t* record_bytes);
+int olf_kf_record_unpack(const uint8_t* buf, size_t len, uint64_t* frame_id, uint64_t* kf_id, double* timestamp, float* t3, float* quat4,
+                         olf_keypoint* keys, float* uright, float* depth, uint8_t* desc, uint64_t* mappoint_ids, olf_keyline* lines,
+                         float* disparity2, double* le3, uint8_t* ldesc, uint64_t* mapline_ids);
+
 /* ---- BoW transform: ORBVocabulary / LineVocabulary (include/ORBVocabulary.h:30-34) ----------
  * = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>; transform() is called by Frame::ComputeBoW (src/Frame.cc:585-597) and
  * KeyFrame::ComputeBoW (src/KeyFrame.cc:96-112) with levelsup = 4. */
