@@ -375,6 +375,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
     __builtin_amdgcn_wave_barrier();
     int nreg = 0, rbase = 0;
+    int flushEpoch = 0;        // number of PEND_FLUSHes so far: between two flushes every pixel this wave has marked USED is in s_pend
 #ifdef OLF_STATS
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
     long long st_mem = 0, st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #else
 #define ST_FLUSH
 #endif
-#define PEND_FLUSH() do { ST_FLUSH __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
+#define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
 #define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
                              if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __builtin_amdgcn_wave_barrier(); } while (0)
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         const int addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
         keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
         const uint32_t wseed = valid ? grad[addr] : kUsed;
+        int maskEpoch = flushEpoch;      // the window's USED bits as loaded here are complete up to this flush count
         const bool isoSeed = (wseed & kIso) != 0;
 #ifdef OLF_STATS
         ++st_win; st_seedl += __popcll(__ballot(valid)); st_isos += __popcll(__ballot(valid && isoSeed));
@@ -606,7 +608,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(__ballot(valid && lane > l));
 #endif
             if (n == 1) mask &= mask - 1;
-            else mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+            else if (maskEpoch == flushEpoch) {
+                // no flush since the window's words were loaded: whatever has been marked since is still in the pending table -- no need to
+                // gather the 64 (spatially random) seed words again
+                mask &= ~((2ull << l) - 1ull) & __ballot(s_pend[addr & (PEND - 1)] != addr);
+            } else {
+                mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+                maskEpoch = flushEpoch;
+            }
         }
     }
 #undef MARK_USED
