@@ -239,6 +239,15 @@ def test_keyframe_record_bytes(oracle):
     assert np.array_equal(rec["mvuRight"], ur) and np.array_equal(rec["mvDepth"], dp) and np.array_equal(rec["mDescriptors"], desc)
     empty = maprecord.pack_keyframe(0, 0, 0.0, [0, 0, 0], [0, 0, 0, 1], np.zeros(0, _lib.KEYPOINT_DTYPE), [], [], np.zeros((0, 32), np.uint8))
     assert len(empty) == 60 and maprecord.unpack_keyframe(empty)[1] == 60
+    # a truncated record is reported, not read past its end (Map::LoadKeyFrame would read garbage)
+    for cut in (10, 55, 60 + 71, len(got) - 1):
+        with pytest.raises(_lib.OlfError):
+            maprecord.unpack_keyframe(got[:cut])
+    # two records back to back, as in the map file
+    both = got + empty
+    r1, o1 = maprecord.unpack_keyframe(both)
+    r2, o2 = maprecord.unpack_keyframe(both, o1)
+    assert o1 == len(got) and o2 == len(both) and len(r2["mvKeys"]) == 0 and r1["mnId"] == 42
 
 
 def test_default_params_match_reference_config():
