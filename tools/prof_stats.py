@@ -6,6 +6,8 @@ n = 64
 os.environ['OLF_LSD_NW'] = '0'
 imgs = synth.stereo_batch(7000, 16, 1242, 375)
 imgs = np.tile(imgs, (n // 32 + 1, 1, 1))[:n].copy()
+if len(sys.argv) > 1 and sys.argv[1] == "bars":
+    imgs = np.tile(synth.stereo_batch(7000, 16, 1242, 375, scene="bars"), (n // 32 + 1, 1, 1))[:n].copy()
 if len(sys.argv) > 1 and sys.argv[1] == "tri":      # 40-pixel bands of one gradient direction: regions of thousands of pixels
     y, x = np.mgrid[0:375, 0:1242]
     imgs[:] = np.clip(np.abs((x % 48) - 24) * 10, 0, 255).astype(np.uint8)
