@@ -154,6 +154,9 @@ int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* ang
 /* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
  * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
+/* debug / tests: cap the 32-pixel chunk pool the multi-wave growth may use per image (0: all of it).  An image that exhausts the pool is grown
+ * again by the one-wave agent inside the same call -- the result does not change, only the time. */
+int olf_debug_lsd_pool(olf_ctx* ctx, int pool_chunks);
 /* debug/test: the LSD agent's unscaled exact float division against IEEE division on blocks*256*per_thread pseudo-random operand pairs
  * from its operand range; *mismatches = number of quotients that differ in any bit (must be 0). */
 int olf_debug_fdiv_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread, uint64_t* mismatches);
@@ -191,7 +194,10 @@ int olf_match_candidates(olf_ctx* ctx, const uint8_t* descQ, int nQ, const uint8
 /* ---- the per-frame ORBmatcher searches, complete (host candidate generation + GPU distances + the reference's resolution) ----
  * Plain view of the Frame / KeyFrame members these searches read (include/Frame.h:49-260, include/KeyFrame.h).  Pointers a search
  * does not read may be NULL.  mp_valid / mp_obs stand for `mvpMapPoints[i] != NULL` and `mvpMapPoints[i]->Observations() > 0`; the
- * searches that assign map points to the current frame update them in place, as the reference updates mvpMapPoints. */
+ * searches that assign map points to the current frame update them in place, as the reference updates mvpMapPoints.
+ * Constness: the entry points take `const olf_frame_view*` -- the VIEW (its pointers and counts) is never modified; mp_valid and mp_obs are
+ * deliberately pointers to non-const bytes, because for the current frame they are outputs (each function's comment names what it updates).
+ * Every other array is read-only. */
 typedef struct olf_frame_view {
     const olf_keypoint* keys;     /* mvKeysUn (= mvKeys for a rectified camera, src/Frame.cc:601-605)            */
     const uint8_t* desc;          /* mDescriptors [n][32]                                                        */

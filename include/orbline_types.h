@@ -101,7 +101,13 @@ typedef struct olf_stereo_params {
     int32_t best_lr_matches;    /* Config::bestLRMatches()                             */
 } olf_stereo_params;
 
+/* The parameter block of olf_ctx_create.  It must be initialised by olf_default_params(), which stamps abi_version and struct_size;
+ * olf_ctx_create refuses a block whose stamp differs from the library's (a caller built against an older header would otherwise hand over a
+ * shorter struct, and the conv_* fields would be read from whatever follows it). */
+#define OLF_ABI_VERSION 3u
 typedef struct olf_params {
+    uint32_t          abi_version;   /* OLF_ABI_VERSION of the header the caller was built with */
+    uint32_t          struct_size;   /* sizeof(olf_params) as the caller sees it               */
     olf_orb_params    orb;
     olf_line_params   line;
     olf_stereo_params stereo;

@@ -45,7 +45,7 @@ class StereoParams(C.Structure):
 
 
 class OlfParams(C.Structure):
-    _fields_ = [("orb", OrbParams), ("line", LineParams), ("stereo", StereoParams)]
+    _fields_ = [("abi_version", C.c_uint32), ("struct_size", C.c_uint32), ("orb", OrbParams), ("line", LineParams), ("stereo", StereoParams)]
 
 
 class FrameBuffers(C.Structure):
@@ -144,6 +144,7 @@ def lib():
         L.olf_cvt_gray.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.olf_remap_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.olf_debug_lsd_waves.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.olf_debug_lsd_pool.argtypes = [C.c_void_p, C.c_int]
         L.olf_frames_pack_bound.argtypes = [C.c_void_p, C.c_int]
         L.olf_frames_pack_bound.restype = C.c_size_t
         L.olf_frames_pack_dev.argtypes = [C.c_void_p, C.POINTER(FrameBuffers), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -190,6 +190,7 @@ int olf_default_params(olf_params* p)
 {
     if (!p) return OLF_ERR_INVALID;
     std::memset(p, 0, sizeof(*p));
+    p->abi_version = OLF_ABI_VERSION; p->struct_size = (uint32_t)sizeof(olf_params);
     p->orb.nfeatures = 2000; p->orb.scale_factor = 1.2f; p->orb.nlevels = 8; p->orb.ini_th_fast = 20; p->orb.min_th_fast = 7;
     p->line.lsd_nfeatures = 500; p->line.min_line_length = 0.025; p->line.lsd_refine = 0; p->line.lsd_scale = 1.2;
     p->line.lsd_sigma_scale = 0.6; p->line.lsd_quant = 2.0; p->line.lsd_ang_th = 22.5; p->line.lsd_log_eps = 1.0;
@@ -209,6 +210,7 @@ void olf_ctx_destroy(olf_ctx* c)
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_front) (void)hipEventDestroy(c->ev_front);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -219,6 +221,11 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
 {
     if (!p || !out || width < 64 || height < 64 || max_images < 1) { set_error("olf_ctx_create: bad argument"); return OLF_ERR_INVALID; }
     *out = nullptr;
+    if (p->abi_version != OLF_ABI_VERSION || p->struct_size != (uint32_t)sizeof(olf_params)) {
+        set_error("olf_ctx_create: the parameter block was not initialised by this library's olf_default_params() (abi_version / struct_size differ: "
+                  "caller built against another include/orbline_types.h)");
+        return OLF_ERR_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         set_error("olf_ctx_create: no HIP device visible (this library has no CPU path)");
@@ -266,10 +273,13 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
-    l.nChunks = 1024 + lg.Ps / 32 + 64;
+    // chunk pool of the multi-wave growth: every pixel in a list once (Ps / 32) plus one partly filled chunk per logged region and ROB slot;
+    // Ps / 16 chunks fill exactly the 2 * Ps words the one-wave agent's log needs anyway.  An image that still runs out is grown again by
+    // the one-wave agent (launch_lsd_grow)
+    l.nChunks = std::max(1024 + lg.Ps / 32 + 64, lg.Ps / 16);
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     A(l.region, n * std::max((size_t)l.nChunks * 32, (size_t)2 * lg.Ps)); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
-    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
+    A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
     {
@@ -494,6 +504,14 @@ int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
     }
     c->lb.forceNW = waves_per_image;
     c->lb.forceE = rob_entries;
+    return OLF_OK;
+}
+
+// debug / tests: cap the chunk pool of the multi-wave growth (0: the whole pool) so that the fall-back to the one-wave agent can be exercised
+int olf_debug_lsd_pool(olf_ctx* c, int pool_chunks)
+{
+    if (!c || pool_chunks < 0) { set_error("olf_debug_lsd_pool: bad argument"); return OLF_ERR_INVALID; }
+    c->lb.poolChunks = pool_chunks;
     return OLF_OK;
 }
 

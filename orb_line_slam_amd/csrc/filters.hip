@@ -137,7 +137,8 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
     return OLF_OK;
 }
 
-// cv::GaussianBlur with 9 .. 15 taps (same fixed-point arithmetic as k_sep7: 8-bit tap fractions, 16-bit row sums, one rounding at the end,
+// cv::GaussianBlur with 9 .. 15 taps (same fixed-point arithmetic as k_sep7: 8-bit tap fractions, one rounding at the end; the row sums are kept
+// in 32 bits because independently rounded taps wider than 7 can sum to 258 or 259 -- 259 * 255 no longer fits 16 bits, and the oracle's row pass is exact,
 // BORDER_REFLECT_101): LSD's blur when it reduces the image a lot (lsd_scale < 0.74) -- no configuration of the reference does, so this is a
 // plain tiled kernel, not a tuned one.  64 x 16 output tile, row sums of the tile + radius rows above and below in LDS.
 struct TapsWide { int r; int t[15]; };
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void k_sep_wide(const uint8_t* __restrict__ sr
                                                   size_t dstImgStride, int dstPitch, int W, int H, TapsWide taps)
 {
     constexpr int TW = 64, TH = 16, RMAX = 7;
-    __shared__ uint16_t s_h[TH + 2 * RMAX][TW];
+    __shared__ uint32_t s_h[TH + 2 * RMAX][TW];
     const int r = taps.r, n = 2 * r + 1;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const uint8_t* in = src + (size_t)blockIdx.z * srcImgStride;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void k_sep_wide(const uint8_t* __restrict__ sr
                 acc += taps.t[k] * (int)row[xx];
             }
         }
-        s_h[ry][cx] = (uint16_t)acc;
+        s_h[ry][cx] = (uint32_t)acc;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < TH * TW; i += 256) {

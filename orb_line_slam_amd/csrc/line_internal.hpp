@@ -72,6 +72,8 @@ struct LineDeviceBufs {
     uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
     int* links = nullptr;          // [n][nChunks] next chunk of a region's pixel list (-1: last)
     int nChunks = 0;               // 32-pixel chunks per image in `region` (ids < 1024: the ROB slots' own chunks, then the pool)
+    int* growFmt = nullptr;        // [n] after the multi-wave growth: 0 chunk chains, -1 given up (pool exhausted), 1 grown again by the one-wave agent (contiguous log)
+    int poolChunks = 0;            // olf_debug_lsd_pool: > 0 caps the chunk pool the multi-wave kernel may use (tests of the fall-back)
     int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
 };

@@ -358,12 +358,15 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
-                                                 int* __restrict__ status, const AngEnt* __restrict__ ent)
+                                                 int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
-        const LineGeom& g = *gp;
+    const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
+    // growFmt != nullptr: the launch behind the multi-wave kernel -- only the images that kernel gave up (-1) are grown here, and marked 1
+    // (= contiguous log) for k_lsd_rect_mixed
+    if (growFmt && growFmt[img] != -1) return;
     const int Ws = g.Ws, Hs = g.Hs;
     uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem;
         o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; }
 #endif
-    if (lane == 0) regCount[img] = nreg;
+    if (lane == 0) { regCount[img] = nreg; if (growFmt) growFmt[img] = 1; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,14 +647,10 @@ struct SegCand { float e0, e1, e2, e3, length; int keep; };
 
 // CHAINED: the pixel lists are chains of 32-pixel chunks (lsd_grow.hip; rr.start = first chunk id) instead of one contiguous log per image.
 template <bool CHAINED>
-__global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
-                                                  const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
-                                                  const int* __restrict__ regCount, SegCand* __restrict__ candAll,
-                                                  const int* __restrict__ linksAll, int nChunks)
+__device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int r, const uint32_t* __restrict__ gradAll,
+                                                const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
+                                                SegCand* __restrict__ candAll, const int* __restrict__ linksAll, int nChunks)
 {
-    const LineGeom& g = *gp;
-    const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= regCount[img]) return;
     const uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
     const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : nullptr;
@@ -778,6 +777,29 @@ __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ g
 #undef RECT_STEP
 }
 
+template <bool CHAINED>
+__global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
+                                                  const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
+                                                  const int* __restrict__ regCount, SegCand* __restrict__ candAll,
+                                                  const int* __restrict__ linksAll, int nChunks)
+{
+    const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= regCount[img]) return;
+    lsd_rect_region<CHAINED>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
+}
+
+// after the multi-wave growth: chunk chains, except for the images that kernel gave up and the one-wave agent grew again (growFmt 1)
+__global__ __launch_bounds__(256) void k_lsd_rect_mixed(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
+                                                        const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
+                                                        const int* __restrict__ regCount, SegCand* __restrict__ candAll,
+                                                        const int* __restrict__ linksAll, int nChunks, const int* __restrict__ growFmt)
+{
+    const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= regCount[img]) return;
+    if (growFmt[img] == 1) lsd_rect_region<false>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
+    else lsd_rect_region<true>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
+}
+
 // LSDDetectorC::detectImpl, Vec4f -> KeyLine (LSDDetector_custom.cpp:290-307): one workgroup per image, candidates in detection order,
 // ordered compaction of the ones that pass the length filter (class_id = position in the output).
 __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ gp, const SegCand* __restrict__ candAll, const int* __restrict__ regCount,
@@ -883,10 +905,17 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
         static const int envE = [] { const char* e = getenv("OLF_LSD_ROB"); const int v = e ? atoi(e) : 0; return (v == 128 || v == 256 || v == 512) ? v : 0; }();
         const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
-        return launch_lsd_grow_mw(g, b, n_images, nw, E, s);
+        const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, s);
+        if (rc != OLF_OK) return rc;
+        // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
+        // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once
+        hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt);
+        OLF_HIP_CHECK(hipGetLastError());
+        return OLF_OK;
     }
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt));
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
@@ -895,8 +924,8 @@ int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
 {
     // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
     if (b.chained)
-        hipLaunchKernelGGL(k_lsd_rect<true>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
-                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);
+        hipLaunchKernelGGL(k_lsd_rect_mixed, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
+                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks, b.growFmt);
     else
         hipLaunchKernelGGL(k_lsd_rect<false>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
                            reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);

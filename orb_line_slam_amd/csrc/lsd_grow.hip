@@ -26,9 +26,8 @@ constexpr int MW_SLOT_BITS = 10;
 constexpr uint32_t MW_FREE = 0xffffffffu;
 constexpr int MW_RING = 256;          // FIFO window of a growing region kept in LDS, per wave
 constexpr int MW_DIR = 128;           // chunk directory per wave (ordinal -> chunk id) for reading the FIFO from memory
-constexpr int MW_FREESTK = 256;
 enum { ST_EMPTY = 0, ST_READY = 1, ST_PARKED = 2, ST_GROWING = 3, ST_DONE = 4, ST_DEAD = 5 };
-enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_N };
+enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_FREEHEAD, C_N };
 
 #define WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -80,7 +79,7 @@ enum { PF_COMMIT = 0, PF_PICK, PF_DISPATCH, PF_PROLOGUE, PF_GATHER, PF_CHAIN, PF
 
 struct MwCtx {
     // LDS
-    int* ctl; int* freeStk;
+    int* ctl;
     int* eRank; int* eState; uint32_t* eBlock; uint32_t* eInval; int* eN; uint32_t* eSeed; double* eAng; float* eDeg; float* eSx; float* eSy;
     uint32_t* ring; int* dir;
     // global, per image
@@ -88,7 +87,8 @@ struct MwCtx {
     int E, mask, nkeys, nChunks, Ws, Hs, minRegSize, maxRegions, lane;
 };
 
-// chunk from the pool: never-used ones by a bump counter; recycled ones (LDS stack, filled only by regions that were given up) under a lock.
+// chunk from the pool: never-used ones by a bump counter; recycled ones (given back by regions that were given up) from a free list that is
+// threaded through links[] itself (head and count in LDS, under a lock), so recycling never loses a chunk however many are given back.
 // -1 when the pool is exhausted
 __device__ __forceinline__ int mw_alloc(const MwCtx& c)
 {
@@ -98,7 +98,11 @@ __device__ __forceinline__ int mw_alloc(const MwCtx& c)
         while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return -1; }
         if (c.lane == 0) {
             const int ft = WG_LOAD(c.ctl + C_FREETOP);
-            if (ft > 0) { id = WG_LOAD(c.freeStk + ft - 1); WG_STORE(c.ctl + C_FREETOP, ft - 1); }
+            if (ft > 0) {
+                id = WG_LOAD(c.ctl + C_FREEHEAD);
+                WG_STORE(c.ctl + C_FREEHEAD, AG_LOAD(c.links + id));
+                WG_STORE(c.ctl + C_FREETOP, ft - 1);
+            }
         }
         unlock(c.ctl + C_LOCKALLOC, c.lane);
         id = uni(id);
@@ -108,13 +112,16 @@ __device__ __forceinline__ int mw_alloc(const MwCtx& c)
     id = uni(id);
     return id < c.nChunks ? id : -1;
 }
+// (the caller has read links[id] -- the next chunk of the list it is walking -- before it gives `id` back)
 __device__ __forceinline__ void mw_free(const MwCtx& c, int id)
 {
     int spins = 0;
     while (!try_lock(c.ctl + C_LOCKALLOC, c.lane)) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 22)) return; }
     if (c.lane == 0) {
         const int ft = WG_LOAD(c.ctl + C_FREETOP);
-        if (ft < MW_FREESTK) { WG_STORE(c.freeStk + ft, id); WG_STORE(c.ctl + C_FREETOP, ft + 1); }   // else: leaked (counts against the pool)
+        AG_STORE(c.links + id, ft > 0 ? WG_LOAD(c.ctl + C_FREEHEAD) : -1);
+        WG_STORE(c.ctl + C_FREEHEAD, id);
+        WG_STORE(c.ctl + C_FREETOP, ft + 1);
     }
     unlock(c.ctl + C_LOCKALLOC, c.lane);
 }
@@ -173,7 +180,7 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
             big &= big - 1ull;
             const int sl = (h + l) & c.mask;
             const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
-            if (nc < 0) { if (c.lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); } break; }
+            if (nc < 0) { if (c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1); break; }       // pool or region log exhausted: the image is grown again by the one-wave agent
             // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
             if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)sl * 32 + c.lane);
             if (c.lane == 0) {
@@ -468,7 +475,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
                 new1 = mw_alloc(c);
                 if (lastOrd > curOrd + 1 && new1 >= 0) new2 = mw_alloc(c);
                 if (new1 < 0 || (lastOrd > curOrd + 1 && new2 < 0)) {
-                    if (lane == 0) { atomicOr(c.status, 8); WG_STORE(c.ctl + C_ABORT, 1); }
+                    if (lane == 0) WG_STORE(c.ctl + C_ABORT, 1);
                     n = n0; blocker = 0; fail = true; break;
                 }
                 if (lane == 0) {
@@ -521,14 +528,14 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
 
 size_t lsd_grow_mw_lds_bytes(int nw, int E)
 {
-    return (size_t)(C_N + 1 + MW_FREESTK) * 4 + (size_t)E * (9 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
+    return (size_t)(C_N + 1) * 4 + (size_t)E * (9 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
 }
 
 __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll, uint32_t* __restrict__ ownerAll,
                                                       const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
-                                                      const AngEnt* __restrict__ ent, int E, int nChunks)
+                                                      const AngEnt* __restrict__ ent, int E, int nChunks, int* __restrict__ growFmt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -538,7 +545,6 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         unsigned char* p = smem;
         c.eAng = reinterpret_cast<double*>(p); p += (size_t)E * 8;
         c.ctl = reinterpret_cast<int*>(p); p += (C_N + 1) * 4;
-        c.freeStk = reinterpret_cast<int*>(p); p += MW_FREESTK * 4;
         c.eRank = reinterpret_cast<int*>(p); p += (size_t)E * 4;
         c.eState = reinterpret_cast<int*>(p); p += (size_t)E * 4;
         c.eBlock = reinterpret_cast<uint32_t*>(p); p += (size_t)E * 4;
@@ -594,7 +600,9 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)pf_acc[q]);
 #endif
     __syncthreads();
-    if (threadIdx.x == 0) regCount[img] = c.ctl[C_ABORT] ? 0 : c.ctl[C_NREG];
+    // growFmt: 0 = this image's regions are chunk chains; -1 = given up (chunk pool or region log exhausted, or the idle guard): nothing of
+    // the image's gradient words was modified (claims live in the owner words), so k_lsd_grow replays it from the start (launch_lsd_grow)
+    if (threadIdx.x == 0) { const bool ab = c.ctl[C_ABORT] != 0; regCount[img] = ab ? 0 : c.ctl[C_NREG]; growFmt[img] = ab ? -1 : 0; }
 }
 
 int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s)
@@ -604,7 +612,8 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
     // device -- a process-wide "already set" flag is wrong with several GPUs in one process)
     if (lds > 64 * 1024) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
     hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E, b.nChunks);
+                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
+                       b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks, b.growFmt);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

@@ -34,6 +34,22 @@ def test_no_cpu_fallback_without_gpu():
         ola.StereoFrontEnd(None, 640, 480, 1)
 
 
+def test_params_block_must_come_from_default_params():
+    """olf_params carries abi_version + struct_size, stamped by olf_default_params and checked by olf_ctx_create before anything
+    else (also before the device check), so a block laid out by an older header is refused instead of being read past its end"""
+    import ctypes as C
+    from orb_line_slam_amd import _lib
+    L = _lib.lib()
+    p = _lib.default_params()
+    assert p.abi_version >= 3 and p.struct_size == C.sizeof(_lib.OlfParams)
+    ctx = C.c_void_p()
+    q = _lib.OlfParams()                                  # zero-initialised: no stamp
+    assert L.olf_ctx_create(C.byref(q), 640, 480, 1, C.byref(ctx)) == -1 and not ctx.value
+    assert b"olf_default_params" in L.olf_last_error()
+    p.struct_size -= 4                                    # a caller whose header lacks the last field
+    assert L.olf_ctx_create(C.byref(p), 640, 480, 1, C.byref(ctx)) == -1 and not ctx.value
+
+
 def test_record_layouts_match_the_reference_types():
     import orb_line_slam_amd as ola
     assert ola.KEYPOINT_DTYPE.itemsize == 28 and ola.KEYLINE_DTYPE.itemsize == 68

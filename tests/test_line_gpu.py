@@ -179,6 +179,26 @@ def test_line_extract_wide_growth_front(oracle):
     assert np.array_equal(d, o["desc"]) and len(k) > 0
 
 
+@pytest.mark.parametrize("scale", [0.65, 0.575])
+def test_lsd_wide_blur_saturated_regions(oracle, scale):
+    """lsd_scale 0.65 / 0.575 at sigma_scale 0.6: the 9-tap kernels' independently rounded 8-bit taps sum to 259 / 258, so the row sums of
+    a 255-valued area (259 * 255 = 66 045) do not fit 16 bits -- the wide blur keeps them in 32 bits like the oracle"""
+    w, h = 640, 360
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.where(((x // 80) + (y // 60)) % 2 == 0, 255, 40).astype(np.uint8)      # saturated plateaus with long straight edges
+    img[100:140, 200:420] = 255
+    p = oracle.full_params(500, 100)
+    p.line.lsd_scale = scale
+    ex = ola.Lineextractor(100, 0.025, lsd_scale=scale)
+    k, d = ex(img)
+    _, scaled = oracle.lsd_detect(img, p.line)
+    assert np.array_equal(ex.debug_scaled(), scaled), "LSD working image"
+    assert scaled.max() >= 250                                                        # bright areas stay bright
+    o = oracle.line_extract(img, p.line)
+    _cmp_keylines(k, o["kls"])
+    assert np.array_equal(d, o["desc"]) and len(k) > 0
+
+
 @pytest.mark.parametrize("w,h", [(333, 257), (1000, 300), (401, 243), (897, 601)])
 def test_stereo_frames_odd_sizes(oracle, w, h):
     """sizes that are multiples of nothing: tile edges, pitch padding, level geometry, cell grids with one column, tiny top levels"""

@@ -50,3 +50,25 @@ def test_growth_noise_and_flat_images(oracle):
             gk, gd = ex(img)
             o = oracle.line_extract(img, p.line)
             assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), waves
+
+
+def test_pool_exhaustion_falls_back_to_the_one_wave_agent(oracle):
+    """an image that exhausts the multi-wave kernel's chunk pool used to lose all its lines (OLF_ERR_CAPACITY).  With the pool capped
+    far below what the image needs, every image must come out identical to the oracle -- grown again by the one-wave agent in the same call --
+    and no capacity flag may be raised; a mixed batch (one image that fits the capped pool, three that do not) exercises k_lsd_rect_mixed."""
+    w, h = 640, 480
+    p = oracle.full_params(2000, 0)
+    imgs = synth.stereo_batch(71, 2, w, h)
+    imgs[3] = 90                                           # a flat image: no regions at all, stays on the chunk-chain path
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    ex = ola.Lineextractor(0, 0.025, max_images=4)
+    for waves, rob, pool in [(8, 256, 300), (16, 512, 600), (4, 128, 2000), (8, 256, 0)]:
+        _set(ex, w, h, 4, waves, rob)
+        _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, pool), "olf_debug_lsd_pool")
+        kls, desc, counts = ex.extract_batch(imgs)
+        assert (_status(ex)[0] & (8 | 16)) == 0, (waves, rob, pool)
+        for i in range(4):
+            n = int(counts[i])
+            assert n == len(want[i]["kls"]), (waves, pool, i, n, len(want[i]["kls"]))
+            assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (waves, pool, i)
+    _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, 0), "olf_debug_lsd_pool")
