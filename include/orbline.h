@@ -154,6 +154,11 @@ int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* ang
 /* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
  * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
+/* debug / tests: the kernel that replays libstdc++'s std::sort for the LSD seed order (convention C.9 variant 1, csrc/lsd_seedsort.hip) on a
+ * caller-supplied array of n <= Ws*Hs keys, (field << 22) | payload with a 10-bit field: out receives the keys whose field is <= kthr in the
+ * order std::sort(keys, keys + n, field ascending) leaves them; depth_limit < 0 = introsort's own 2 * floor(log2 n), a small value forces
+ * its heap-sort branch. */
+int olf_debug_seed_sort(olf_ctx* ctx, const uint32_t* keys, int n, int kthr, int depth_limit, uint32_t* out, int32_t* out_n);
 /* debug / tests: cap the 32-pixel chunk pool the multi-wave growth may use per image (0: all of it).  An image that exhausts the pool is grown
  * again by the one-wave agent inside the same call -- the result does not change, only the time. */
 int olf_debug_lsd_pool(olf_ctx* ctx, int pool_chunks);

@@ -417,6 +417,57 @@ using namespace orc;
 extern "C" {
 
 // raw LSD segments (x1,y1,x2,y2 floats) + optional scaled image (dims via sw/sh) + region sizes
+// std::sort itself on an array of keys ((field << 22) | payload), field ascending: what convention C.9 variant 1 means for a bin sequence.
+// The element type does not enter libstdc++'s algorithm (only comparisons and moves do), so a plain uint32_t array stands for the vector of
+// {Point, norm} that ll_angle sorts with compare_norm (norm descending <=> field ascending).
+void orc_std_sort_keys(const uint32_t* keys, int n, uint32_t* out)
+{
+    std::vector<uint32_t> v(keys, keys + n);
+    std::sort(v.begin(), v.end(), [](uint32_t a, uint32_t b) { return (a >> 22) < (b >> 22); });
+    std::memcpy(out, v.data(), (size_t)n * 4);
+}
+
+// The same sort with an explicit depth limit (libstdc++ bits/stl_algo.h restated: __introsort_loop with __move_median_to_first +
+// __unguarded_partition, std::partial_sort = the library's own heap sort when the limit is reached, __final_insertion_sort = a stable sort
+// of what the loop leaves).  With depth_limit = 2 * floor(log2 n) it must equal orc_std_sort_keys (tests/test_oracle_cpu.py checks that);
+// smaller limits reach the heap-sort branch that real images never reach.
+void orc_introsort_keys(const uint32_t* keys, int n, int depth_limit, uint32_t* out)
+{
+    std::vector<uint32_t> A(keys, keys + n);
+    auto K = [](uint32_t e) { return e >> 22; };
+    auto lt = [&](uint32_t a, uint32_t b) { return K(a) < K(b); };
+    struct R { int f, l, d; };
+    std::vector<R> stack;
+    if (n > 0) stack.push_back({0, n, depth_limit});
+    while (!stack.empty()) {
+        R r = stack.back(); stack.pop_back();
+        int first = r.f, last = r.l, depth = r.d;
+        while (last - first > 16) {
+            if (depth == 0) { std::partial_sort(A.begin() + first, A.begin() + last, A.begin() + last, lt); break; }
+            --depth;
+            const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+            if (lt(A[a], A[b])) { if (lt(A[b], A[c])) std::swap(A[first], A[b]); else if (lt(A[a], A[c])) std::swap(A[first], A[c]); else std::swap(A[first], A[a]); }
+            else if (lt(A[a], A[c])) std::swap(A[first], A[a]);
+            else if (lt(A[b], A[c])) std::swap(A[first], A[c]);
+            else std::swap(A[first], A[b]);
+            const uint32_t piv = A[first];
+            int i = first + 1, j = last;
+            for (;;) {
+                while (lt(A[i], piv)) ++i;
+                --j;
+                while (lt(piv, A[j])) --j;
+                if (!(i < j)) break;
+                std::swap(A[i], A[j]);
+                ++i;
+            }
+            stack.push_back({i, last, depth});
+            last = i;
+        }
+    }
+    std::stable_sort(A.begin(), A.end(), lt);
+    std::memcpy(out, A.data(), (size_t)n * 4);
+}
+
 int orc_lsd_detect(const uint8_t* img, int w, int h, const olf_line_params* P, float* segs, int cap, int* n, uint8_t* scaled, int* sw, int* sh)
 {
     Image im(w, h);

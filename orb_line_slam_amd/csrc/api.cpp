@@ -507,6 +507,23 @@ int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
     return OLF_OK;
 }
 
+// debug / tests: the std::sort seed-order kernel (lsd_seedsort.hip) on a caller-supplied key array ((field << 22) | payload, sorted by the
+// 10-bit field ascending exactly as libstdc++'s std::sort would leave it); kthr: only keys whose field is <= kthr are listed (-1: from the
+// image statistics -- not meaningful here, pass n_bins - 1 to list everything); depth_limit: introsort's depth limit (-1: 2 * floor(log2 n))
+int olf_debug_seed_sort(olf_ctx* c, const uint32_t* keys, int n, int kthr, int depth_limit, uint32_t* out, int32_t* out_n)
+{
+    if (!c || !keys || !out || !out_n || n < 0 || n > c->line.geom.Ps || kthr < 0 || kthr > 1023) { set_error("olf_debug_seed_sort: bad argument"); return OLF_ERR_INVALID; }
+    OLF_HIP_CHECK(hipMemcpyAsync(c->lb.keysA, keys, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_lsd_seedsort(c->line.geom, c->lb, 1, c->stream, n, kthr, depth_limit));
+    int cnt = 0;
+    OLF_HIP_CHECK(hipMemcpyAsync(&cnt, c->lb.keyCount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *out_n = cnt;
+    if (cnt < 0 || cnt > n) { set_error("olf_debug_seed_sort: count out of range"); return OLF_ERR_HIP; }
+    if (cnt) OLF_HIP_CHECK(hipMemcpy(out, c->lb.keysB, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    return OLF_OK;
+}
+
 // debug / tests: cap the chunk pool of the multi-wave growth (0: the whole pool) so that the fall-back to the one-wave agent can be exercised
 int olf_debug_lsd_pool(olf_ctx* c, int pool_chunks)
 {

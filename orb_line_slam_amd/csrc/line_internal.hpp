@@ -42,6 +42,7 @@ struct LineGeom {
     float gaussCoefG[63];
     int resizeTabX, resizeTabY;
     int resizeTiled;
+    int seedOrder;             // convention C.9: 0 raster order inside a gradient bin (stable radix sort), 1 libstdc++'s std::sort order (lsd_seedsort.hip)
     int resizeExact;           // convention C.10: the upsampling is cv::resize INTER_LINEAR_EXACT (8-bit coefficients in rx / ry)
 };
 
@@ -96,6 +97,7 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
+int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);
 int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_desc,

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
                 const int gx = DA + BC, gy = DA - BC;
                 const int nn = gx * gx + gy * gy;
                 if (nn >= g.nThr) { packed[p] = pack_g(gx, gy); n = max(n, nn); ++ndef; }
+                else packed[p] = pack_g(gx, gy) | kNotDef;      // undefined, but its bin is still needed by the std::sort seed order (lsd_seedsort.hip)
             }
         } else {
             int yy = y, xx = x;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
                     const int gx = DA + BC, gy = DA - BC;
                     const int nn = gx * gx + gy * gy;
                     if (nn >= g.nThr) { packed[p] = pack_g(gx, gy); n = max(n, nn); ++ndef; }
+                    else packed[p] = pack_g(gx, gy) | kNotDef;
                 }
             }
         }
@@ -145,7 +147,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // halo rows are then L2 hits.
 constexpr float kDegUndef = -1000.f;
 constexpr int KEYS_THREADS = 512;      // 8 waves share the 36 KB of LDS a chunk needs: 4 blocks = 32 waves per CU (256 threads: 14.9 ms per 6144 images, 512: 11.5, 1024: 15.5)
-template <bool OWNER>
+// ALLKEYS (convention C.9, variant 1 -- OpenCV >= 3.3): the key of EVERY pixel with x < Ws - 1, y < Hs - 1, defined or not, at its raster position
+// y * (Ws - 1) + x of `keys` -- the vector ll_angle hands to std::sort; lsd_seedsort.hip replays that sort and writes the seed list and its
+// length, so the compacted emission below is skipped.
+template <bool OWNER, bool ALLKEYS>
 __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
                                                   int* __restrict__ keyCount, uint32_t* __restrict__ owner, const float* __restrict__ angDeg,
@@ -206,6 +211,20 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
     const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
+    if (ALLKEYS) {
+        uint32_t* kall = keys + (size_t)img * Ps;
+        for (int li = threadIdx.x; li < LG_CHUNK && c0 + li < Ps; li += KEYS_THREADS) {
+            const int idx = c0 + li;
+            const int y = idx / Ws, x = idx - y * Ws;
+            if (x < Ws - 1 && y < Hs - 1) {
+                const uint32_t p = grad[idx];
+                const int gx = unpack_gx(p), gy = unpack_gy(p);
+                const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const int bin = (int)(norm * bin_coef);
+                kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+            }
+        }
+    }
     // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
     for (int t = threadIdx.x; t < n3; t += KEYS_THREADS) {
         int w = 0, before = 0;
@@ -234,9 +253,9 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         }
         if (iso) grad[idx] = p | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
-        kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+        if (!ALLKEYS) kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
     }
-    if (chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
+    if (!ALLKEYS && chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,7 +437,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
         ++st_win; st_seedl += __popcll(__ballot(valid)); st_isos += __popcll(__ballot(valid && isoSeed));
 #endif
-        unsigned long long mask = __ballot(valid && !(wseed & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+        // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; ll_angle's seed loop skips them)
+        unsigned long long mask = __ballot(valid && !(wseed & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
         // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
         // are per-(gx, gy) table entries
         double seedAng = 0;
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // gather the 64 (spatially random) seed words again
                 mask &= ~((2ull << l) - 1ull) & __ballot(s_pend[addr & (PEND - 1)] != addr);
             } else {
-                mask = __ballot(valid && lane > l && !(grad[addr] & kUsed) && s_pend[addr & (PEND - 1)] != addr);
+                mask = __ballot(valid && lane > l && !(grad[addr] & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
                 maskEpoch = flushEpoch;
             }
         }
@@ -849,6 +869,7 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
 
 // ---------------------------------------------------------------------------------------------
 int launch_lsd_sort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
+int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
 
 int lsd_grow_waves(int n_images);
 // the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
@@ -873,13 +894,19 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const int nChunks = (g.Ps + LG_CHUNK - 1) / LG_CHUNK, total = nChunks * n_images;
         const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
-        if (lsd_grow_path(b, n_images) != 0)
-            hipLaunchKernelGGL(k_lsd_keys<true>, dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
-        else
-            hipLaunchKernelGGL(k_lsd_keys<false>, dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+        const bool ow = lsd_grow_path(b, n_images) != 0;
+        if (g.seedOrder == 1) {
+            if (ow) hipLaunchKernelGGL((k_lsd_keys<true, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            else hipLaunchKernelGGL((k_lsd_keys<false, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+        } else {
+            if (ow) hipLaunchKernelGGL((k_lsd_keys<true, false>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            else hipLaunchKernelGGL((k_lsd_keys<false, false>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+        }
     }
     OLF_HIP_CHECK(hipGetLastError());
-    { int rc = launch_lsd_sort(g, b, n_images, s); if (rc != OLF_OK) return rc; }
+    // the seed order: bins high to low; inside a bin raster order (a stable radix sort of the defined pixels' keys) or libstdc++'s std::sort order
+    // over all pixels (convention C.9)
+    { int rc = g.seedOrder == 1 ? launch_lsd_seedsort(g, b, n_images, s, -1, -1, -1) : launch_lsd_sort(g, b, n_images, s); if (rc != OLF_OK) return rc; }
     return OLF_OK;
 }
 

@@ -231,7 +231,8 @@ __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, cons
     int s = 0;
     if (dn == dn0 && t - h <= c.E - 64) {
         const uint32_t wm = cl.wm;
-        const bool live = valid && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
+        // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; they are never seeds)
+        const bool live = valid && !(w & kNotDef) && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
         const unsigned long long m = __ballot(live);
         if (live) {
             s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;

@@ -123,12 +123,14 @@ class Lineextractor:
     11-argument LSD form.  bFLD=True returns nothing, exactly like the reference (src/LineExtractor.cc:68)."""
 
     def __init__(self, lsd_nfeatures, llength_th, lsd_refine=0, lsd_scale=1.2, lsd_sigma_scale=0.6, lsd_quant=2.0, lsd_ang_th=22.5,
-                 lsd_log_eps=1.0, lsd_density_th=0.6, lsd_n_bins=1024, bFLD=False, max_images=2, context=None):
+                 lsd_log_eps=1.0, lsd_density_th=0.6, lsd_n_bins=1024, bFLD=False, max_images=2, context=None, conv_seed_order=None):
         p = _lib.default_params()
         lp = p.line
         lp.lsd_nfeatures, lp.min_line_length, lp.lsd_refine = int(lsd_nfeatures), float(llength_th), int(lsd_refine)
         lp.lsd_scale, lp.lsd_sigma_scale, lp.lsd_quant, lp.lsd_ang_th = float(lsd_scale), float(lsd_sigma_scale), float(lsd_quant), float(lsd_ang_th)
         lp.lsd_log_eps, lp.lsd_density_th, lp.lsd_n_bins = float(lsd_log_eps), float(lsd_density_th), int(lsd_n_bins)
+        if conv_seed_order is not None:      # convention C.9 (include/orbline_types.h); None = the library's default
+            lp.conv_seed_order = int(conv_seed_order)
         self._params, self._max_images, self._ctx, self.bFLD = p, int(max_images), context, bool(bFLD)
 
     def _context(self, width, height, n_images):

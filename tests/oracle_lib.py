@@ -154,6 +154,22 @@ def lsd_detect(img, lp, cap=20000):
     return segs[:n.value].copy(), scaled[:sw.value * sh.value].reshape(sh.value, sw.value).copy()
 
 
+def std_sort_keys(keys):
+    """std::sort(keys, field ascending) -- the real library call"""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    out = np.empty_like(keys)
+    _L.orc_std_sort_keys(_p(keys), len(keys), _p(out))
+    return out
+
+
+def introsort_keys(keys, depth_limit):
+    """libstdc++'s introsort restated with an explicit depth limit (heap-sort branch = std::partial_sort)"""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    out = np.empty_like(keys)
+    _L.orc_introsort_keys(_p(keys), len(keys), int(depth_limit), _p(out))
+    return out
+
+
 def line_extract(img, lp, use_std_sort=False, cap=None, all_cap=20000):
     img = np.ascontiguousarray(img)
     h, w = img.shape

@@ -244,6 +244,24 @@ def test_lsd_seed_order_convention_exposure(oracle):
     assert 0.9 * tot < same < tot, (same, tot)
 
 
+def test_introsort_restatement_equals_std_sort(oracle):
+    """oracle/line_oracle.cpp orc_introsort_keys (libstdc++'s introsort written out, used to pin the GPU kernel's heap-sort branch under a forced
+    depth limit) against the real std::sort at the library's own limit 2 * floor(log2 n)"""
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 16, 17, 33, 100, 1000, 5000, 70001):
+        for nk in (1, 2, 7, 1024):
+            k = rng.integers(0, nk, n).astype(np.uint32)
+            keys = (k << 22) | np.arange(n, dtype=np.uint32)
+            want = oracle.std_sort_keys(keys)
+            lim = 2 * (int(n).bit_length() - 1) if n > 0 else 0
+            assert np.array_equal(oracle.introsort_keys(keys, lim), want), (n, nk)
+            assert np.array_equal(np.sort(want >> 22, kind="stable"), want >> 22)
+    # and the unstable order is really different from the stable one (otherwise the convention would not matter)
+    k = rng.integers(0, 4, 5000).astype(np.uint32)
+    keys = (k << 22) | np.arange(5000, dtype=np.uint32)
+    assert not np.array_equal(oracle.std_sort_keys(keys), keys[np.argsort(k, kind="stable")])
+
+
 def test_lsd_resize_convention_changes_only_the_working_image(oracle):
     """Convention C.10: INTER_LINEAR_EXACT differs from INTER_LINEAR by at most one grey level per pixel of LSD's working image."""
     left, _ = synth.stereo_pair(5, 320, 240)
