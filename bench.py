@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
+    ap.add_argument("--seed-order", type=int, choices=(0, 1), default=None, help="convention C.9: order of the LSD seeds inside a gradient bin (default: the library's)")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
     args = ap.parse_args()
 
@@ -190,6 +191,8 @@ def main():
     params = _lib.default_params()
     params.orb.nfeatures, params.line.lsd_nfeatures = cfg["nf"], cfg["nl"]
     params.stereo.fx, params.stereo.bf = cfg["fx"], cfg["bf"]
+    if args.seed_order is not None:
+        params.line.conv_seed_order = args.seed_order
     ctx = _lib.Context(params, W, H, 2 * B)
     cap, lcap = ctx.orb_capacity, ctx.line_capacity
 

@@ -28,14 +28,13 @@
 
 namespace olf {
 
-constexpr int SS_CAP = 1536;      // elements of a range held in LDS (6 KB: 24 waves = 24 images per CU)
-constexpr int SS_PF = 4;          // tiles in flight per side while a range streams from memory
+constexpr int SS_CAP = 1024;      // elements of a range held in LDS (4 KB + 2 KB of exchange arrays: 24 waves = 24 images per CU)
+constexpr int SS_NE_MEM = 4;      // tiles per block while a range streams from memory (exchange arrays + the two staged blocks: 4 x 256 words = the idle range buffer)
+constexpr int SS_NE_LDS = 4;      // ... while it is LDS resident (exchange arrays: 2 x 256 words behind the range buffer)
 
 struct SsCtx {
     uint32_t* A;          // the image's keys in memory; sorted in place
     uint32_t* sbuf;       // LDS copy of [ldsFirst, ldsLast)
-    uint32_t* xl;         // LDS, 64 words: stoppers of the left scan by rank
-    uint32_t* xr;         // ... of the right scan
     uint32_t* out;        // the seed list
     int ldsFirst;
     int lane;
@@ -46,114 +45,198 @@ template <bool LDS> __device__ __forceinline__ uint32_t ss_ld(const SsCtx& c, in
 template <bool LDS> __device__ __forceinline__ void ss_st(const SsCtx& c, int i, uint32_t v) { if (LDS) c.sbuf[i - c.ldsFirst] = v; else c.A[i] = v; }
 __device__ __forceinline__ int ss_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
-// The meeting zone of the two scans, inside one tile (values v, lane l <-> position base + l).  GE: the zone's elements >= pivot (stoppers of the
-// left scan, ranked from the left), LE: its elements <= pivot (stoppers of the right scan, ranked from the right).  Pair j swaps while
-// L[j] < R[j]; the partition's return value is min(L[s], R[s - 1]) after s swaps, or the end of the zone if neither exists.
-template <bool LDS>
-__device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t& v, int base, unsigned long long GE, unsigned long long LE, int zoneEndLane)
+// ---- the Hoare partition, NE x 64 elements per side and step -----------------------------------------------------------------------------
+// A block is NE tiles held in registers, slot u / lane l <-> position base + 64 u + l.  Its stoppers are ranked in scan order once when
+// the block is read (the left scan's: elements >= pivot by ascending position; the right scan's: elements <= pivot by descending position);
+// c? = stoppers of the block that have found their partner.  A step pairs min(nL - cL, nR - cR) pending stoppers by rank through the LDS
+// exchange arrays and stores the swapped values; the side that runs out of stoppers reads its next block.  Many independent element chains
+// per step is what a single wave needs: the 64-element version of this loop spent 870 cycles per tile on dependent latency.
+template <int NE> struct SsBlock {
+    uint32_t v[NE];
+    int rk[NE];           // rank of the element among the block's stoppers, -1: not a stopper
+    int base, n, c;       // position of slot 0 / lane 0; stoppers; stoppers consumed
+    int lim;              // left block: positions < lim are valid; right block: positions >= lim
+};
+
+// The meeting zone of the two scans lies inside the last block of the side that still has stoppers.  G: the zone's elements >= pivot with
+// rank jG from the left (jG < 0: not in G), LE: its elements <= pivot with rank jLE from the right.  Pair j swaps while L[j] < R[j]; the
+// partition's return value is min(L[s], R[s - 1]) after s swaps, or zoneEnd if neither exists.
+template <bool LDS, int NE>
+__device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t* XL, uint32_t* XR, SsBlock<NE>& B, const int* jG, int nG, const int* jLE, int nLE, int zoneEnd)
 {
     const int lane = c.lane;
-    const bool isG = (GE >> lane) & 1ull, isLE = (LE >> lane) & 1ull;
-    const int nG = __popcll(GE), nLE = __popcll(LE);
-    const int rg = ss_rank_below(GE);
-    const int rle = nLE - ss_rank_below(LE) - (isLE ? 1 : 0);
-    if (isG) c.xl[rg] = (uint32_t)lane;
-    if (isLE) c.xr[rle] = (uint32_t)lane;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int pos = B.base + 64 * u + lane;
+        if (jG[u] >= 0) XL[jG[u]] = (uint32_t)pos;
+        if (jLE[u] >= 0) XR[jLE[u]] = (uint32_t)pos;
+    }
     __builtin_amdgcn_wave_barrier();
-    int partner = lane;
-    bool swG = false, sw = false;
-    if (isG && rg < nLE) { const int p = (int)c.xr[rg]; if (lane < p) { partner = p; swG = sw = true; } }
-    if (isLE && rle < nG) { const int p = (int)c.xl[rle]; if (p < lane) { partner = p; sw = true; } }      // (an element equal to the pivot is in both sets but can only swap as one of them)
+    bool swG[NE], swLE[NE];
+    int s = 0;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int pos = B.base + 64 * u + lane;
+        swG[u] = false; swLE[u] = false;
+        if (jG[u] >= 0 && jG[u] < nLE) swG[u] = pos < (int)XR[jG[u]];
+        if (jLE[u] >= 0 && jLE[u] < nG) swLE[u] = (int)XL[jLE[u]] < pos;       // (an element equal to the pivot is in both sets but can only swap as one of them)
+        s += (int)__popcll(__ballot(swG[u]));
+    }
     __builtin_amdgcn_wave_barrier();
-    const int s = __popcll(__ballot(swG));
-    const uint32_t nv = (uint32_t)__shfl((int)v, partner);
-    if (sw) { v = nv; ss_st<LDS>(c, base + lane, nv); }
-    const unsigned long long cand = __ballot((isG && rg == s) || (isLE && s >= 1 && rle == s - 1));
-    return base + (cand ? (int)__builtin_ctzll(cand) : zoneEndLane);
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        if (swG[u]) XL[jG[u]] = B.v[u];
+        if (swLE[u]) XR[jLE[u]] = B.v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    int cut = zoneEnd;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int pos = B.base + 64 * u + lane;
+        if (swG[u]) { B.v[u] = XR[jG[u]]; ss_st<LDS>(c, pos, B.v[u]); }
+        if (swLE[u]) { B.v[u] = XL[jLE[u]]; ss_st<LDS>(c, pos, B.v[u]); }
+        const unsigned long long cand = __ballot(jG[u] == s || (s >= 1 && jLE[u] == s - 1));
+        if (cand) cut = min(cut, B.base + 64 * u + (int)__builtin_ctzll(cand));
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cut;
 }
 
-// std::__unguarded_partition(lo, hi, pivot) on [lo, hi) (= [first + 1, last)) with comp(a, b) = K(a) < K(b); returns the cut
-template <bool LDS>
-__device__ __forceinline__ int ss_partition(const SsCtx& c, int lo, int hi, uint32_t Kp)
+// std::__unguarded_partition(lo, hi, pivot) on [lo, hi) (= [first + 1, last)) with comp(a, b) = K(a) < K(b); returns the cut.
+// LDS: the range lives in c.sbuf (exchange arrays XL / XR behind it); otherwise it streams from memory, the blocks' NE loads in flight together,
+// swapped values stored straight back (exchange arrays in c.sbuf, which is free while no range is LDS resident).
+template <bool LDS, int NE>
+__device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32_t* XR, uint32_t* SL, uint32_t* SR, int lo, int hi, uint32_t Kp)
 {
     const int lane = c.lane;
     int lc = lo, rc = hi;                    // unread: [lc, rc)
-    uint32_t vL = 0, vR = 0;                 // the current tile of either side; lane l <-> position baseL + l / baseR + l
-    int baseL = 0, baseR = 0;
-    bool validL = false, validR = false;
-    unsigned long long LQ = 0, RQ = 0;       // stoppers of the current tiles that have not found a partner yet
-    uint32_t pl[SS_PF], pr[SS_PF];           // tiles on their way (memory path only): pl[u] = [lc + 64 u, ..), pr[u] = [rc - 64 (u + 1), ..)
-    if (!LDS) {
+    // memory path: the block after the current one is on its way into LDS (SL / SR, global_load_lds: no register, no compiler-placed wait --
+    // loads kept in registers ended up behind an s_waitcnt vmcnt(0) right after their issue).  pfL / pfR: the position it starts at, -1: none
+    int pfL = -1, pfR = -1;
+    SsBlock<NE> L, R;
+    L.n = L.c = R.n = R.c = 0; L.base = lo; R.base = hi; L.lim = lo; R.lim = hi;
 #pragma unroll
-        for (int u = 0; u < SS_PF; ++u) {
-            const int i = lo + 64 * u + lane, j = hi - 64 * (u + 1) + lane;
-            pl[u] = i < hi ? c.A[i] : 0u;
-            pr[u] = j >= lo ? c.A[j] : 0u;
-        }
-    }
+    for (int u = 0; u < NE; ++u) { L.v[u] = R.v[u] = 0u; L.rk[u] = R.rk[u] = -1; }
     for (;;) {
-        if (LQ == 0) {
+        if (L.c == L.n) {
             if (lc >= rc) break;
-            const int n = min(64, rc - lc);
-            validL = lane < n;
-            baseL = lc;
-            if (LDS) vL = validL ? c.sbuf[lc + lane - c.ldsFirst] : 0u;
-            else {
-                vL = pl[0];
+            const int n = min(64 * NE, rc - lc);
+            L.base = lc; L.lim = lc + n;
+            if (!LDS && pfL == lc) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int u = 0; u + 1 < SS_PF; ++u) pl[u] = pl[u + 1];
-                const int i = lc + 64 * SS_PF + lane;
-                pl[SS_PF - 1] = i < hi ? c.A[i] : 0u;
+                for (int u = 0; u < NE; ++u) L.v[u] = SL[64 * u + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staged block is in registers before the next one may overwrite it
+            } else {
+#pragma unroll
+                for (int u = 0; u < NE; ++u) { const int p = lc + 64 * u + lane; L.v[u] = p < L.lim ? ss_ld<LDS>(c, p) : 0u; }
             }
+            if (!LDS) {
+                pfL = -1;
+                if (lc + n < rc) {
+                    pfL = lc + n;
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) { const int p = pfL + 64 * u + lane; if (p < hi) __builtin_amdgcn_global_load_lds(c.A + p, SL + 64 * u, 4, 0, 0); }
+                }
+            }
+            int run = 0;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const bool st = lc + 64 * u + lane < L.lim && ssK(L.v[u]) >= Kp;
+                const unsigned long long m = __ballot(st);
+                L.rk[u] = st ? run + ss_rank_below(m) : -1;
+                run += (int)__popcll(m);
+            }
+            L.n = run; L.c = 0;
             lc += n;
-            LQ = __ballot(validL && ssK(vL) >= Kp);
         }
-        if (RQ == 0) {
+        if (R.c == R.n) {
             if (lc >= rc) break;
-            const int n = min(64, rc - lc);
-            validR = lane >= 64 - n;           // a short tile (the last one) fills the top lanes: lane l <-> position rc - 64 + l either way
-            baseR = rc - 64;
-            if (LDS) vR = validR ? c.sbuf[baseR + lane - c.ldsFirst] : 0u;
-            else {
-                vR = pr[0];
+            const int n = min(64 * NE, rc - lc);
+            R.base = rc - 64 * NE; R.lim = rc - n;      // a short block (the last one) fills the top slots
+            if (!LDS && pfR == R.base) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int u = 0; u + 1 < SS_PF; ++u) pr[u] = pr[u + 1];
-                const int j = rc - 64 * (SS_PF + 1) + lane;
-                pr[SS_PF - 1] = j >= lo ? c.A[j] : 0u;
+                for (int u = 0; u < NE; ++u) R.v[u] = SR[64 * u + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll
+                for (int u = 0; u < NE; ++u) { const int p = R.base + 64 * u + lane; R.v[u] = p >= R.lim ? ss_ld<LDS>(c, p) : 0u; }
             }
+            if (!LDS) {
+                pfR = -1;
+                if (lc < rc - n) {
+                    pfR = rc - n - 64 * NE;
+#pragma unroll
+                    for (int u = 0; u < NE; ++u) { const int p = pfR + 64 * u + lane; if (p >= lo) __builtin_amdgcn_global_load_lds(c.A + p, SR + 64 * u, 4, 0, 0); }
+                }
+            }
+            int run = 0;
+#pragma unroll
+            for (int u = NE - 1; u >= 0; --u) {
+                const bool st = R.base + 64 * u + lane >= R.lim && ssK(R.v[u]) <= Kp;
+                const unsigned long long m = __ballot(st);
+                const int cnt = (int)__popcll(m);
+                R.rk[u] = st ? run + cnt - 1 - ss_rank_below(m) : -1;
+                run += cnt;
+            }
+            R.n = run; R.c = 0;
             rc -= n;
-            RQ = __ballot(validR && ssK(vR) <= Kp);
         }
-        if (LQ != 0 && RQ != 0) {
-            // pair the pending stoppers by rank: the k-th from the left with the k-th from the right -- all of them lie on their own side of
-            // the unread part, so every pair swaps
-            const bool isL = (LQ >> lane) & 1ull, isR = (RQ >> lane) & 1ull;
-            const int nl = __popcll(LQ), nr = __popcll(RQ), k = min(nl, nr);
-            const int rl = ss_rank_below(LQ);
-            const int rr = nr - ss_rank_below(RQ) - (isR ? 1 : 0);
-            const bool goL = isL && rl < k, goR = isR && rr < k;
-            if (goL) c.xl[rl] = vL;
-            if (goR) c.xr[rr] = vR;
+        if (L.c < L.n && R.c < R.n) {
+            // pair the pending stoppers by rank: all of them lie on their own side of the unread part, so every pair swaps
+            const unsigned k = (unsigned)min(L.n - L.c, R.n - R.c);
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                if ((unsigned)(L.rk[u] - L.c) < k) XL[L.rk[u] - L.c] = L.v[u];
+                if ((unsigned)(R.rk[u] - R.c) < k) XR[R.rk[u] - R.c] = R.v[u];
+            }
             __builtin_amdgcn_wave_barrier();
-            if (goL) { vL = c.xr[rl]; ss_st<LDS>(c, baseL + lane, vL); }
-            if (goR) { vR = c.xl[rr]; ss_st<LDS>(c, baseR + lane, vR); }
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                if ((unsigned)(L.rk[u] - L.c) < k) { L.v[u] = XR[L.rk[u] - L.c]; ss_st<LDS>(c, L.base + 64 * u + lane, L.v[u]); }
+                if ((unsigned)(R.rk[u] - R.c) < k) { R.v[u] = XL[R.rk[u] - R.c]; ss_st<LDS>(c, R.base + 64 * u + lane, R.v[u]); }
+            }
             __builtin_amdgcn_wave_barrier();
-            LQ = __ballot(isL && rl >= k);
-            RQ = __ballot(isR && rr >= k);
+            L.c += (int)k; R.c += (int)k;
         }
     }
-    // everything has been read; at most one side still has stoppers, and they sit in that side's last tile
-    if (LQ != 0) {
-        // the right scan walks into the left side's last tile from above: the zone is [first pending stopper, end of that tile)
-        const int l0 = (int)__builtin_ctzll(LQ);
-        const unsigned long long LE = __ballot(validL && lane >= l0 && ssK(vL) <= Kp);
-        return ss_zone<LDS>(c, vL, baseL, LQ, LE, lc - baseL);
+    if (!LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no block may still be on its way into LDS when the buffers are reused
+    // everything has been read; at most one side still has stoppers, and they sit in that side's last block
+    if (L.c < L.n) {
+        // the right scan walks into the left side's last block from above: the zone is [first pending stopper, end of that block)
+        int l0 = lc;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) { const unsigned long long mm = __ballot(L.rk[u] == L.c); if (mm) l0 = L.base + 64 * u + (int)__builtin_ctzll(mm); }
+        int jG[NE], jLE[NE], run = 0;
+#pragma unroll
+        for (int u = NE - 1; u >= 0; --u) {
+            const int pos = L.base + 64 * u + lane;
+            const bool le = pos < L.lim && pos >= l0 && ssK(L.v[u]) <= Kp;
+            const unsigned long long m = __ballot(le);
+            const int cnt = (int)__popcll(m);
+            jLE[u] = le ? run + cnt - 1 - ss_rank_below(m) : -1;
+            run += cnt;
+            jG[u] = L.rk[u] >= L.c ? L.rk[u] - L.c : -1;
+        }
+        return ss_zone<LDS, NE>(c, XL, XR, L, jG, L.n - L.c, jLE, run, lc);
     }
-    if (RQ != 0) {
-        // the left scan walks into the right side's last tile from below: the zone is [start of that tile, last pending stopper]
-        const int r0 = 63 - (int)__builtin_clzll(RQ);
-        const unsigned long long GE = __ballot(validR && lane <= r0 && ssK(vR) >= Kp);
-        return ss_zone<LDS>(c, vR, baseR, GE, RQ, r0 + 1);
+    if (R.c < R.n) {
+        // the left scan walks into the right side's last block from below: the zone is [start of that block, last pending stopper]
+        int r0 = rc;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) { const unsigned long long mm = __ballot(R.rk[u] == R.c); if (mm) r0 = R.base + 64 * u + (int)__builtin_ctzll(mm); }
+        int jG[NE], jLE[NE], run = 0;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int pos = R.base + 64 * u + lane;
+            const bool ge = pos >= R.lim && pos <= r0 && ssK(R.v[u]) >= Kp;
+            const unsigned long long m = __ballot(ge);
+            jG[u] = ge ? run + ss_rank_below(m) : -1;
+            run += (int)__popcll(m);
+            jLE[u] = R.rk[u] >= R.c ? R.rk[u] - R.c : -1;
+        }
+        return ss_zone<LDS, NE>(c, XL, XR, R, jG, run, jLE, R.n - R.c, r0 + 1);
     }
     return lc;
 }
@@ -269,17 +352,31 @@ __device__ __forceinline__ int ss_emit_sorted(const SsCtx& c, int first, int las
     return outPos + cnt;
 }
 
+// -DOLF_SS_PROF: cycles and counts per phase of image 0 into status[16..] (tools/prof_seedsort.py)
+#ifdef OLF_SS_PROF
+enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OTHER, SP_N_PART_MEM, SP_N_PART_LDS, SP_N_EQUAL, SP_N_LEAF, SP_N_LOAD, SP_V_PART_MEM, SP_V_PART_LDS, SP_V_EQUAL, SP_N };
+#define SSPROF(i) do { const long long _t = __builtin_readcyclecounter(); sp_acc[i] += _t - sp_t; sp_t = _t; } while (0)
+#define SSCNT(i, v) (sp_acc[i] += (v))
+#else
+#define SSPROF(i)
+#define SSCNT(i, v)
+#endif
+
 __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
-                                                     const int* __restrict__ maxN, int nOverride, int kthrOverride, int depthOverride)
+                                                     const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
 {
+#ifdef OLF_SS_PROF
+    long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
+#endif
     __shared__ uint32_t s_buf[SS_CAP];
-    __shared__ uint32_t s_xl[64], s_xr[64];
+    __shared__ uint32_t s_x[2 * 64 * SS_NE_LDS];
+    static_assert(4 * 64 * SS_NE_MEM <= SS_CAP, "the memory path's exchange arrays and staged blocks live in the range buffer");
     const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     SsCtx c;
     c.A = keysInAll + (size_t)img * g.Ps;
     c.out = keysOutAll + (size_t)img * g.Ps;
-    c.sbuf = s_buf; c.xl = s_xl; c.xr = s_xr; c.ldsFirst = 0; c.lane = lane;
+    c.sbuf = s_buf; c.ldsFirst = 0; c.lane = lane;
     const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
     uint32_t Kthr;
     if (kthrOverride >= 0) Kthr = (uint32_t)kthrOverride;
@@ -312,8 +409,9 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
         for (;;) {
             const int m = last - first;
             if (lb > Kthr) break;                                     // only undefined pixels: never seeds, never leave the range
-            if (m <= 16) { outPos = inLDS ? ss_emit_leaf<true>(c, first, last, Kthr, outPos) : ss_emit_leaf<false>(c, first, last, Kthr, outPos); break; }
-            if (lb == ub && ss_equal_levels(m) <= depth) { outPos = inLDS ? ss_emit_equal<true>(c, first, last, outPos) : ss_emit_equal<false>(c, first, last, outPos); break; }
+            SSPROF(SP_OTHER);
+            if (m <= 16) { outPos = inLDS ? ss_emit_leaf<true>(c, first, last, Kthr, outPos) : ss_emit_leaf<false>(c, first, last, Kthr, outPos); SSPROF(SP_LEAF); SSCNT(SP_N_LEAF, 1); break; }
+            if (lb == ub && ss_equal_levels(m) <= depth) { outPos = inLDS ? ss_emit_equal<true>(c, first, last, outPos) : ss_emit_equal<false>(c, first, last, outPos); SSPROF(SP_EQUAL); SSCNT(SP_N_EQUAL, 1); SSCNT(SP_V_EQUAL, m); break; }
             if (depth == 0) {
                 if (lane == 0) { if (inLDS) ss_heapsort<true>(c, first, last); else ss_heapsort<false>(c, first, last); }
                 __builtin_amdgcn_wave_barrier();
@@ -330,6 +428,7 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
                 }
                 __builtin_amdgcn_wave_barrier();
                 inLDS = true; c.ldsFirst = first; ldsLast = last;
+                SSPROF(SP_LOAD); SSCNT(SP_N_LOAD, 1);
             }
             --depth;
             // __move_median_to_first(first, first + 1, mid, last - 1)
@@ -351,18 +450,28 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t Kp = ssK(es);
-            const int cut = inLDS ? ss_partition<true>(c, first + 1, last, Kp) : ss_partition<false>(c, first + 1, last, Kp);
+            SSPROF(SP_PIVOT);
+            int cut;
+            if (!inLDS) cut = ss_partition<false, SS_NE_MEM>(c, s_buf, s_buf + 64 * SS_NE_MEM, s_buf + 128 * SS_NE_MEM, s_buf + 192 * SS_NE_MEM, first + 1, last, Kp);
+            else if (m <= 65) cut = ss_partition<true, 1>(c, s_x, s_x + 64, nullptr, nullptr, first + 1, last, Kp);       // small ranges: no work on empty slots
+            else if (m <= 129) cut = ss_partition<true, 2>(c, s_x, s_x + 128, nullptr, nullptr, first + 1, last, Kp);
+            else cut = ss_partition<true, SS_NE_LDS>(c, s_x, s_x + 64 * SS_NE_LDS, nullptr, nullptr, first + 1, last, Kp);
+            if (inLDS) { SSPROF(SP_PART_LDS); SSCNT(SP_N_PART_LDS, 1); SSCNT(SP_V_PART_LDS, m); } else { SSPROF(SP_PART_MEM); SSCNT(SP_N_PART_MEM, 1); SSCNT(SP_V_PART_MEM, m); }
             SS_PUSH(cut, last, depth, max(lb, Kp), ub);               // [cut, last): K >= Kp
             last = cut; ub = min(ub, Kp);                             // [first, cut): K <= Kp (the pivot sits at first)
         }
     }
 #undef SS_PUSH
+#ifdef OLF_SS_PROF
+    SSPROF(SP_OTHER);
+    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); for (int q = 0; q < SP_N; ++q) o[q] = sp_acc[q]; }
+#endif
     if (lane == 0) keyCount[img * 32] = outPos;
 }
 
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
-    hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, nOverride, kthrOverride, depthOverride);
+    hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

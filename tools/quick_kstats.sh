@@ -2,7 +2,7 @@
 # per-kernel times of one one-stream bench step: bash tools/quick_kstats.sh [rows]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/ks1; OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /tmp/ks1.log 2>&1
+rm -rf /tmp/ks1; OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 $KS_ARGS > /tmp/ks1.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/ks1/*kernel_stats.csv')[0]
