@@ -29,8 +29,8 @@
 namespace olf {
 
 constexpr int SS_CAP = 1024;      // elements of a range held in LDS (4 KB + 2 KB of exchange arrays: 24 waves = 24 images per CU)
-constexpr int SS_NE_MEM = 4;      // tiles per block while a range streams from memory (exchange arrays + the two staged blocks: 4 x 256 words = the idle range buffer)
-constexpr int SS_NE_LDS = 4;      // ... while it is LDS resident (exchange arrays: 2 x 256 words behind the range buffer)
+constexpr int SS_NE_MEM = 4;      // tiles per block while a range streams from memory (stopper queues: 2 x 256 pairs = the idle range buffer; the staged blocks behind it)
+constexpr int SS_NE_LDS = 2;      // ... while it is LDS resident (stopper queues: 2 x 128 pairs behind the range buffer)
 
 struct SsCtx {
     uint32_t* A;          // the image's keys in memory; sorted in place
@@ -41,6 +41,9 @@ struct SsCtx {
 };
 
 __device__ __forceinline__ uint32_t ssK(uint32_t e) { return e >> 22; }
+// wave-uniform values are pinned to scalar registers: the divergence analysis otherwise gives up on the block counters (they flow through
+// loops with per-lane conditions), and every branch on them becomes an exec-mask sequence with vector copies of the loop state
+__device__ __forceinline__ int ssU(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <bool LDS> __device__ __forceinline__ uint32_t ss_ld(const SsCtx& c, int i) { return LDS ? c.sbuf[i - c.ldsFirst] : c.A[i]; }
 template <bool LDS> __device__ __forceinline__ void ss_st(const SsCtx& c, int i, uint32_t v) { if (LDS) c.sbuf[i - c.ldsFirst] = v; else c.A[i] = v; }
 __device__ __forceinline__ int ss_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
@@ -82,6 +85,7 @@ __device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t* XL, uint32_t* X
         if (jLE[u] >= 0 && jLE[u] < nG) swLE[u] = (int)XL[jLE[u]] < pos;       // (an element equal to the pivot is in both sets but can only swap as one of them)
         s += (int)__popcll(__ballot(swG[u]));
     }
+    s = ssU(s);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
@@ -99,16 +103,20 @@ __device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t* XL, uint32_t* X
         if (cand) cut = min(cut, B.base + 64 * u + (int)__builtin_ctzll(cand));
     }
     __builtin_amdgcn_wave_barrier();
-    return cut;
+    return ssU(cut);
 }
 
 // std::__unguarded_partition(lo, hi, pivot) on [lo, hi) (= [first + 1, last)) with comp(a, b) = K(a) < K(b); returns the cut.
-// LDS: the range lives in c.sbuf (exchange arrays XL / XR behind it); otherwise it streams from memory, the blocks' NE loads in flight together,
-// swapped values stored straight back (exchange arrays in c.sbuf, which is free while no range is LDS resident).
+// When a block is read, its stoppers go to the side's queue in LDS as (position, value) pairs in scan order (QL / QR, 64 NE entries each); a
+// step swaps the first k = min(pending left, pending right) pairs with consecutive lanes -- dense over the stoppers, no per-slot bookkeeping --
+// and the side whose queue is empty reads its next block.  dropRight: the part right of the cut will never be looked at again (it can only hold
+// undefined pixels), so what would be swapped into it is not stored.
+// LDS: the range lives in c.sbuf; otherwise it streams from memory, the next block of either side already on its way into SL / SR.
 template <bool LDS, int NE>
-__device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32_t* XR, uint32_t* SL, uint32_t* SR, int lo, int hi, uint32_t Kp)
+__device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR, uint32_t* SL, uint32_t* SR, int lo, int hi, uint32_t Kp, bool dropRight)
 {
     const int lane = c.lane;
+    lo = ssU(lo); hi = ssU(hi); Kp = (uint32_t)ssU((int)Kp);
     int lc = lo, rc = hi;                    // unread: [lc, rc)
     // memory path: the block after the current one is on its way into LDS (SL / SR, global_load_lds: no register, no compiler-placed wait --
     // loads kept in registers ended up behind an s_waitcnt vmcnt(0) right after their issue).  pfL / pfR: the position it starts at, -1: none
@@ -128,26 +136,29 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32
                 for (int u = 0; u < NE; ++u) L.v[u] = SL[64 * u + lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the staged block is in registers before the next one may overwrite it
             } else {
+                // (positions past the block are read clamped: no per-slot branch; their values are never looked at)
 #pragma unroll
-                for (int u = 0; u < NE; ++u) { const int p = lc + 64 * u + lane; L.v[u] = p < L.lim ? ss_ld<LDS>(c, p) : 0u; }
+                for (int u = 0; u < NE; ++u) L.v[u] = ss_ld<LDS>(c, min(lc + 64 * u + lane, L.lim - 1));
             }
             if (!LDS) {
                 pfL = -1;
                 if (lc + n < rc) {
                     pfL = lc + n;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) { const int p = pfL + 64 * u + lane; if (p < hi) __builtin_amdgcn_global_load_lds(c.A + p, SL + 64 * u, 4, 0, 0); }
+                    for (int u = 0; u < NE; ++u) __builtin_amdgcn_global_load_lds(c.A + min(pfL + 64 * u + lane, hi - 1), SL + 64 * u, 4, 0, 0);
                 }
             }
             int run = 0;
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
-                const bool st = lc + 64 * u + lane < L.lim && ssK(L.v[u]) >= Kp;
+                const int pos = lc + 64 * u + lane;
+                const bool st = pos < L.lim && ssK(L.v[u]) >= Kp;
                 const unsigned long long m = __ballot(st);
                 L.rk[u] = st ? run + ss_rank_below(m) : -1;
+                if (st) QL[L.rk[u]] = make_uint2((uint32_t)pos, L.v[u]);
                 run += (int)__popcll(m);
             }
-            L.n = run; L.c = 0;
+            L.n = ssU(run); L.c = 0;
             lc += n;
         }
         if (R.c == R.n) {
@@ -161,48 +172,48 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
 #pragma unroll
-                for (int u = 0; u < NE; ++u) { const int p = R.base + 64 * u + lane; R.v[u] = p >= R.lim ? ss_ld<LDS>(c, p) : 0u; }
+                for (int u = 0; u < NE; ++u) R.v[u] = ss_ld<LDS>(c, max(R.base + 64 * u + lane, R.lim));
             }
             if (!LDS) {
                 pfR = -1;
                 if (lc < rc - n) {
                     pfR = rc - n - 64 * NE;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) { const int p = pfR + 64 * u + lane; if (p >= lo) __builtin_amdgcn_global_load_lds(c.A + p, SR + 64 * u, 4, 0, 0); }
+                    for (int u = 0; u < NE; ++u) __builtin_amdgcn_global_load_lds(c.A + max(pfR + 64 * u + lane, lo), SR + 64 * u, 4, 0, 0);
                 }
             }
             int run = 0;
 #pragma unroll
             for (int u = NE - 1; u >= 0; --u) {
-                const bool st = R.base + 64 * u + lane >= R.lim && ssK(R.v[u]) <= Kp;
+                const int pos = R.base + 64 * u + lane;
+                const bool st = pos >= R.lim && ssK(R.v[u]) <= Kp;
                 const unsigned long long m = __ballot(st);
                 const int cnt = (int)__popcll(m);
                 R.rk[u] = st ? run + cnt - 1 - ss_rank_below(m) : -1;
+                if (st) QR[R.rk[u]] = make_uint2((uint32_t)pos, R.v[u]);
                 run += cnt;
             }
-            R.n = run; R.c = 0;
+            R.n = ssU(run); R.c = 0;
             rc -= n;
         }
         if (L.c < L.n && R.c < R.n) {
-            // pair the pending stoppers by rank: all of them lie on their own side of the unread part, so every pair swaps
-            const unsigned k = (unsigned)min(L.n - L.c, R.n - R.c);
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                if ((unsigned)(L.rk[u] - L.c) < k) XL[L.rk[u] - L.c] = L.v[u];
-                if ((unsigned)(R.rk[u] - R.c) < k) XR[R.rk[u] - R.c] = R.v[u];
+            // all pending stoppers lie on their own side of the unread part, so every pair swaps
+            const int k = ssU(min(L.n - L.c, R.n - R.c));
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < k; j += 64) {
+                const uint2 a = QL[L.c + j], b = QR[R.c + j];
+                ss_st<LDS>(c, (int)a.x, b.y);
+                if (!dropRight) ss_st<LDS>(c, (int)b.x, a.y);
             }
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < NE; ++u) {
-                if ((unsigned)(L.rk[u] - L.c) < k) { L.v[u] = XR[L.rk[u] - L.c]; ss_st<LDS>(c, L.base + 64 * u + lane, L.v[u]); }
-                if ((unsigned)(R.rk[u] - R.c) < k) { R.v[u] = XL[R.rk[u] - R.c]; ss_st<LDS>(c, R.base + 64 * u + lane, R.v[u]); }
-            }
-            __builtin_amdgcn_wave_barrier();
-            L.c += (int)k; R.c += (int)k;
+            L.c += k; R.c += k;
         }
     }
     if (!LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no block may still be on its way into LDS when the buffers are reused
-    // everything has been read; at most one side still has stoppers, and they sit in that side's last block
+    // everything has been read; at most one side still has stoppers, and they sit in that side's last block (whose pending elements have not
+    // been touched by the swaps above, so the register copy of the block is current where it matters)
+    uint32_t* XL = reinterpret_cast<uint32_t*>(QL);
+    uint32_t* XR = reinterpret_cast<uint32_t*>(QR);
     if (L.c < L.n) {
         // the right scan walks into the left side's last block from above: the zone is [first pending stopper, end of that block)
         int l0 = lc;
@@ -219,7 +230,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32
             run += cnt;
             jG[u] = L.rk[u] >= L.c ? L.rk[u] - L.c : -1;
         }
-        return ss_zone<LDS, NE>(c, XL, XR, L, jG, L.n - L.c, jLE, run, lc);
+        return ss_zone<LDS, NE>(c, XL, XR, L, jG, L.n - L.c, jLE, ssU(run), lc);
     }
     if (R.c < R.n) {
         // the left scan walks into the right side's last block from below: the zone is [start of that block, last pending stopper]
@@ -236,7 +247,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint32_t* XL, uint32
             run += (int)__popcll(m);
             jLE[u] = R.rk[u] >= R.c ? R.rk[u] - R.c : -1;
         }
-        return ss_zone<LDS, NE>(c, XL, XR, R, jG, run, jLE, R.n - R.c, r0 + 1);
+        return ss_zone<LDS, NE>(c, XL, XR, R, jG, ssU(run), jLE, R.n - R.c, r0 + 1);
     }
     return lc;
 }
@@ -368,9 +379,9 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
 #ifdef OLF_SS_PROF
     long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
 #endif
-    __shared__ uint32_t s_buf[SS_CAP];
-    __shared__ uint32_t s_x[2 * 64 * SS_NE_LDS];
-    static_assert(4 * 64 * SS_NE_MEM <= SS_CAP, "the memory path's exchange arrays and staged blocks live in the range buffer");
+    __shared__ __align__(8) uint32_t s_buf[SS_CAP];
+    __shared__ __align__(8) uint32_t s_x[4 * 64 * SS_NE_LDS];      // LDS path: the two stopper queues; memory path: the two staged blocks
+    static_assert(4 * 64 * SS_NE_MEM <= SS_CAP && 2 * 64 * SS_NE_MEM <= 4 * 64 * SS_NE_LDS, "memory path: queues in the range buffer, staged blocks in s_x");
     const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     SsCtx c;
@@ -405,6 +416,7 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
         --sp;
         int first = __builtin_amdgcn_readlane(stF, sp), last = __builtin_amdgcn_readlane(stL, sp), depth = __builtin_amdgcn_readlane(stD, sp);
         uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)stLb, sp), ub = (uint32_t)__builtin_amdgcn_readlane((int)stUb, sp);     // lb <= K <= ub for every element of the range
+        first = ssU(first); last = ssU(last); depth = ssU(depth); lb = (uint32_t)ssU((int)lb); ub = (uint32_t)ssU((int)ub);
         if (inLDS && first >= ldsLast) inLDS = false;
         for (;;) {
             const int m = last - first;
@@ -452,13 +464,16 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
             const uint32_t Kp = ssK(es);
             SSPROF(SP_PIVOT);
             int cut;
-            if (!inLDS) cut = ss_partition<false, SS_NE_MEM>(c, s_buf, s_buf + 64 * SS_NE_MEM, s_buf + 128 * SS_NE_MEM, s_buf + 192 * SS_NE_MEM, first + 1, last, Kp);
-            else if (m <= 65) cut = ss_partition<true, 1>(c, s_x, s_x + 64, nullptr, nullptr, first + 1, last, Kp);       // small ranges: no work on empty slots
-            else if (m <= 129) cut = ss_partition<true, 2>(c, s_x, s_x + 128, nullptr, nullptr, first + 1, last, Kp);
-            else cut = ss_partition<true, SS_NE_LDS>(c, s_x, s_x + 64 * SS_NE_LDS, nullptr, nullptr, first + 1, last, Kp);
+            const bool dropRight = Kp > Kthr;
+            uint2* const qx = reinterpret_cast<uint2*>(s_x);
+            uint2* const qb = reinterpret_cast<uint2*>(s_buf);
+            if (!inLDS) cut = ss_partition<false, SS_NE_MEM>(c, qb, qb + 64 * SS_NE_MEM, s_x, s_x + 64 * SS_NE_MEM, first + 1, last, Kp, dropRight);
+            else if (m <= 65) cut = ss_partition<true, 1>(c, qx, qx + 64, nullptr, nullptr, first + 1, last, Kp, dropRight);       // small ranges: no work on empty slots
+            else cut = ss_partition<true, SS_NE_LDS>(c, qx, qx + 64 * SS_NE_LDS, nullptr, nullptr, first + 1, last, Kp, dropRight);
             if (inLDS) { SSPROF(SP_PART_LDS); SSCNT(SP_N_PART_LDS, 1); SSCNT(SP_V_PART_LDS, m); } else { SSPROF(SP_PART_MEM); SSCNT(SP_N_PART_MEM, 1); SSCNT(SP_V_PART_MEM, m); }
             SS_PUSH(cut, last, depth, max(lb, Kp), ub);               // [cut, last): K >= Kp
             last = cut; ub = min(ub, Kp);                             // [first, cut): K <= Kp (the pivot sits at first)
+            outPos = ssU(outPos);
         }
     }
 #undef SS_PUSH
