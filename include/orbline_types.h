@@ -77,10 +77,11 @@ typedef struct olf_line_params {
      * C.11 conv_gauss_sum256: as in olf_orb_params, for LSD's sigma-0.6 blur and LBD's 5x5 sigma-1 blur.
      * C.10 conv_resize_exact: LSD's x1.2 upsampling, 0: cv::resize INTER_LINEAR (11-bit coefficients); 1: INTER_LINEAR_EXACT (8-bit
      *      coefficients, round-to-nearest at the end), which later 3.4.x releases of lsd.cpp call.
-     * C.9  conv_seed_order: order of the seeds INSIDE a gradient bin, 0: raster (the linked-list pseudo-ordering of the original LSD and of
-     *      OpenCV <= 3.2); 1: whatever std::sort(begin, end, norm descending) of libstdc++ leaves (OpenCV >= 3.3 sorts a vector of all pixels by
-     *      bin with the unstable std::sort).  Only the CPU oracle implements 1: the order is a property of the introsort implementation run on
-     *      the whole pixel sequence, which has no data-parallel equivalent -- olf_ctx_create refuses it with OLF_ERR_INVALID. */
+     * C.9  conv_seed_order: order of the seeds INSIDE a gradient bin.  1 (default): whatever std::sort(begin, end, norm descending) of
+     *      libstdc++ leaves -- OpenCV >= 3.3 pushes every pixel as {point, bin} and calls the unstable std::sort; the reference's CMakeLists.txt
+     *      asks for OpenCV 3.4 first.  The order is a property of libstdc++'s introsort run over the whole pixel sequence; csrc/lsd_seedsort.hip
+     *      replays it bit-exactly (oracle: the real std::sort).  0: raster order (the linked-list pseudo-ordering of the original LSD and of
+     *      OpenCV <= 3.2; a stable radix sort on the device). */
     int32_t conv_gauss_sum256;
     int32_t conv_resize_exact;
     int32_t conv_seed_order;

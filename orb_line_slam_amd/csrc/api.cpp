@@ -195,6 +195,7 @@ int olf_default_params(olf_params* p)
     p->line.lsd_nfeatures = 500; p->line.min_line_length = 0.025; p->line.lsd_refine = 0; p->line.lsd_scale = 1.2;
     p->line.lsd_sigma_scale = 0.6; p->line.lsd_quant = 2.0; p->line.lsd_ang_th = 22.5; p->line.lsd_log_eps = 1.0;
     p->line.lsd_density_th = 0.6; p->line.lsd_n_bins = 1024;
+    p->line.conv_seed_order = 1;      // OpenCV >= 3.3 (the reference asks for 3.4 first, CMakeLists.txt:37-43): std::sort seed order
     p->stereo.fx = 718.856f; p->stereo.bf = 386.1448f; p->stereo.matching_s_ws = 10; p->stereo.line_sim_th = 0.75;
     p->stereo.min_ratio_12_l = 0.9; p->stereo.min_disp = 1.0; p->stereo.line_horiz_th = 0.1; p->stereo.stereo_overlap_th = 0.75;
     p->stereo.ls_min_disp_ratio = 0.7; p->stereo.best_lr_matches = 1;

@@ -25,6 +25,7 @@
 // Output: keysB = the keys ((n_bins - 1 - bin) << 22 | address) of all pixels whose bin is at least the smallest bin of a defined pixel, in
 // seed order.  Undefined pixels that share that smallest bin are in the list too; the growth kernels skip them (NOTDEF bit of the gradient word).
 #include "lsd_device.hpp"
+#pragma clang diagnostic ignored "-Winline-asm"      // ss_async_ld names m0 (the LDS base of global_load_lds) as clobbered
 
 namespace olf {
 
@@ -46,6 +47,15 @@ __device__ __forceinline__ uint32_t ssK(uint32_t e) { return e >> 22; }
 __device__ __forceinline__ int ssU(int v) { return __builtin_amdgcn_readfirstlane(v); }
 template <bool LDS> __device__ __forceinline__ uint32_t ss_ld(const SsCtx& c, int i) { return LDS ? c.sbuf[i - c.ldsFirst] : c.A[i]; }
 template <bool LDS> __device__ __forceinline__ void ss_st(const SsCtx& c, int i, uint32_t v) { if (LDS) c.sbuf[i - c.ldsFirst] = v; else c.A[i] = v; }
+// one tile of the next block on its way from memory into LDS (global_load_lds_dword: lane l's word lands at lds_byte_off + 4 l).  Inline
+// assembly on purpose: issued through the builtin, the compiler's wait-count pass puts an s_waitcnt vmcnt(0) in front of the next LDS access
+// of any kind (it cannot tell the queues from the staging area), which turns the prefetch into a blocking load.  The data is only read after
+// an explicit s_waitcnt vmcnt(0); the compiler's own waits stay safe because vector memory operations complete in order.
+__device__ __forceinline__ void ss_async_ld(const uint32_t* g, unsigned lds_byte_off)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned ss_lds_off(const void* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(p)); }
 __device__ __forceinline__ int ss_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
 // ---- the Hoare partition, NE x 64 elements per side and step -----------------------------------------------------------------------------
@@ -145,7 +155,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
                 if (lc + n < rc) {
                     pfL = lc + n;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) __builtin_amdgcn_global_load_lds(c.A + min(pfL + 64 * u + lane, hi - 1), SL + 64 * u, 4, 0, 0);
+                    for (int u = 0; u < NE; ++u) ss_async_ld(c.A + min(pfL + 64 * u + lane, hi - 1), ss_lds_off(SL) + 256u * u);
                 }
             }
             int run = 0;
@@ -179,7 +189,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
                 if (lc < rc - n) {
                     pfR = rc - n - 64 * NE;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) __builtin_amdgcn_global_load_lds(c.A + max(pfR + 64 * u + lane, lo), SR + 64 * u, 4, 0, 0);
+                    for (int u = 0; u < NE; ++u) ss_async_ld(c.A + max(pfR + 64 * u + lane, lo), ss_lds_off(SR) + 256u * u);
                 }
             }
             int run = 0;

@@ -311,7 +311,7 @@ def test_stereo_frame_against_committed_fixture():
 @pytest.mark.parametrize("gauss256,exact", [(1, 0), (0, 1), (1, 1)])
 def test_opencv_version_conventions(oracle, gauss256, exact):
     """Conventions C.10 / C.11 (which OpenCV 3.4.x patch level the reference linked decides them): the library follows the oracle under every
-    combination; the std::sort seed order (C.9 variant 1) exists in the oracle only and is refused."""
+    combination, and under the raster seed order of OpenCV <= 3.2 (C.9 variant 0; variant 1, std::sort, is the default and what every other test runs)."""
     from orb_line_slam_amd import _lib
     w, h = 640, 480
     p = oracle.full_params(1000, 200, 435.2047, 47.9064)
@@ -328,7 +328,13 @@ def test_opencv_version_conventions(oracle, gauss256, exact):
     assert np.array_equal(g["mDescriptors_Line"], ol["desc"])
     base = oracle.full_params(1000, 200, 435.2047, 47.9064)
     assert not np.array_equal(ol["desc"], oracle.line_extract(imgs[0], base.line)["desc"]) or not np.array_equal(o["descL"], oracle.stereo_points(imgs[0], imgs[1], base)["descL"])
-    p.line.conv_seed_order = 1
+    # the raster seed order (OpenCV <= 3.2) through the fused entry, against the oracle under the same convention
+    p.line.conv_seed_order = 0
+    g0 = ola.StereoFrontEnd(p, w, h, max_pairs=1).frames(imgs).pair(0)
+    ol0 = oracle.line_extract(imgs[0], p.line)
+    _cmp_keylines(g0["mvKeys_Line"], ol0["kls"])
+    assert np.array_equal(g0["mDescriptors_Line"], ol0["desc"])
+    p.line.conv_seed_order = 2
     with pytest.raises(_lib.OlfError):
         ola.StereoFrontEnd(p, w, h, max_pairs=1)
 
