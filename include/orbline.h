@@ -230,6 +230,13 @@ typedef struct olf_frame_view {
  * received (-1 = none); cur->mp_valid / mp_obs are updated; *nmatches = the reference's return value. */
 int olf_search_by_projection(olf_ctx* ctx, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
                              int32_t* matches, int32_t* nmatches);
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, map<int,int>& match12),
+ * src/ORBmatcher.cc:1474-1618 -- the overload Tracking::TrackWithMotionModelWithLine calls (src/Tracking.cc:1296,1302).  Same search; match12[i2]
+ * = the value the reference's map holds under key i2 (-1: no such key): match12.insert keeps the FIRST LastFrame index CurrentFrame feature i2
+ * was matched with (:1577) while matches[i2] / mvpMapPoints[i2] keep the last one (:1575); match12.erase on a rotation rejection (:1612).
+ * Walking i2 upwards over match12[i2] >= 0 reproduces the map's iteration order. */
+int olf_search_by_projection_match12(olf_ctx* ctx, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
+                                     int32_t* matches, int32_t* match12, int32_t* nmatches);
 /* int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize),
  * src/ORBmatcher.cc:407-522 (monocular map initialisation).  Only keys / desc / n / the image bounds of the views are read.
  * prev_matched: f1->n (x, y) pairs, updated in place with the matched F2 positions; matches12[i1] = F2 index or -1. */
@@ -282,6 +289,15 @@ int olf_fuse_search(olf_ctx* ctx, const olf_frame_view* kf, int n_mp, const uint
 int olf_fuse_search_sim3(olf_ctx* ctx, const olf_frame_view* kf, const float* Scw, int n_mp, const uint8_t* skip, const float* world,
                          const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th, int32_t* best_idx,
                          int32_t* best_dist);
+/* int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
+ * src/ORBmatcher.cc:292-405 (LoopClosing::ComputeSim3, src/LoopClosing.cc:381): the loop candidate's map points projected into the key frame
+ * under the Sim3 pose Scw (4x4, row-major).  skip[i] = vpPoints[i]->isBad() || spAlreadyFound.count(vpPoints[i]) (:311-312, :321); the point
+ * arrays as in olf_fuse_search_sim3.  matched[idx] (in / out, kf->n bytes) = vpMatched[idx] != NULL: a key point that holds a match is passed
+ * over (:378) and a point whose best distance is <= TH_LOW takes its key point at once (:397-401) -- matches[idx] = the index into vpPoints
+ * key point idx received in this call (-1 = none); *nmatches = the reference's return value. */
+int olf_search_by_projection_sim3(olf_ctx* ctx, const olf_frame_view* kf, const float* Scw, int n_mp, const uint8_t* skip, const float* world,
+                                  const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th, uint8_t* matched,
+                                  int32_t* matches, int32_t* nmatches);
 /* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12,
  * const cv::Mat &t12, const float th), src/ORBmatcher.cc:1104-1328.  matches12[i1]: in -- -1 = NULL, >= 0 = pMP->GetIndexInKeyFrame(pKF2),
  * -2 = a map point pKF2 does not observe; out -- additionally the agreed matches.  vn_match1 / vn_match2 = vnMatch1 / vnMatch2. */

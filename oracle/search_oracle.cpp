@@ -18,6 +18,7 @@
 // matmul.cpp; OpenCV is not in the image, so this is a stated convention, not a verified fact.
 // PARITY UNPINNED (see oracle_common.hpp).
 #include "oracle_common.hpp"
+#include <map>
 #include <climits>
 
 namespace orc {
@@ -91,11 +92,14 @@ static void mat3_mul_add(const float* T /*4x4 row-major*/, const float v[3], flo
 using namespace orc;
 extern "C" {
 
-int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
+// (match12: the reference's map<int, int> of the overload src/ORBmatcher.cc:1474-1618, nullptr for the four-argument overload :1330-1472)
+static int search_by_projection_impl(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
                              uint8_t* cur_mp_obs, const float* curTcw, const olf_keypoint* lastKeys, int lastN, const uint8_t* last_mp_valid,
                              const float* last_mp_world, const uint8_t* last_mp_desc, const uint8_t* last_mp_obs, const uint8_t* last_outlier,
-                             const float* lastTcw, const float* cam9, const float* scaleFactors, float th, int bMono, int checkOri, int* matches)
+                             const float* lastTcw, const float* cam9, const float* scaleFactors, float th, int bMono, int checkOri, int* matches,
+                             std::map<int, int>* match12)
 {
+    if (match12) match12->clear();
     Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
     const float mb = c.mbf / c.fx;
     GridFrame G; G.keys = curKeys; G.N = curN; G.c = c; G.build();
@@ -145,6 +149,7 @@ int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc
             cur_mp_valid[bestIdx2] = 1; cur_mp_obs[bestIdx2] = last_mp_obs[i];
             matches[bestIdx2] = i;
             nmatches++;
+            if (match12) match12->insert(std::pair<int, int>(bestIdx2, i));      // :1577 -- insert() keeps an existing key
             if (checkOri) {
                 float rot = lastKeys[i].angle - curKeys[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
@@ -159,9 +164,35 @@ int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc
         three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
         for (int i = 0; i < HISTO_LENGTH; i++)
             if (i != ind1 && i != ind2 && i != ind3)
-                for (int j : rotHist[i]) { cur_mp_valid[j] = 0; matches[j] = -1; nmatches--; }
+                for (int j : rotHist[i]) { cur_mp_valid[j] = 0; matches[j] = -1; nmatches--; if (match12) match12->erase(j); }
     }
     return nmatches;
+}
+
+int orc_search_by_projection(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
+                             uint8_t* cur_mp_obs, const float* curTcw, const olf_keypoint* lastKeys, int lastN, const uint8_t* last_mp_valid,
+                             const float* last_mp_world, const uint8_t* last_mp_desc, const uint8_t* last_mp_obs, const uint8_t* last_outlier,
+                             const float* lastTcw, const float* cam9, const float* scaleFactors, float th, int bMono, int checkOri, int* matches)
+{
+    return search_by_projection_impl(curKeys, curDesc, curURight, curN, cur_mp_valid, cur_mp_obs, curTcw, lastKeys, lastN, last_mp_valid, last_mp_world,
+                                     last_mp_desc, last_mp_obs, last_outlier, lastTcw, cam9, scaleFactors, th, bMono, checkOri, matches, nullptr);
+}
+
+// ... with the map<int, int>& match12 of src/ORBmatcher.cc:1474-1618: pairs (key, value) in the map's iteration order, *n_pairs of them
+int orc_search_by_projection_match12(const olf_keypoint* curKeys, const uint8_t* curDesc, const float* curURight, int curN, uint8_t* cur_mp_valid,
+                             uint8_t* cur_mp_obs, const float* curTcw, const olf_keypoint* lastKeys, int lastN, const uint8_t* last_mp_valid,
+                             const float* last_mp_world, const uint8_t* last_mp_desc, const uint8_t* last_mp_obs, const uint8_t* last_outlier,
+                             const float* lastTcw, const float* cam9, const float* scaleFactors, float th, int bMono, int checkOri, int* matches,
+                             int* pairs, int* n_pairs)
+{
+    std::map<int, int> m12;
+    const int n = search_by_projection_impl(curKeys, curDesc, curURight, curN, cur_mp_valid, cur_mp_obs, curTcw, lastKeys, lastN, last_mp_valid,
+                                            last_mp_world, last_mp_desc, last_mp_obs, last_outlier, lastTcw, cam9, scaleFactors, th, bMono, checkOri,
+                                            matches, &m12);
+    int k = 0;
+    for (const auto& kv : m12) { pairs[2 * k] = kv.first; pairs[2 * k + 1] = kv.second; ++k; }
+    *n_pairs = k;
+    return n;
 }
 
 // ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:407-522; prevMatched: (x, y) per F1 key point, updated in place
@@ -648,6 +679,51 @@ extern "C" void orc_fuse_search_sim3(const olf_keypoint* keys, const uint8_t* de
         const float radius = th * scaleFactors[nPredictedLevel];
         best_in_area(G, desc, u, v, radius, nPredictedLevel, mp_desc + 32 * (size_t)i, bestIdxOut[i], bestDistOut[i]);
     }
+}
+
+// int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
+// src/ORBmatcher.cc:292-405 (LoopClosing.cc:381).  mp_skip = isBad() || spAlreadyFound.count(pMP); matched[idx] = vpMatched[idx] != NULL (in / out);
+// kfMatch[idx] = index into vpPoints assigned to key point idx by this call.  Returns nmatches.
+extern "C" int orc_search_by_projection_sim3(const olf_keypoint* keys, const uint8_t* desc, int N, const float* Scw, const float* cam9, const float* scaleFactors,
+                          int nLevels, float logScaleFactor, int nMP, const uint8_t* mp_skip, const float* mp_world, const float* mp_normal,
+                          const float* mp_maxd, const float* mp_mind, const uint8_t* mp_desc, int th, uint8_t* matched, int* kfMatch)
+{
+    Cam c = {cam9[0], cam9[1], cam9[2], cam9[3], cam9[4], cam9[5], cam9[6], cam9[7], cam9[8]};
+    GridFrame G; G.keys = keys; G.N = N; G.c = c; G.build();
+    float Rcw[9], tcw[3], Ow[3];
+    orc_sim3_decompose(Scw, Rcw, tcw, Ow);                 // :301-305
+    for (int i = 0; i < N; ++i) kfMatch[i] = -1;
+    int nmatches = 0;
+    for (int iMP = 0; iMP < nMP; iMP++) {
+        if (mp_skip[iMP]) continue;                        // :320-322
+        const float* p3Dw = mp_world + 3 * iMP;
+        float p3Dc[3];
+        r3_mul_add(Rcw, p3Dw, tcw, p3Dc);                  // :328
+        if (p3Dc[2] < 0.0) continue;                       // :331
+        const float invz = 1 / p3Dc[2];                    // :335 (an int over a float: float division)
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+        if (!(u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY)) continue;      // KeyFrame::IsInImage
+        const float maxDistance = 1.2f * mp_maxd[iMP], minDistance = 0.8f * mp_mind[iMP];      // Get{Max,Min}DistanceInvariance, src/MapPoint.cc:385-396
+        float PO[3]; double nrm = 0, dot = 0;
+        for (int k = 0; k < 3; ++k) { PO[k] = p3Dw[k] - Ow[k]; nrm += (double)PO[k] * (double)PO[k]; dot += (double)PO[k] * (double)mp_normal[3 * iMP + k]; }
+        const float dist = (float)std::sqrt(nrm);          // cv::norm(PO)
+        if (dist < minDistance || dist > maxDistance) continue;
+        if (dot < 0.5 * dist) continue;                    // :358
+        const int nPredictedLevel = predict_scale(mp_maxd[iMP], dist, logScaleFactor, nLevels);
+        const float radius = th * scaleFactors[nPredictedLevel];
+        const uint8_t* dMP = mp_desc + 32 * (size_t)iMP;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t idx : G.area(u, v, radius)) {
+            if (matched[idx]) continue;                    // :378
+            const int kpLevel = keys[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int d = hamming256(dMP, desc + 32 * idx);
+            if (d < bestDist) { bestDist = d; bestIdx = (int)idx; }
+        }
+        if (bestDist <= TH_LOW) { matched[bestIdx] = 1; kfMatch[bestIdx] = iMP; nmatches++; }
+    }
+    return nmatches;
 }
 
 // SearchBySim3.  Per key frame: keys / desc / n, Tcw (4x4), and for every feature its map point (valid, bad, world, maxd, mind, descriptor);

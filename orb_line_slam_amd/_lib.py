@@ -127,6 +127,7 @@ def lib():
         L.olf_stereo_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FrameBuffers)]
         L.olf_match_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_by_projection.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.olf_search_by_projection_match12.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_by_bow.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_float, C.c_int, C.c_void_p, C.c_void_p]
         L.olf_search_for_initialization.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.POINTER(FrameViewC), C.c_void_p, C.c_int, C.c_float, C.c_int,
                                                     C.c_void_p, C.c_void_p]
@@ -137,6 +138,7 @@ def lib():
         L.olf_search_for_triangulation.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.olf_fuse_search.argtypes = [C.c_void_p, V, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_fuse_search_sim3.argtypes = [C.c_void_p, V, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p]
+        L.olf_search_by_projection_sim3.argtypes = [C.c_void_p, V, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_by_sim3.argtypes = [C.c_void_p, V, V, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_search_local_map.argtypes = [C.c_void_p, C.POINTER(FrameViewC), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]

@@ -134,18 +134,20 @@ bool bad_view(const olf_frame_view* f, bool needs_pose)
 }
 // views whose scale tables are indexed by a predicted pyramid level (MapPoint::PredictScale) or by a key point's octave
 bool bad_levels(const olf_frame_view* f) { return f->n_levels < 1 || f->n_levels > OLF_MAX_LEVELS || !f->scale_factors; }
-}  // namespace
 
-extern "C" {
-
-int olf_search_by_projection(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
-                             int32_t* matches, int32_t* nmatches)
+// Both SearchByProjection(Frame, Frame) overloads: src/ORBmatcher.cc:1330-1472 and, with match12, :1474-1618.  match12 models the reference's
+// map<int, int>: match12.insert(pair(bestIdx2, i)) keeps the FIRST last-frame index a current feature was matched with (:1577; a feature whose
+// new map point has no observations can be matched again, and mvpMapPoints[bestIdx2] = pMP then keeps the last one), match12.erase(idx) on a
+// rotation-histogram rejection (:1612).
+int search_by_projection_frames(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
+                                int32_t* matches, int32_t* match12, int32_t* nmatches)
 {
     if (!c || bad_view(cur, true) || bad_view(last, true) || !matches || !nmatches || !cur->scale_factors || !cur->mp_valid || !cur->mp_obs ||
         (cur->n && !cur->uright) || (last->n && (!last->mp_valid || !last->mp_world || !last->mp_desc || !last->mp_obs))) {
         set_error("olf_search_by_projection: bad argument"); return OLF_ERR_INVALID;
     }
     for (int i = 0; i < cur->n; ++i) matches[i] = -1;
+    if (match12) for (int i = 0; i < cur->n; ++i) match12[i] = -1;
     *nmatches = 0;
     const float mb = cur->mbf / cur->fx;
     // twc = -Rcw.t() * tcw;  tlc = Rlw * twc + tlw                                   (:1341-1349)
@@ -207,6 +209,7 @@ int olf_search_by_projection(olf_ctx* c, const olf_frame_view* cur, const olf_fr
             cur->mp_valid[bestIdx2] = 1;
             cur->mp_obs[bestIdx2] = last->mp_obs[i];
             matches[bestIdx2] = i;
+            if (match12 && match12[bestIdx2] < 0) match12[bestIdx2] = i;
             n++;
             if (check_orientation) rotHist[rot_bin(last->keys[i].angle, cur->keys[bestIdx2].angle)].push_back(bestIdx2);
         }
@@ -216,11 +219,27 @@ int olf_search_by_projection(olf_ctx* c, const olf_frame_view* cur, const olf_fr
         three_maxima(rotHist, ind1, ind2, ind3);
         for (int b = 0; b < HISTO_LENGTH; b++) {
             if (b == ind1 || b == ind2 || b == ind3) continue;
-            for (int j : rotHist[b]) { cur->mp_valid[j] = 0; matches[j] = -1; n--; }
+            for (int j : rotHist[b]) { cur->mp_valid[j] = 0; matches[j] = -1; if (match12) match12[j] = -1; n--; }
         }
     }
     *nmatches = n;
     return OLF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int olf_search_by_projection(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
+                             int32_t* matches, int32_t* nmatches)
+{
+    return search_by_projection_frames(c, cur, last, th, bMono, check_orientation, matches, nullptr, nmatches);
+}
+
+int olf_search_by_projection_match12(olf_ctx* c, const olf_frame_view* cur, const olf_frame_view* last, float th, int bMono, int check_orientation,
+                                     int32_t* matches, int32_t* match12, int32_t* nmatches)
+{
+    if (!match12) { set_error("olf_search_by_projection_match12: bad argument"); return OLF_ERR_INVALID; }
+    return search_by_projection_frames(c, cur, last, th, bMono, check_orientation, matches, match12, nmatches);
 }
 
 int olf_search_for_initialization(olf_ctx* c, const olf_frame_view* f1, const olf_frame_view* f2, float* prev_matched, int window_size, float nnratio,
@@ -715,16 +734,20 @@ namespace {
 // per map point: gates, window, candidates.  Rcw9 / tcw3 / Ow3: camera pose; stereo_gate: the chi-square test of the plain Fuse.
 int fuse_core(olf_ctx* c, const char* who, const olf_frame_view* kf, const float* Rcw9, const float* tcw3, const float* Ow3, int n_mp,
               const uint8_t* skip, const float* world, const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th,
-              bool stereo_gate, int none_dist, int32_t* best_idx, int32_t* best_dist)
+              bool stereo_gate, int none_dist, int32_t* best_idx, int32_t* best_dist, uint8_t* matched = nullptr, int32_t* kf_match = nullptr,
+              int32_t* nmatches = nullptr)
 {
+    // matched != nullptr: SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:292-405) -- key points that hold a match are
+    // skipped (:378), a point whose best distance is <= TH_LOW takes its key point at once (:397-401), so later points see it taken
     if (bad_levels(kf)) { set_error(std::string(who) + ": n_levels / scale_factors missing"); return OLF_ERR_INVALID; }
     const float logSF = log_scale_factor(*kf);
     const Grid grid(*kf);
     Batch q;
     struct Meta { float u, v, ur; int level; };
     std::vector<Meta> meta;
+    int taken = 0;
     for (int i = 0; i < n_mp; ++i) {
-        best_idx[i] = -1; best_dist[i] = none_dist;
+        if (best_idx) { best_idx[i] = -1; best_dist[i] = none_dist; }
         if (skip && skip[i]) continue;
         const float* p3Dw = world + 3 * (size_t)i;
         float p3Dc[3], u, v, invz;
@@ -752,6 +775,7 @@ int fuse_core(olf_ctx* c, const char* who, const olf_frame_view* kf, const float
         int bestDist = none_dist, bestIdx = -1;
         for (int p = q.offs[k]; p < q.offs[k + 1]; ++p) {
             const int idx = q.cand[p];
+            if (matched && matched[idx]) continue;
             const olf_keypoint& kp = kf->keys[idx];
             const int kpLevel = kp.octave;
             if (kpLevel < m.level - 1 || kpLevel > m.level) continue;
@@ -773,9 +797,24 @@ int fuse_core(olf_ctx* c, const char* who, const olf_frame_view* kf, const float
             const int dist = q.dist[p];
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
         }
-        best_idx[q.owner[k]] = bestIdx; best_dist[q.owner[k]] = bestDist;
+        if (best_idx) { best_idx[q.owner[k]] = bestIdx; best_dist[q.owner[k]] = bestDist; }
+        if (matched && bestDist <= TH_LOW) { matched[bestIdx] = 1; kf_match[bestIdx] = q.owner[k]; ++taken; }
     }
+    if (nmatches) *nmatches = taken;
     return OLF_OK;
+}
+
+// Decompose Scw (src/ORBmatcher.cc:301-305, :985-989): scw = sqrt(row0 . row0); Rcw = sRcw / scw, tcw = Scw.col(3) / scw (a cv::Mat divided by a
+// scalar is a scaling by the double 1/scw rounded to float); Ow = -Rcw.t() * tcw
+void sim3_decompose(const float* Scw, float* R, float* t, float* ow)
+{
+    double d = 0;
+    for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
+    const float scw = (float)std::sqrt(d);
+    const float inv = (float)(1.0 / (double)scw);
+    float Rt[9];
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) { R[3 * r + k] = Scw[4 * r + k] * inv; Rt[3 * k + r] = R[3 * r + k]; } t[r] = Scw[4 * r + 3] * inv; }
+    r3_apply(Rt, t, nullptr, ow, -1.0, true);
 }
 }  // namespace
 
@@ -798,17 +837,23 @@ int olf_fuse_search_sim3(olf_ctx* c, const olf_frame_view* kf, const float* Scw,
 {
     if (!c || bad_view(kf, false) || !Scw || n_mp < 0 || !best_idx || !best_dist || !kf->scale_factors ||
         (n_mp && (!world || !normal || !maxd || !mind || !desc))) { set_error("olf_fuse_search_sim3: bad argument"); return OLF_ERR_INVALID; }
-    // Decompose Scw (:985-989): scw = sqrt(row0 . row0); Rcw = sRcw / scw, tcw = Scw.col(3) / scw (a cv::Mat divided by a scalar is a
-    // scaling by the double 1/scw rounded to float); Ow = -Rcw.t() * tcw
-    double d = 0;
-    for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
-    const float scw = (float)std::sqrt(d);
-    const float inv = (float)(1.0 / (double)scw);
-    float R[9], Rt[9], t[3], ow[3];
-    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) { R[3 * r + k] = Scw[4 * r + k] * inv; Rt[3 * k + r] = R[3 * r + k]; } t[r] = Scw[4 * r + 3] * inv; }
-    r3_apply(Rt, t, nullptr, ow, -1.0, true);          // Ow = -Rcw.t() * tcw (src/ORBmatcher.cc:989)
+    float R[9], t[3], ow[3];
+    sim3_decompose(Scw, R, t, ow);
     return fuse_core(c, "olf_fuse_search_sim3", kf, R, t, ow, n_mp, skip, world, normal, maxd, mind, desc, th, false, 2147483647, best_idx,
                      best_dist);
+}
+
+int olf_search_by_projection_sim3(olf_ctx* c, const olf_frame_view* kf, const float* Scw, int n_mp, const uint8_t* skip, const float* world,
+                                  const float* normal, const float* maxd, const float* mind, const uint8_t* desc, float th, uint8_t* matched,
+                                  int32_t* matches, int32_t* nmatches)
+{
+    if (!c || bad_view(kf, false) || !Scw || n_mp < 0 || !matched || !matches || !nmatches || !kf->scale_factors ||
+        (n_mp && (!world || !normal || !maxd || !mind || !desc))) { set_error("olf_search_by_projection_sim3: bad argument"); return OLF_ERR_INVALID; }
+    float R[9], t[3], ow[3];
+    sim3_decompose(Scw, R, t, ow);
+    for (int i = 0; i < kf->n; ++i) matches[i] = -1;
+    return fuse_core(c, "olf_search_by_projection_sim3", kf, R, t, ow, n_mp, skip, world, normal, maxd, mind, desc, th, false, 256, nullptr, nullptr,
+                     matched, matches, nmatches);
 }
 
 int olf_search_by_sim3(olf_ctx* c, const olf_frame_view* kf1, const olf_frame_view* kf2, int32_t* matches12, float s12, const float* R12,

@@ -270,6 +270,22 @@ def _search_by_projection(self, CurrentFrame, LastFrame, th, bMono):
     return int(n[0]), matches
 
 
+def _search_by_projection_match12(self, CurrentFrame, LastFrame, th, bMono, match12):
+    """int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, map<int,int>& match12),
+    src/ORBmatcher.cc:1474-1618 (Tracking::TrackWithMotionModelWithLine, src/Tracking.cc:1296,1302) -> olf_search_by_projection_match12.
+    `match12` (a dict) is cleared and filled like the reference's map: key = CurrentFrame feature, value = the FIRST LastFrame feature it was
+    matched with; keys in ascending order, as a std::map iterates.  Returns (nmatches, matches) like the four-argument overload."""
+    keep = []
+    cur, last = _view_c(CurrentFrame, keep), _view_c(LastFrame, keep)
+    matches, m12, n = np.full(CurrentFrame.N, -1, np.int32), np.full(CurrentFrame.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_projection_match12(_ctx(self._context).handle, cur, last, float(th), int(bool(bMono)), int(bool(self.mbCheckOrientation)),
+                                                 ptr(matches), ptr(m12), ptr(n)), "olf_search_by_projection_match12")
+    match12.clear()
+    for i2 in np.nonzero(m12 >= 0)[0]:
+        match12[int(i2)] = int(m12[i2])
+    return int(n[0]), matches
+
+
 def _search_for_initialization(self, F1, F2, vbPrevMatched, windowSize=10):
     """int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12,
     int windowSize), src/ORBmatcher.cc:407-522 (monocular initialisation) -> olf_search_for_initialization.  vbPrevMatched: float32 [N1, 2],
@@ -363,15 +379,18 @@ def _search_by_projection_kf(self, CurrentFrame, pKF, sAlreadyFound, th, ORBdist
 
 
 def _search_by_projection_dispatch(self, a, b, *args):
-    """The reference overloads SearchByProjection on the second argument: a Frame (:1330), a vector<MapPoint*> (:47) or a KeyFrame* (:1620)."""
+    """The reference overloads SearchByProjection on the second argument: a Frame (:1330; with a trailing map<int,int>& match12 :1474), a
+    vector<MapPoint*> (:47) or a KeyFrame* (:1620; with a cv::Mat Scw first :292 -- see SearchByProjectionSim3)."""
     if isinstance(b, KeyFrameView):
         return _search_by_projection_kf(self, a, b, *args)
     return _search_by_projection_dispatch2(self, a, b, *args)
 
 
-def _search_by_projection_dispatch2(self, a, b, th=1.0, bMono=False):
+def _search_by_projection_dispatch2(self, a, b, th=1.0, bMono=False, match12=None):
     if isinstance(b, MapPointView):
         return _search_local_map(self, a, b, th)
+    if match12 is not None:
+        return _search_by_projection_match12(self, a, b, th, bMono, match12)
     return _search_by_projection(self, a, b, th, bMono)
 
 
@@ -481,6 +500,29 @@ def _fuse_search_sim3(self, pKF, Scw, vpPoints, th):
     check(lib().olf_fuse_search_sim3(_ctx(self._context).handle, kf, ptr(S), mp.n, *(ptr(x) for x in arrs), float(th), ptr(bi), ptr(bd)),
           "olf_fuse_search_sim3")
     return bi, bd.astype(np.int64)
+
+
+def _search_by_projection_sim3(self, pKF, Scw, vpPoints, vpMatched, th):
+    """int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
+    src/ORBmatcher.cc:292-405 (LoopClosing::ComputeSim3, src/LoopClosing.cc:381) -> olf_search_by_projection_sim3.  vpPoints: MapPointView with
+    skip = isBad() || (the point is already in vpMatched); vpMatched: bool array over pKF's key points (vpMatched[idx] != NULL), updated in
+    place.  Returns (nmatches, matches) with matches[idx] = index into vpPoints that key point idx received (-1 = none)."""
+    mp = vpPoints
+    keep = []
+    kf = _view_c(pKF, keep)
+    a = np.ascontiguousarray
+    S = a(Scw, np.float32).reshape(16)
+    arrs = [a(mp.skip, np.uint8), a(mp.world, np.float32), a(mp.normal, np.float32), a(mp.maxd, np.float32), a(mp.mind, np.float32),
+            a(mp.descriptor, np.uint8)]
+    if not (isinstance(vpMatched, np.ndarray) and vpMatched.dtype == np.bool_ and vpMatched.flags.c_contiguous and len(vpMatched) == pKF.N):
+        raise ValueError("vpMatched: a C-contiguous bool array with one entry per key point of pKF (updated in place)")
+    matches, n = np.full(pKF.N, -1, np.int32), np.zeros(1, np.int32)
+    check(lib().olf_search_by_projection_sim3(_ctx(self._context).handle, kf, ptr(S), mp.n, *(ptr(x) for x in arrs), float(th), vpMatched.ctypes.data,
+                                              ptr(matches), ptr(n)), "olf_search_by_projection_sim3")
+    return int(n[0]), matches
+
+
+ORBmatcher.SearchByProjectionSim3 = _search_by_projection_sim3
 
 
 def _search_by_sim3(self, pKF1, pKF2, vpMatches12, s12, R12, t12, th):

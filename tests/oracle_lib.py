@@ -234,6 +234,22 @@ def search_by_projection(cur, last, th, bMono=False, checkOri=True):
     return n, matches
 
 
+def search_by_projection_match12(cur, last, th, bMono=False, checkOri=True):
+    """the overload with map<int,int>& match12 (src/ORBmatcher.cc:1474-1618) -> (nmatches, matches, [(key, value), ...] in map order, mp_valid after)"""
+    cv, co = cur.mp_valid.astype(np.uint8).copy(), cur.mp_obs.astype(np.uint8).copy()
+    cam = np.array([cur.fx, cur.fy, cur.cx, cur.cy, cur.mbf, cur.mnMinX, cur.mnMaxX, cur.mnMinY, cur.mnMaxY], np.float32)
+    matches = np.full(cur.N, -1, np.int32)
+    pairs, npairs = np.zeros((max(cur.N, 1), 2), np.int32), C.c_int()
+    a = lambda x, dt=None: np.ascontiguousarray(x if dt is None else x.astype(dt))
+    args = [a(cur.mvKeysUn), a(cur.mDescriptors), a(cur.mvuRight), None, cv, co, a(cur.mTcw), a(last.mvKeysUn), None, a(last.mp_valid, np.uint8),
+            a(last.mp_world), a(last.mp_desc), a(last.mp_obs, np.uint8), a(last.mvbOutlier, np.uint8), a(last.mTcw), cam, a(cur.mvScaleFactors)]
+    _L.orc_search_by_projection_match12.restype = C.c_int
+    n = _L.orc_search_by_projection_match12(_p(args[0]), _p(args[1]), _p(args[2]), cur.N, _p(cv), _p(co), _p(args[6]), _p(args[7]), last.N, _p(args[9]),
+                                            _p(args[10]), _p(args[11]), _p(args[12]), _p(args[13]), _p(args[14]), _p(cam), _p(args[16]), C.c_float(th),
+                                            int(bMono), int(checkOri), _p(matches), _p(pairs), C.byref(npairs))
+    return n, matches, [tuple(r) for r in pairs[:npairs.value]], cv
+
+
 def search_for_initialization(f1, f2, prev_matched, window_size, nnratio, checkOri=True):
     """f1/f2: FrameView -> (nmatches, vnMatches12, updated vbPrevMatched)"""
     cam = np.array([f2.fx, f2.fy, f2.cx, f2.cy, f2.mbf, f2.mnMinX, f2.mnMaxX, f2.mnMinY, f2.mnMaxY], np.float32)
@@ -475,6 +491,20 @@ def fuse_search_sim3(kf, Scw, mp, th):
     _L.orc_fuse_search_sim3(_p(arrs[0]), _p(arrs[1]), kf.N, _p(arrs[2]), _p(cam), _p(sf), len(sf), _logsf(sf), mp.n, _p(arrs[3]), _p(arrs[4]),
                             _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), C.c_float(th), _p(bi), _p(bd))
     return bi, bd
+
+
+def search_by_projection_sim3(kf, Scw, mp, matched, th):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:292-405 -> (nmatches, kfMatch, matched after)"""
+    a = np.ascontiguousarray
+    cam, sf = _cam(kf), a(kf.mvScaleFactors)
+    m = a(matched.astype(np.uint8).copy())
+    km = np.full(kf.N, -1, np.int32)
+    arrs = [a(kf.mvKeysUn), a(kf.mDescriptors), a(Scw, np.float32), a(mp.skip.astype(np.uint8)), a(mp.world), a(mp.normal), a(mp.maxd), a(mp.mind),
+            a(mp.descriptor)]
+    _L.orc_search_by_projection_sim3.restype = C.c_int
+    n = _L.orc_search_by_projection_sim3(_p(arrs[0]), _p(arrs[1]), kf.N, _p(arrs[2]), _p(cam), _p(sf), len(sf), _logsf(sf), mp.n, _p(arrs[3]), _p(arrs[4]),
+                                         _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), int(th), _p(m), _p(km))
+    return n, km, m
 
 
 def search_by_sim3(kf1, kf2, matches12, s12, R12, t12, th):

@@ -49,6 +49,38 @@ def test_search_by_projection(oracle, th, bMono):
     assert n2 == n2o and np.array_equal(m2, m2o)
 
 
+@pytest.mark.parametrize("th,bMono,check", [(7, False, True), (14, False, False), (15, True, True)])
+def test_search_by_projection_match12(oracle, th, bMono, check):
+    """The overload Tracking::TrackWithMotionModelWithLine calls (src/ORBmatcher.cc:1474-1618, src/Tracking.cc:1296,1302): same search, plus the
+    map<int,int> match12.  Temporal points (map points without observations, Tracking::UpdateLastFrame) let a current feature be matched twice:
+    mvpMapPoints[i2] then keeps the LAST last-frame point while match12.insert keeps the FIRST -- the last frame's points are listed twice
+    here (second copy with perturbed descriptors and Observations() == 0 everywhere) so that this happens many times."""
+    last, cur = _frames(oracle)
+    n0 = last.N
+    two = copy.deepcopy(last)
+    for name in ("mvKeysUn", "mDescriptors", "mvuRight", "mp_valid", "mp_world", "mp_desc", "mp_obs", "mp_bad", "mvbOutlier"):
+        a = getattr(last, name)
+        setattr(two, name, np.concatenate([a, a]))
+    two.N, two.mvKeys = 2 * n0, two.mvKeysUn
+    two.mp_obs[:] = False                                    # every map point of the last frame is a temporal one
+    rng = np.random.default_rng(9)
+    flip = rng.integers(0, 256, (n0, 32)).astype(np.uint8) & rng.integers(0, 256, (n0, 32)).astype(np.uint8) & rng.integers(0, 256, (n0, 32)).astype(np.uint8) & 0x11
+    two.mp_desc[n0:] ^= flip                                 # a few bits: the second copy still matches the same current feature
+    two.mvKeysUn["angle"][n0:] = (two.mvKeysUn["angle"][n0:] + rng.choice([0.0, 0.0, 120.0], n0)).astype(np.float32) % 360   # some land in another rotation bin
+    cur.mTcw = np.eye(4, dtype=np.float32)
+    cur.mTcw[0, 3] = 0.02
+    cur_o = copy.deepcopy(cur)
+    n_o, m_o, pairs_o, valid_o = oracle.search_by_projection_match12(cur_o, two, th, bMono, checkOri=check)
+    m12 = {7: 7}
+    n_g, m_g = ola.ORBmatcher(0.9, check).SearchByProjection(cur, two, th, bMono, m12)
+    assert n_g == n_o and np.array_equal(m_g, m_o)
+    assert list(m12.items()) == pairs_o                      # same keys, same values, same (ascending) order
+    assert np.array_equal(cur.mp_valid.astype(np.uint8), valid_o)
+    differ = sum(1 for k, v in pairs_o if m_o[k] != v)
+    assert differ > 20, differ                               # insert-keeps-first really differs from the last assignment
+    assert n_g != len(pairs_o) or not check                  # nmatches counts both assignments of a twice-matched feature
+
+
 @pytest.mark.parametrize("window,ratio", [(100, 0.9), (30, 0.7), (10, 0.9)])
 def test_search_for_initialization(oracle, window, ratio):
     """SearchForInitialization (monocular initialisation, src/ORBmatcher.cc:407-522): level-0 key points only, greedy with re-assignment
@@ -252,6 +284,38 @@ def test_fuse_search_sim3(oracle, th, scale):
     bi_g, bd_g = ola.ORBmatcher(0.6, True).FuseSearchSim3(kf, Scw, mp, th)
     assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
     assert (bi_g >= 0).sum() > 200 and ((bd_g <= 50) & (bi_g >= 0)).sum() > 100
+
+
+@pytest.mark.parametrize("th,scale", [(10, 1.0), (4, 1.03)])
+def test_search_by_projection_sim3(oracle, th, scale):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:292-405, LoopClosing::ComputeSim3): greedy -- a key point taken by
+    an earlier point (or matched before the call) is passed over by the later ones.  Every map point is listed twice (the second copy with a
+    few descriptor bits flipped), so the second copy has to settle for another key point or for none."""
+    last, cur = _frames(oracle, seed=83)
+    kf = _as_kf(cur)
+    sel = np.flatnonzero(last.mp_valid)
+    rng = np.random.default_rng(37)
+    world = last.mp_world[sel].copy(); world[:, 0] += np.float32(3 * 0.54 / 718.856) * world[:, 2]
+    d = np.linalg.norm(world, axis=1).astype(np.float32)
+    lvl = last.mvKeysUn["octave"][sel].astype(np.float32)
+    maxd = (d * np.float32(1.2) ** lvl * rng.uniform(0.95, 1.05, len(sel))).astype(np.float32)
+    normal = (world / d[:, None] + rng.normal(0, 0.3, world.shape)).astype(np.float32)
+    desc2 = last.mDescriptors[sel].copy()
+    desc2[:, rng.integers(0, 32, 3)] ^= rng.integers(0, 256, (len(sel), 3)).astype(np.uint8) & 0x21
+    two = lambda a: np.concatenate([a, a])
+    mp = ola.MapPointGeom(two(world), two(normal), two(maxd), two(maxd) / np.float32(1.2) ** 7, np.concatenate([last.mDescriptors[sel], desc2]),
+                          skip=rng.random(2 * len(sel)) < 0.1)
+    R, t = _rot(0.002, -0.003, 0.001), np.array([0.01, -0.004, 0.02], np.float32)
+    Scw = np.eye(4, dtype=np.float32); Scw[:3, :3] = np.float32(scale) * R; Scw[:3, 3] = np.float32(scale) * t
+    mp.world = ((mp.world - t) @ R).astype(np.float32)
+    matched0 = rng.random(kf.N) < 0.15                                       # vpMatched as SearchByBoW left it
+    n_o, km_o, m_o = oracle.search_by_projection_sim3(kf, Scw, mp, matched0, th)
+    matched = matched0.copy()
+    n_g, km_g = ola.ORBmatcher(0.75, True).SearchByProjectionSim3(kf, Scw, mp, matched, th)
+    assert n_g == n_o and np.array_equal(km_g, km_o) and np.array_equal(matched.astype(np.uint8), m_o)
+    assert n_g > 100 and not (km_g[matched0] >= 0).any()
+    first, second = km_g[(km_g >= 0) & (km_g < len(sel))], km_g[km_g >= len(sel)]
+    assert len(second) > 10                                                  # second copies that found another key point: the greedy state matters
 
 
 @pytest.mark.parametrize("th,s12", [(7.5, 1.0), (10.0, 0.98)])
