@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <type_traits>
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -212,6 +213,20 @@ public:
     template <class KeyFrameT, class FrameT, class MapPointT> int SearchByBoW(KeyFrameT* pKF, FrameT& F, std::vector<MapPointT*>& vpMapPointMatches);
     template <class FrameT, class Point2fT> int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Point2fT>& vbPrevMatched, std::vector<int>& vnMatches12,
                                                                         int windowSize = 10);
+    // the rest of include/ORBmatcher.h:37-103 (Tracking.cc:1296,1302,2322,2336; LocalMapping.cc:268,489,514; LoopClosing.cc:271,329,381,605)
+    template <class FrameT> int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, std::map<int, int>& match12);
+    template <class FrameT, class KeyFrameT, class MapPointT>
+    int SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist);
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int SearchByProjection(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th);
+    template <class KeyFrameT, class MapPointT> int SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12);
+    template <class KeyFrameT, class MatT>
+    int SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, MatT F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo);
+    template <class KeyFrameT, class MapPointT> int Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th = 3.0);
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int Fuse(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint);
+    template <class KeyFrameT, class MatT, class MapPointT>
+    int SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const MatT& R12, const MatT& t12, const float th);
 
     // The members of the reference's MapPoints read by SearchByProjection(Frame&, const vector<MapPoint*>&, th), gathered into arrays
     struct TrackedMapPoints {

@@ -1,6 +1,7 @@
 // orbline_reference_api.hpp -- the reference's OWN call signatures on top of the C ABI, so that the call sites of Tracking.cc need no edit:
 //
-//   matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, bMono)                 src/Tracking.cc:1296,1302   (include/ORBmatcher.h:52)
+//   matcher.SearchByProjection(mCurrentFrame, mLastFrame, th, bMono, match12)        src/Tracking.cc:1296,1302   (include/ORBmatcher.h:53; the
+//                                                                                    four-argument form :52 as well)
 //   matcher.SearchByBoW(mpReferenceKF, mCurrentFrame, vpMapPointMatches)             src/Tracking.cc:970         (include/ORBmatcher.h:66)
 //   matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th)                 src/Tracking.cc:1941        (include/ORBmatcher.h:48)
 //   match(mLastFrame.mDescriptors_Line, mCurrentFrame.mDescriptors_Line, nnr, m12)   src/Tracking.cc:1308, :979  (include/LineMatcher.h:61)
@@ -8,6 +9,10 @@
 //   matchGrid(points1 | lines1, desc1, grid, desc2, [directions2,] w, matches_12)    src/Frame.cc:926            (include/LineMatcher.h:66-69)
 //   GridStructure / GridWindow / getLineCoords                                       include/gridStructure.h:33-58
 //   StereoFrameFeatures(frame, imLeft, imRight)  = the feature part of Frame::Frame  src/Frame.cc:164-171,199-207
+//   and every other ORBmatcher call of the reference: SearchByProjection(cur, pKF, sFound, th, ORBdist) Tracking.cc:2322,2336;
+//   SearchForTriangulation LocalMapping.cc:268; Fuse(pKF, vpMapPoints[, th]) LocalMapping.cc:489,514; SearchByBoW(pKF1, pKF2, vpMatches12)
+//   LoopClosing.cc:271; SearchBySim3 LoopClosing.cc:329; SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) LoopClosing.cc:381;
+//   Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) LoopClosing.cc:605; SearchForInitialization Tracking.cc:628
 //
 // Everything is a template over the reference's types (Frame, KeyFrame, MapPoint, MapLine, cv::Mat), used only through the public members
 // the reference functions themselves read (include/Frame.h:137-260, include/KeyFrame.h, include/MapPoint.h): the header compiles without
@@ -20,6 +25,8 @@
 #pragma once
 #include <cmath>
 #include <list>
+#include <map>
+#include <set>
 #include <unordered_set>
 #include <limits>
 #include <type_traits>
@@ -204,6 +211,268 @@ template <class KeyFrameT, class FrameT, class MapPointT> int ORBmatcher::Search
         for (int iF = 0; iF < F.N; ++iF) if (m[iF] >= 0) vpMapPointMatches[iF] = vpMapPointsKF[m[iF]];
         return n;
     }
+}
+
+// ---- the rest of the ORBmatcher surface (include/ORBmatcher.h:37-103): the searches of the relocaliser, LocalMapping and LoopClosing ----------
+namespace olf_detail {
+
+// MapPoint::mfMaxDistance / mfMinDistance are protected in the reference (include/MapPoint.h:145-146); the searches need the raw values
+// (PredictScale divides mfMaxDistance by the distance, src/MapPoint.cc:397-412).  Inside the reference tree either declare
+//     friend struct ORB_SLAM2::olf_detail::MapPointDistances;
+// in class MapPoint (one line) -- then the members are read directly -- or nothing: the fall-back inverts the public
+// GetMaxDistanceInvariance() = 1.2f * mfMaxDistance / GetMinDistanceInvariance() = 0.8f * mfMinDistance by searching the floats around the
+// quotient for one whose product reproduces the returned value (exact except where two neighbouring floats share a product).
+struct MapPointDistances {
+    template <class MP> static auto maxd(MP* p, int) -> decltype((float)p->mfMaxDistance) { return p->mfMaxDistance; }
+    template <class MP> static float maxd(MP* p, long) { return invert(p->GetMaxDistanceInvariance(), 1.2f); }
+    template <class MP> static auto mind(MP* p, int) -> decltype((float)p->mfMinDistance) { return p->mfMinDistance; }
+    template <class MP> static float mind(MP* p, long) { return invert(p->GetMinDistanceInvariance(), 0.8f); }
+    static float invert(float y, float k)
+    {
+        float x = y / k;
+        for (int pass = 0; pass < 2; ++pass) {
+            float c = x;
+            for (int s = 0; s < 3 && !(k * c == y); ++s) c = std::nextafter(c, pass ? 3.4e38f : -3.4e38f);
+            if (k * c == y) return c;
+        }
+        return x;
+    }
+};
+
+template <class MatT> void mat4(const MatT& m, float* out16) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out16[4 * r + c] = m.template at<float>(r, c); }
+
+// The members of a reference KeyFrame read by the key-frame searches (include/KeyFrame.h:57-62,92-116,185-231)
+template <class KeyFrameT> struct KeyFrameGather {
+    typedef typename std::remove_pointer<typename decltype(std::declval<KeyFrameT&>().GetMapPointMatches())::value_type>::type MapPointT;
+    olf_frame_view v;
+    std::vector<MapPointT*> mps;
+    std::vector<uint8_t> valid, obs, bad, mpdesc;
+    std::vector<float> world, maxd, mind;
+    float Tcw[16];
+    DescRows<decltype(KeyFrameT::mDescriptors)> desc;
+    FeatVecCSR fv;
+    KeyFrameGather(KeyFrameT* pKF, bool with_points) : mps(pKF->GetMapPointMatches()), desc(pKF->mDescriptors), fv(pKF->mFeatVec)
+    {
+        v = olf_frame_view();
+        const int n = (int)mps.size();
+        v.keys = keypoints(pKF->mvKeysUn); v.desc = desc.p; v.uright = pKF->mvuRight.empty() ? nullptr : pKF->mvuRight.data(); v.n = n;
+        valid.assign(n, 0); obs.assign(n, 0); bad.assign(n, 0);
+        if (with_points) { world.assign((size_t)3 * n, 0.f); mpdesc.assign((size_t)32 * n, 0); maxd.assign(n, 0.f); mind.assign(n, 0.f); }
+        for (int i = 0; i < n; ++i) {
+            MapPointT* pMP = mps[i];
+            if (!pMP) continue;
+            valid[i] = 1; obs[i] = pMP->Observations() > 0 ? 1 : 0; bad[i] = pMP->isBad() ? 1 : 0;
+            if (with_points) {
+                const auto wp = pMP->GetWorldPos();
+                for (int k = 0; k < 3; ++k) world[3 * i + k] = wp.template at<float>(k);
+                const auto d = pMP->GetDescriptor();
+                std::memcpy(&mpdesc[(size_t)32 * i], d.data, 32);
+                maxd[i] = MapPointDistances::maxd(pMP, 0); mind[i] = MapPointDistances::mind(pMP, 0);
+            }
+        }
+        v.mp_valid = valid.data(); v.mp_obs = obs.data(); v.mp_bad = bad.data();
+        if (with_points) { v.mp_world = world.data(); v.mp_desc = mpdesc.data(); v.mp_maxd = maxd.data(); v.mp_mind = mind.data(); }
+        mat4(pKF->GetPose(), Tcw); v.Tcw = Tcw;
+        v.fx = pKF->fx; v.fy = pKF->fy; v.cx = pKF->cx; v.cy = pKF->cy; v.mbf = pKF->mbf;
+        v.minX = (float)pKF->mnMinX; v.maxX = (float)pKF->mnMaxX; v.minY = (float)pKF->mnMinY; v.maxY = (float)pKF->mnMaxY;
+        v.scale_factors = pKF->mvScaleFactors.data(); v.n_levels = pKF->mnScaleLevels;
+        fv.attach(v);
+    }
+};
+
+// the members of a list of reference MapPoints read by the two Fuse searches and SearchByProjection(pKF, Scw, ...)
+template <class MapPointT> struct PointGather {
+    std::vector<uint8_t> skip, desc;
+    std::vector<float> world, normal, maxd, mind;
+    ORBmatcher::FuseMapPoints m;
+    template <class SkipFn> PointGather(const std::vector<MapPointT*>& pts, SkipFn skip_if)
+    {
+        const size_t n = pts.size();
+        skip.assign(n, 1); desc.assign(32 * n, 0); world.assign(3 * n, 0.f); normal.assign(3 * n, 0.f); maxd.assign(n, 0.f); mind.assign(n, 0.f);
+        for (size_t i = 0; i < n; ++i) {
+            MapPointT* p = pts[i];
+            if (!p || skip_if(p)) continue;
+            skip[i] = 0;
+            const auto w = p->GetWorldPos(); const auto nv = p->GetNormal(); const auto d = p->GetDescriptor();
+            for (int k = 0; k < 3; ++k) { world[3 * i + k] = w.template at<float>(k); normal[3 * i + k] = nv.template at<float>(k); }
+            std::memcpy(&desc[32 * i], d.data, 32);
+            maxd[i] = MapPointDistances::maxd(p, 0); mind[i] = MapPointDistances::mind(p, 0);
+        }
+        m.n = (int)n; m.skip = skip.data(); m.world = world.data(); m.normal = normal.data(); m.mfMaxDistance = maxd.data(); m.mfMinDistance = mind.data();
+        m.descriptor = desc.data();
+    }
+};
+}  // namespace olf_detail
+
+// int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, map<int,int>& match12),
+// src/ORBmatcher.cc:1474-1618 (Tracking::TrackWithMotionModelWithLine, src/Tracking.cc:1296,1302)
+template <class FrameT> int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono, std::map<int, int>& match12)
+{
+    olf_detail::FrameGather<FrameT> cur(CurrentFrame, false), last(LastFrame, true);
+    const std::vector<uint8_t> before = cur.valid;
+    std::vector<int32_t> m(CurrentFrame.N, -1), first(CurrentFrame.N, -1);
+    int32_t n = 0;
+    olf_detail::check(olf_search_by_projection_match12(olf_detail::thread_ctx(), &cur.v, &last.v, th, bMono ? 1 : 0, mbCheckOrientation ? 1 : 0, m.data(),
+                                                       first.data(), &n), "olf_search_by_projection_match12");
+    match12.clear();
+    for (int i2 = 0; i2 < CurrentFrame.N; ++i2) {
+        if (m[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[m[i2]];              // the LAST point assigned (:1575)
+        else if (before[i2] && !cur.valid[i2]) CurrentFrame.mvpMapPoints[i2] = nullptr;             // dropped by the rotation histogram (:1610)
+        if (first[i2] >= 0) match12.insert(match12.end(), std::pair<int, int>(i2, first[i2]));      // the FIRST one inserted (:1577)
+    }
+    return n;
+}
+
+// int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist),
+// src/ORBmatcher.cc:1620-1747 (Tracking::Relocalization, src/Tracking.cc:2322,2336)
+template <class FrameT, class KeyFrameT, class MapPointT>
+int ORBmatcher::SearchByProjection(FrameT& CurrentFrame, KeyFrameT* pKF, const std::set<MapPointT*>& sAlreadyFound, const float th, const int ORBdist)
+{
+    olf_detail::FrameGather<FrameT> cur(CurrentFrame, false);
+    olf_detail::KeyFrameGather<KeyFrameT> kf(pKF, true);
+    const std::vector<uint8_t> before = cur.valid;
+    std::vector<uint8_t> found(kf.mps.size(), 0);
+    for (size_t i = 0; i < kf.mps.size(); ++i) found[i] = kf.mps[i] && sAlreadyFound.count(kf.mps[i]) ? 1 : 0;
+    std::vector<int32_t> m;
+    const int n = SearchByProjection(olf_detail::thread_ctx(), cur.v, kf.v, found.data(), th, ORBdist, m);
+    for (int i2 = 0; i2 < CurrentFrame.N; ++i2) {
+        if (m[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = kf.mps[m[i2]];
+        else if (before[i2] && !cur.valid[i2]) CurrentFrame.mvpMapPoints[i2] = nullptr;
+    }
+    return n;
+}
+
+// int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th),
+// src/ORBmatcher.cc:292-405 (LoopClosing::ComputeSim3, src/LoopClosing.cc:381)
+template <class KeyFrameT, class MatT, class MapPointT>
+int ORBmatcher::SearchByProjection(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, std::vector<MapPointT*>& vpMatched, int th)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> kf(pKF, false);
+    std::set<MapPointT*> spAlreadyFound(vpMatched.begin(), vpMatched.end());
+    spAlreadyFound.erase(static_cast<MapPointT*>(nullptr));
+    const olf_detail::PointGather<MapPointT> pts(vpPoints, [&](MapPointT* p) { return p->isBad() || spAlreadyFound.count(p) != 0; });
+    float S[16];
+    olf_detail::mat4(Scw, S);
+    std::vector<uint8_t> matched(vpMatched.size(), 0);
+    for (size_t i = 0; i < vpMatched.size(); ++i) matched[i] = vpMatched[i] ? 1 : 0;
+    if ((int)matched.size() != kf.v.n) throw std::runtime_error("SearchByProjection(pKF, Scw, ...): vpMatched must have one entry per key point of pKF");
+    std::vector<int32_t> m(kf.v.n, -1);
+    int32_t n = 0;
+    olf_detail::check(olf_search_by_projection_sim3(olf_detail::thread_ctx(), &kf.v, S, pts.m.n, pts.m.skip, pts.m.world, pts.m.normal, pts.m.mfMaxDistance,
+                                                    pts.m.mfMinDistance, pts.m.descriptor, (float)th, matched.data(), m.data(), &n),
+                      "olf_search_by_projection_sim3");
+    for (int idx = 0; idx < kf.v.n; ++idx) if (m[idx] >= 0) vpMatched[idx] = vpPoints[m[idx]];
+    return n;
+}
+
+// int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:524-657 (LoopClosing.cc:271)
+template <class KeyFrameT, class MapPointT> int ORBmatcher::SearchByBoW(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> k1(pKF1, false), k2(pKF2, false);
+    std::vector<int32_t> m;
+    const int n = SearchByBoW(olf_detail::thread_ctx(), KeyFramePair(), k1.v, k2.v, m);
+    vpMatches12 = std::vector<MapPointT*>(k1.mps.size(), static_cast<MapPointT*>(nullptr));
+    for (size_t i = 0; i < k1.mps.size(); ++i) if (m[i] >= 0) vpMatches12[i] = k2.mps[m[i]];
+    return n;
+}
+
+// int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo),
+// src/ORBmatcher.cc:659-825 (LocalMapping::CreateNewMapPoints, src/LocalMapping.cc:268)
+template <class KeyFrameT, class MatT>
+int ORBmatcher::SearchForTriangulation(KeyFrameT* pKF1, KeyFrameT* pKF2, MatT F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> k1(pKF1, false), k2(pKF2, false);
+    float F[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) F[3 * r + c] = F12.template at<float>(r, c);
+    const auto Cw = pKF1->GetCameraCenter();
+    const float cw[3] = {Cw.template at<float>(0), Cw.template at<float>(1), Cw.template at<float>(2)};
+    std::vector<int32_t> m12(k1.v.n, -1);
+    int32_t n = 0;
+    olf_detail::check(olf_search_for_triangulation(olf_detail::thread_ctx(), &k1.v, &k2.v, F, cw, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0, m12.data(), &n),
+                      "olf_search_for_triangulation");
+    vMatchedPairs.clear();
+    vMatchedPairs.reserve(n > 0 ? n : 0);
+    for (int i = 0; i < k1.v.n; ++i) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)m12[i]));
+    return n;
+}
+
+// int Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, const float th = 3.0), src/ORBmatcher.cc:827-975 (LocalMapping.cc:489,514).
+// The search of every point runs first (one call); what the reference does with a hit (:950-972: Replace / AddObservation / AddMapPoint) is
+// replayed on the reference's own objects in list order.  A hit's (bestIdx, bestDist) depends on nothing that loop changes; whether a point
+// is looked at does (isBad() / IsInKeyFrame(pKF) after an earlier Replace or AddObservation), so that gate is evaluated again at its turn.
+template <class KeyFrameT, class MapPointT> int ORBmatcher::Fuse(KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> kf(pKF, false);
+    const olf_detail::PointGather<MapPointT> pts(vpMapPoints, [&](MapPointT* p) { return p->isBad() || p->IsInKeyFrame(pKF); });
+    const auto Ow = pKF->GetCameraCenter();
+    const float ow[3] = {Ow.template at<float>(0), Ow.template at<float>(1), Ow.template at<float>(2)};
+    std::vector<int32_t> bestIdx(pts.m.n, -1), bestDist(pts.m.n, 256);
+    olf_detail::check(olf_fuse_search(olf_detail::thread_ctx(), &kf.v, pts.m.n, pts.m.skip, pts.m.world, pts.m.normal, pts.m.mfMaxDistance, pts.m.mfMinDistance,
+                                      pts.m.descriptor, th, ow, bestIdx.data(), bestDist.data()), "olf_fuse_search");
+    int nFused = 0;
+    for (size_t i = 0; i < vpMapPoints.size(); ++i) {
+        MapPointT* pMP = vpMapPoints[i];
+        if (!pMP || pts.skip[i] || bestDist[i] > TH_LOW) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+        MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx[i]);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
+        } else {
+            pMP->AddObservation(pKF, bestIdx[i]);
+            pKF->AddMapPoint(pMP, bestIdx[i]);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+
+// int Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, float th, vector<MapPoint*> &vpReplacePoint),
+// src/ORBmatcher.cc:977-1102 (LoopClosing::SearchAndFuse, src/LoopClosing.cc:605)
+template <class KeyFrameT, class MatT, class MapPointT>
+int ORBmatcher::Fuse(KeyFrameT* pKF, MatT Scw, const std::vector<MapPointT*>& vpPoints, float th, std::vector<MapPointT*>& vpReplacePoint)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> kf(pKF, false);
+    const std::set<MapPointT*> spAlreadyFound = pKF->GetMapPoints();
+    const olf_detail::PointGather<MapPointT> pts(vpPoints, [&](MapPointT* p) { return p->isBad() || spAlreadyFound.count(p) != 0; });
+    float S[16];
+    olf_detail::mat4(Scw, S);
+    std::vector<int32_t> bestIdx, bestDist;
+    FuseSearch(olf_detail::thread_ctx(), kf.v, S, pts.m, th, bestIdx, bestDist);
+    int nFused = 0;
+    for (size_t iMP = 0; iMP < vpPoints.size(); ++iMP) {
+        MapPointT* pMP = vpPoints[iMP];
+        if (!pMP || pts.skip[iMP] || bestDist[iMP] > TH_LOW) continue;
+        MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx[iMP]);
+        if (pMPinKF) { if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF; }
+        else { pMP->AddObservation(pKF, bestIdx[iMP]); pKF->AddMapPoint(pMP, bestIdx[iMP]); }
+        nFused++;
+    }
+    return nFused;
+}
+
+// int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12,
+// const float th), src/ORBmatcher.cc:1104-1328 (LoopClosing::ComputeSim3, src/LoopClosing.cc:329)
+template <class KeyFrameT, class MatT, class MapPointT>
+int ORBmatcher::SearchBySim3(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12, const float& s12, const MatT& R12, const MatT& t12, const float th)
+{
+    olf_detail::KeyFrameGather<KeyFrameT> k1(pKF1, true), k2(pKF2, true);
+    const int N1 = k1.v.n;
+    std::vector<int32_t> m12(N1, -1);
+    for (int i = 0; i < N1 && i < (int)vpMatches12.size(); ++i) {
+        MapPointT* pMP = vpMatches12[i];
+        if (!pMP) continue;
+        const int idx2 = pMP->GetIndexInKeyFrame(pKF2);          // (:1139-1151)
+        m12[i] = idx2 >= 0 ? idx2 : -2;
+    }
+    float R[9], t[3];
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = R12.template at<float>(r, c); t[r] = t12.template at<float>(r); }
+    const std::vector<int32_t> before = m12;
+    const int n = SearchBySim3(olf_detail::thread_ctx(), k1.v, k2.v, m12, s12, R, t, th);
+    for (int i1 = 0; i1 < N1; ++i1) if (m12[i1] >= 0 && m12[i1] != before[i1]) vpMatches12[i1] = k2.mps[m12[i1]];      // (:1319)
+    return n;
 }
 
 // ---- LineMatcher free functions (include/LineMatcher.h:57-69) --------------------------------------------------------------------------

@@ -8,7 +8,9 @@
 #include <array>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <map>
+#include <set>
 
 namespace standin {
 // the members of cv::Mat the adaptor touches
@@ -36,10 +38,27 @@ struct Mat {
 typedef olf_keypoint KeyPoint;          // layout of cv::KeyPoint
 typedef olf_keyline KeyLine;            // layout of cv::line_descriptor::KeyLine
 
+struct KeyFrame;
 struct MapPoint {
-    Mat world, desc;
+    Mat world, desc, normal;
     bool bad = false;
     int nobs = 1;
+    std::map<KeyFrame*, size_t> observers;
+    MapPoint* replaced = nullptr;
+    Mat GetNormal() const { return normal; }
+    bool IsInKeyFrame(KeyFrame* k) const { return observers.count(k) != 0; }
+    int GetIndexInKeyFrame(KeyFrame* k) const { auto it = observers.find(k); return it == observers.end() ? -1 : (int)it->second; }
+    void AddObservation(KeyFrame* k, size_t idx) { if (!observers.count(k)) { observers[k] = idx; ++nobs; } }
+    void Replace(MapPoint* p) { bad = true; replaced = p; }
+    // only the public accessors of the reference (mfMaxDistance / mfMinDistance are protected there): the templates have to invert them
+    float GetMaxDistanceInvariance() const { return 1.2f * maxDistance; }
+    float GetMinDistanceInvariance() const { return 0.8f * minDistance; }
+    float rawMax() const { return maxDistance; }
+    float rawMin() const { return minDistance; }
+    void setDistances(float mx, float mn) { maxDistance = mx; minDistance = mn; }
+private:
+    float maxDistance = 0.f, minDistance = 0.f;
+public:
     bool mbTrackInView = false;
     int mnTrackScaleLevel = 0;
     float mTrackViewCos = 1.f, mTrackProjX = 0.f, mTrackProjY = 0.f, mTrackProjXR = -1.f;
@@ -77,11 +96,23 @@ float Frame::fx = 718.856f, Frame::fy = 718.856f, Frame::cx = 607.19f, Frame::cy
 float Frame::mnMinX = 0.f, Frame::mnMaxX = 1242.f, Frame::mnMinY = 0.f, Frame::mnMaxY = 375.f;
 
 struct KeyFrame {
+    int N = 0;
     std::vector<KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight;
     Mat mDescriptors;
     FeatureVector mFeatVec;
     std::vector<MapPoint*> mps;
-    std::vector<MapPoint*> GetMapPointMatches() const { return mps; }
+    float fx = 718.856f, fy = 718.856f, cx = 607.19f, cy = 185.2f, mbf = 386.1448f;
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 1242, mnMaxY = 375;
+    int mnScaleLevels = 8;
+    std::vector<float> mvScaleFactors;
+    Mat Tcw;
+    std::vector<MapPoint*> GetMapPointMatches() { return mps; }
+    MapPoint* GetMapPoint(size_t idx) { return mps[idx]; }
+    std::set<MapPoint*> GetMapPoints() { std::set<MapPoint*> s; for (MapPoint* p : mps) if (p && !p->bad) s.insert(p); return s; }
+    void AddMapPoint(MapPoint* p, size_t idx) { mps[idx] = p; }
+    Mat GetPose() { return Tcw; }
+    Mat GetCameraCenter() { Mat c; c.create(3, 1, 5); for (int r = 0; r < 3; ++r) { float a = 0; for (int k = 0; k < 3; ++k) a -= Tcw.at<float>(k, r) * Tcw.at<float>(k, 3); c.at<float>(r) = a; } return c; }
 };
 }  // namespace standin
 
@@ -183,6 +214,139 @@ int main()
             for (int i = 0; i < n; ++i) if (ini12[i] >= 0 && (ini12[i] != i || prev[i].x != cur.mvKeysUn[i].x || cur.mvKeysUn[i].octave > 0)) return 31;
         }
     }
+    // ---- the rest of the ORBmatcher surface (include/ORBmatcher.h:37-103) through the reference's own signatures ----------------------------
+    {
+        // every pool point gets a normal, distances and a second descriptor-identical twin (for the two-frame overload with match12)
+        for (int i = 0; i < n; ++i) {
+            MapPoint& p = pool[i];
+            const float x = p.world.at<float>(0), y = p.world.at<float>(1), z = p.world.at<float>(2), d = std::sqrt(x * x + y * y + z * z);
+            p.normal.create(3, 1, 5);
+            p.normal.at<float>(0) = x / d; p.normal.at<float>(1) = y / d; p.normal.at<float>(2) = z / d;
+            const float mx = d * std::pow(1.2f, (float)cur.mvKeysUn[i].octave + 0.5f);         // PredictScale -> octave + 1: accepts the key point's octave
+            p.setDistances(mx, mx / std::pow(1.2f, 8.f));
+            p.observers.clear(); p.bad = false; p.nobs = 1;
+        }
+        auto make_kf = [&](KeyFrame& k, const Frame& F) {
+            k.N = F.N; k.mvKeysUn = F.mvKeysUn; k.mvuRight = F.mvuRight; k.mDescriptors = F.mDescriptors; k.mFeatVec = FeatureVector();
+            for (int i = 0; i < F.N; ++i) k.mFeatVec[(unsigned)(i % 10)].push_back((unsigned)i);
+            k.mps.assign(F.N, nullptr); k.mvScaleFactors = F.mvScaleFactors;
+            k.Tcw.create(4, 4, 5); for (int i = 0; i < 4; ++i) k.Tcw.at<float>(i, i) = 1.f;
+        };
+        // int SearchByProjection(Frame&, const Frame&, th, bMono, map<int,int>& match12)                          src/Tracking.cc:1296,1302
+        {
+            Frame c2; fill_frame(c2, n); c2.mvKeysUn = cur.mvKeysUn; c2.mDescriptors = cur.mDescriptors;
+            std::map<int, int> match12; match12[-5] = 1;
+            int n12 = -1;
+            try { n12 = matcher.SearchByProjection(c2, last, 7.f, false, match12); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (n12 != nm || (int)match12.size() != nm || match12.count(-5)) { std::printf("match12: %d matches, %d keys, want %d\n", n12, (int)match12.size(), nm); return 50; }
+                for (const auto& kv : match12) if (c2.mvpMapPoints[kv.first] != last.mvpMapPoints[kv.second]) return 51;
+            }
+        }
+        KeyFrame kA; make_kf(kA, cur);
+        for (int i = 0; i < n; ++i) if (i % 3) kA.mps[i] = &pool[i];
+        // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)   src/Tracking.cc:2322,2336
+        {
+            Frame c3; fill_frame(c3, n); c3.mvKeysUn = cur.mvKeysUn; c3.mDescriptors = cur.mDescriptors;
+            std::set<MapPoint*> sFound; sFound.insert(&pool[1]); sFound.insert(&pool[2]);
+            int nr = -1;
+            try { nr = matcher.SearchByProjection(c3, &kA, sFound, 10.f, 100); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (nr <= 0 || c3.mvpMapPoints[1] || c3.mvpMapPoints[2]) { std::printf("SearchByProjection(Frame, KeyFrame): %d\n", nr); return 52; }
+                for (int i = 0; i < n; ++i) if (c3.mvpMapPoints[i] && c3.mvpMapPoints[i] != &pool[i]) return 53;
+            }
+        }
+        // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th)                               src/LoopClosing.cc:381
+        Mat Scw; Scw.create(4, 4, 5); for (int i = 0; i < 4; ++i) Scw.at<float>(i, i) = 1.f;
+        {
+            KeyFrame kB; make_kf(kB, cur);
+            std::vector<MapPoint*> pts, matched(n, nullptr);
+            for (int i = 0; i < n; ++i) pts.push_back(&pool[i]);
+            matched[4] = &pool[4]; matched[5] = &pool[7];
+            int ns = -1;
+            try { ns = matcher.SearchByProjection(&kB, Scw, pts, matched, 10); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (ns <= 0 || matched[5] != &pool[7]) { std::printf("SearchByProjection(KeyFrame, Scw): %d\n", ns); return 54; }
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) { if (i != 5 && matched[i] && matched[i] != &pool[i]) return 55; cnt += matched[i] != nullptr; }
+                if (cnt != ns + 2) return 56;
+            }
+        }
+        // int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)                            src/LoopClosing.cc:271
+        KeyFrame kC; make_kf(kC, cur);
+        for (int i = 0; i < n; ++i) if (i % 2) kC.mps[i] = &pool[i];
+        {
+            std::vector<MapPoint*> v12;
+            int nk = -1;
+            try { nk = matcher.SearchByBoW(&kA, &kC, v12); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (nk <= 0 || (int)v12.size() != n) { std::printf("SearchByBoW(KF, KF): %d\n", nk); return 57; }
+                for (int i = 0; i < n; ++i) if (v12[i] && (v12[i] != &pool[i] || !kA.mps[i] || !kC.mps[i])) return 58;
+            }
+        }
+        // int SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)                                     src/LocalMapping.cc:268
+        {
+            KeyFrame k1, k2; make_kf(k1, cur); make_kf(k2, cur);
+            k2.Tcw.at<float>(0, 3) = -0.5f;                                   // a baseline along x: F12 = [t]x for identity rotations, rows of equal y match
+            Mat F12; F12.create(3, 3, 5);
+            F12.at<float>(1, 2) = -1.f; F12.at<float>(2, 1) = 1.f;
+            std::vector<std::pair<size_t, size_t>> pairs(3);
+            int nt = -1;
+            try { nt = matcher.SearchForTriangulation(&k1, &k2, F12, pairs, false); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (nt < 0 || (int)pairs.size() != nt) { std::printf("SearchForTriangulation: %d, %d pairs\n", nt, (int)pairs.size()); return 59; }
+                for (size_t k = 1; k < pairs.size(); ++k) if (pairs[k].first <= pairs[k - 1].first) return 60;      // idx1 ascending, as the reference builds the list
+            }
+        }
+        // int Fuse(pKF, vpMapPoints, th) and int Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)                          src/LocalMapping.cc:489, LoopClosing.cc:605
+        {
+            KeyFrame kF; make_kf(kF, cur);
+            MapPoint other; other.nobs = 5;
+            kF.mps[9] = &other;                                                // key point 9 already holds a point with more observations
+            std::vector<MapPoint*> pts;
+            for (int i = 0; i < n; ++i) pts.push_back(&pool[i]);
+            pts.push_back(nullptr);
+            int nf = -1;
+            try { nf = matcher.Fuse(&kF, pts, 3.f); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (nf <= 0) { std::printf("Fuse: %d\n", nf); return 61; }
+                int added = 0;
+                for (int i = 0; i < n; ++i) { if (i != 9 && kF.mps[i]) { if (kF.mps[i] != &pool[i] || !pool[i].IsInKeyFrame(&kF)) return 62; ++added; } }
+                if (!pool[9].bad || pool[9].replaced != &other || added + 1 != nf) { std::printf("Fuse: %d fused, %d added\n", nf, added); return 63; }
+                pool[9].bad = false; pool[9].replaced = nullptr;
+            }
+            for (int i = 0; i < n; ++i) { pool[i].observers.clear(); pool[i].nobs = 1; }
+            KeyFrame kG; make_kf(kG, cur);
+            kG.mps[11] = &other;
+            std::vector<MapPoint*> repl(pts.size(), nullptr);
+            int ng = -1;
+            pts.pop_back();
+            try { ng = matcher.Fuse(&kG, Scw, pts, 4.f, repl); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (ng <= 0 || repl[11] != &other) { std::printf("Fuse(Scw): %d\n", ng); return 64; }
+                for (int i = 0; i < n; ++i) if (i != 11 && kG.mps[i] && kG.mps[i] != &pool[i]) return 65;
+            }
+            for (int i = 0; i < n; ++i) { pool[i].observers.clear(); pool[i].nobs = 1; }
+        }
+        // int SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)                                                  src/LoopClosing.cc:329
+        {
+            KeyFrame k1, k2; make_kf(k1, cur); make_kf(k2, cur);
+            for (int i = 0; i < n; ++i) { k1.mps[i] = (i % 4) ? &pool[i] : nullptr; k2.mps[i] = (i % 5) ? &pool[i] : nullptr; if (k2.mps[i]) pool[i].observers[&k2] = (size_t)i; }
+            std::vector<MapPoint*> v12(n, nullptr);
+            v12[1] = &pool[1];                                                 // already matched (to key point 1 of k2)
+            Mat R12, t12; R12.create(3, 3, 5); t12.create(3, 1, 5);
+            for (int i = 0; i < 3; ++i) R12.at<float>(i, i) = 1.f;
+            int n3 = -1;
+            const float s12 = 1.f;
+            try { n3 = matcher.SearchBySim3(&k1, &k2, v12, s12, R12, t12, 7.5f); } catch (const std::runtime_error& e) { ++thrown; if (gpu) std::printf("threw: %s\n", e.what()); }
+            if (gpu) {
+                if (n3 <= 0) { std::printf("SearchBySim3: %d\n", n3); return 66; }
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) if (v12[i]) { if (v12[i] != &pool[i] || !k1.mps[i] || !k2.mps[i]) return 67; ++cnt; }
+                if (cnt != n3 + 1) return 68;
+            }
+        }
+    }
     // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b); int distance(const cv::Mat&, const cv::Mat&)     (host, no device)
     Mat zero(1, 32, 0), ones(1, 32, 0);
     for (int b = 0; b < 32; ++b) ones.data[b] = 0xff;
@@ -241,7 +405,7 @@ int main()
         Mat small(100, 100, 0);
         try { ORB_SLAM2::StereoFrameFeatures(F, L, small); return 26; } catch (const std::runtime_error&) {}      // size mismatch throws, src/Frame.cc:145-146
     }
-    if (!gpu && thrown != 8) { std::printf("no device: %d of 8 device calls threw\n", thrown); return 40; }
+    if (!gpu && thrown != 16) { std::printf("no device: %d of 16 device calls threw\n", thrown); return 40; }
     if (gpu && thrown != 0) return 41;
     std::printf(gpu ? "REFERENCE_API_OK %d %d %d\n" : "REFERENCE_API_COMPILED %d %d %d\n", nm, nl, nb);
     return 0;

@@ -211,8 +211,9 @@ def _build_reference_api(tmp_path):
 
 
 def test_reference_signatures_instantiate(tmp_path):
-    """include/orbline_reference_api.hpp: every template with the reference's own signature (ORBmatcher::SearchByProjection x2, SearchByBoW,
-    DescriptorDistance, match x2, matchNNR, distance, matchGrid x2, GridStructure, getLineCoords, StereoFrameFeatures) instantiates with
+    """include/orbline_reference_api.hpp: every template with the reference's own signature (all of include/ORBmatcher.h:37-103 -- SearchByProjection
+    x5, SearchByBoW x2, SearchForInitialization, SearchForTriangulation, Fuse x2, SearchBySim3, DescriptorDistance -- match x2, matchNNR, distance,
+    matchGrid x2, GridStructure, getLineCoords, StereoFrameFeatures) instantiates with
     stand-ins that carry the reference's member names, links, and -- without a device -- throws instead of falling back."""
     out = subprocess.run([_build_reference_api(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert out.returncode == 0 and b"REFERENCE_API_COMPILED" in out.stdout, out.stdout
