@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
     ap.add_argument("--seed-order", type=int, choices=(0, 1), default=None, help="convention C.9: order of the LSD seeds inside a gradient bin (default: the library's)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="N>1: nccl = RCCL over xGMI (device buffers); gloo = the same gather staged through host memory (lets 2 ranks share one GPU: the N>1 code path on a 1-GPU box)")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
     args = ap.parse_args()
 
@@ -165,13 +166,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()        # more ranks than GPUs only with --backend gloo (ranks then share a device)
+    if world > 1 and args.backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node (RCCL needs one device per rank; --backend gloo lets ranks share one)")
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")      # where the scalar reductions of the harness live
 
     cfg = CONFIGS[args.config]
     W, H = cfg["w"], cfg["h"]
@@ -185,7 +193,7 @@ def main():
         print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 64)}", file=sys.stderr, flush=True)
         B = max(fit, 64)
     if world > 1:
-        tb = torch.tensor([B], dtype=torch.int64, device=dev)
+        tb = torch.tensor([B], dtype=torch.int64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         B = int(tb.item())
     params = _lib.default_params()
@@ -288,7 +296,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

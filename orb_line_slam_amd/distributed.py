@@ -23,6 +23,20 @@ def gather_records(packed, nbytes, dist, dst=0, recv=None):
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = packed.device
+    if dist.get_backend() == "gloo" and packed.is_cuda:
+        # gloo moves host memory only: the same size exchange and point-to-point sends on a host copy of the record (the one-GPU test of the
+        # N > 1 path, bench.py --backend gloo; on a multi-GPU node the backend is RCCL and the device buffers go out as they are)
+        host = packed[:int(nbytes)].cpu()
+        recs, sizes = gather_records(host, nbytes, dist, dst, None)
+        if recs is not None:
+            for r in range(world):
+                if r == dst:
+                    recs[r] = packed[:sizes[r]]
+                elif recv is not None:
+                    recv[r][:sizes[r]].copy_(recs[r]); recs[r] = recv[r][:sizes[r]]
+                else:
+                    recs[r] = recs[r].to(dev)
+        return recs, sizes
     sizes_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes_t, torch.tensor([int(nbytes)], dtype=torch.int64, device=dev))
     sizes = [int(s.item()) for s in sizes_t]
