@@ -58,7 +58,8 @@ def source_hash():
 def algorithmic_bytes(W, H, N, NL, mean_len, nlevels=8, sf=1.2):
     """SURVEY.md Appendix D per image and stage, re-evaluated for this build's layouts (DESIGN.md "byte model"): LSD keeps the integer
     gradient pair (4 B/px) instead of fp32 modgrad + angle (8 B/px); the pseudo-sort reads it once and writes 4-byte keys; region growing
-    reads the gradient word (4) and reads + writes the used / owner state (2, as the reference's byte map)."""
+    reads the gradient word (4) and reads + writes the used / owner state (2, as the reference's byte map); the std::sort seed order (round 3) reads
+    the key of every pixel once more and writes the seed list (about a quarter of the pixels): 4 Ps + Ps."""
     lv, s = [], 1.0
     for _ in range(nlevels):
         lv.append((int(round(W / s)), int(round(H / s))))
@@ -67,7 +68,7 @@ def algorithmic_bytes(W, H, N, NL, mean_len, nlevels=8, sf=1.2):
     Pp, P0, P7 = sum(P), P[0], P[-1]
     Ps = int(round(W * 1.2)) * int(round(H * 1.2))
     st = {"orb_pyramid": P0 + (Pp - P0) + (Pp - P7), "orb_fast": Pp, "orb_octree": 0, "orb_blur": 2 * Pp, "orb_describe": (749 + 512 + 32 + 28) * N,
-          "stereo_points": 0, "lsd_front": 2 * P0 + (P0 + Ps) + (Ps + 4 * Ps) + (4 * Ps + 4 * Ps), "lsd_grow": (4 + 2) * Ps, "lsd_rect": 0,
+          "stereo_points": 0, "lsd_front": 2 * P0 + (P0 + Ps) + (Ps + 4 * Ps) + (4 * Ps + 4 * Ps) + (4 * Ps + Ps), "lsd_grow": (4 + 2) * Ps, "lsd_rect": 0,
           "line_select_lbd": 2 * P0 + (P0 + 4 * P0) + 63 * mean_len * 4 * NL + (32 + 68) * NL, "stereo_lines": 0, "match_bf": 0}
     orb = st["orb_pyramid"] + st["orb_fast"] + st["orb_blur"] + st["orb_describe"]
     lsd = st["lsd_front"] + st["lsd_grow"]
@@ -82,8 +83,11 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
     subprocess.run(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"], check=True)   # -march=native: always rebuilt on the box that runs it
     L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_fast.so"))
     from orb_line_slam_amd import synth
-    times, t_all, seed = [], time.time(), 1000
-    while True:
+    times, stages, t_all, seed = [], [], time.time(), 1000
+    L.orc_frame_stage_ms.argtypes = [C.c_void_p]
+    WARM, TIMED = 20, 200                       # at least 200 timed frames after 20 warm-up frames
+    st8 = np.zeros(8, np.float64)
+    while len(times) < WARM + TIMED:
         l, r = synth.stereo_pair(seed, W, H)
         seed += 1
         n = [C.c_int() for _ in range(4)]
@@ -93,24 +97,44 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
                                 None, None, C.byref(n[2]), None, None, C.byref(n[3]), 1 << 20, None, None, None)
         times.append(time.perf_counter() - t)
         assert rc == 0
-        if (time.time() - t_all > seconds_budget * 0.6 and len(times) >= 8) or len(times) >= 400:
+        L.orc_frame_stage_ms(st8.ctypes.data_as(C.c_void_p))
+        stages.append(st8.copy())
+        if time.time() - t_all > max(seconds_budget, 10.0) * 3 and len(times) >= WARM + 20:      # a very slow host: keep the default run bounded
             break
-    times = np.array(times[2:])   # drop warm-up
+    times = np.array(times[WARM:]); stages = np.array(stages[WARM:])
     med = float(np.median(times))
+    sm = np.median(stages, axis=0)
     out = {"value": round(1.0 / med, 3), "unit": "stereo frames/s", "cores": 4, "kind": "port",
-           "sample": f"{len(times)} synthetic {W}x{H} stereo pairs, one at a time, 4 threads/frame like src/Frame.cc:164-171, "
-                     f"median {med * 1e3:.1f} ms/frame (mean {times.mean() * 1e3:.1f})", "host_cores": os.cpu_count()}
-    # Mode B: all cores, one frame per thread at a time (threads = 1 inside a frame)
+           "sample": f"{len(times)} synthetic {W}x{H} stereo pairs after {WARM} warm-up frames, one at a time, 4 threads/frame like src/Frame.cc:164-171, "
+                     f"median {med * 1e3:.1f} ms/frame (mean {times.mean() * 1e3:.1f}, p95 {np.percentile(times, 95) * 1e3:.1f})",
+           "host_cores": os.cpu_count(),
+           # wall time per stage, median over the timed frames (the four extractions run concurrently on their own threads, the two stereo
+           # matchers after them on the calling thread): the frame time is about max(extractions) + stereo points + stereo lines
+           "stages_ms": {"orb_left": round(sm[0], 2), "orb_right": round(sm[1], 2), "lsd_left": round(sm[2], 2), "lbd_left": round(sm[3], 2),
+                         "lsd_right": round(sm[4], 2), "lbd_right": round(sm[5], 2), "stereo_points": round(sm[6], 2), "stereo_lines": round(sm[7], 2)}}
+    # Mode B: throughput, one whole frame per thread at a time (threads = 1 inside a frame), at 1, 4, 16, 64, ... all host threads: does it scale?
     try:
         cores = len(os.sched_getaffinity(0))
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q == "max" else round(int(q) / int(per), 2)
+        except Exception:
+            pass
         nd = 16
         imgs = synth.stereo_batch(2000, nd, W, H)
         L.orc_stereo_frames_throughput.restype = C.c_double
         L.orc_stereo_frames_throughput.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
-        frames = max(cores * 2, 16)
-        fps = L.orc_stereo_frames_throughput(imgs.ctypes.data_as(C.c_void_p), nd, W, H, C.byref(params), cores, frames)
-        out["mode_b"] = {"value": round(float(fps), 2), "unit": "stereo frames/s", "cores": cores,
-                         "sample": f"{frames} frames ({nd} distinct), one frame per thread, {cores} threads"}
+        sweep = {}
+        for th in sorted({1, 4, 16, 64, cores} & set(range(1, cores + 1))):
+            frames = max(4 * th, 8)              # four frames per worker: the first one warms its arena
+            fps = float(L.orc_stereo_frames_throughput(imgs.ctypes.data_as(C.c_void_p), nd, W, H, C.byref(params), th, frames))
+            sweep[str(th)] = {"fps": round(fps, 2), "fps_per_thread": round(fps / th, 3), "frames": frames}
+        best_th = max(sweep, key=lambda k: sweep[k]["fps"])
+        best = sweep[best_th]
+        out["mode_b"] = {"value": best["fps"], "unit": "stereo frames/s", "cores": int(best_th), "host_threads": cores, "cpu_quota_cores": quota, "threads_sweep": sweep,
+                         "sample": f"one frame per thread, 4 frames per thread ({nd} distinct pairs), thread counts {list(sweep)}; affinity {cores} of "
+                                   f"{os.cpu_count()} logical CPUs, cgroup cpu.max quota {quota}; per-thread malloc arenas keep freed pages (oracle/frame_oracle.cpp)"}
     except Exception as e:   # the throughput leg is extra information: never lose the line over it
         out["mode_b"] = {"error": str(e)}
     return out
@@ -300,6 +324,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # every stage on its own: the four extraction / matching entries back to back on one stream (what OLF_ONE_STREAM=1 makes of a step), outside the
+    # timed region -- in the two-stream step the stages slow each other down, so only these times can be set against a stage's own bytes
+    alone = None
+    if rank == 0 and not args.no_extras:
+        ctx.profile(True)
+        s0 = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            check(Lh.olf_line_extract_dev(ctx.handle, imgs.data_ptr(), 2 * B, kls.data_ptr(), ldesc.data_ptr(), lcounts.data_ptr(), s0), "olf_line_extract_dev")
+            check(Lh.olf_stereo_lines_dev(ctx.handle, B, kls.data_ptr(), ldesc.data_ptr(), lcounts.data_ptr(), lm.data_ptr(), ldisp.data_ptr(), lle.data_ptr(), s0), "olf_stereo_lines_dev")
+            check(Lh.olf_orb_extract_dev(ctx.handle, imgs.data_ptr(), 2 * B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), s0), "olf_orb_extract_dev")
+            check(Lh.olf_stereo_points_dev(ctx.handle, B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), ur.data_ptr(), dp.data_ptr(), s0), "olf_stereo_points_dev")
+        torch.cuda.synchronize()
+        alone = {k: v[0] / 2 for k, v in ctx.profile_read().items() if v[1]}
+        ctx.profile(False)
+
     verify = None
     if gather_on and args.verify:
         # rank 0 runs every other rank's input itself and compares the record it received in the last step, byte for byte
@@ -358,6 +397,17 @@ def main():
                          "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6)},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
         }
+        if alone:
+            # per stage: algorithmic bytes of a launch over the whole batch / the stage's time when it runs alone -> GB/s and fraction of the 8 TB/s
+            # peak (stages without a byte model -- octree, matchers, region2rect -- carry their time only)
+            rs = {}
+            for k, ms in alone.items():
+                by = ab["stage"].get("orb_fast" if k == "orb_fast_cells" else k, 0) * 2 * B
+                rs[k] = {"ms_alone": round(ms, 3)}
+                if by:
+                    rs[k].update(GBps=round(by / (ms * 1e-3) / 1e9, 1), frac=round(by / (ms * 1e-3) / 1e9 / 8000.0, 4))
+            out["roofline"]["stages"] = rs
+            out["roofline"]["sum_alone_ms"] = round(sum(alone.values()), 2)
         if gather_on:
             out["gather"] = {"mode": args.gather, "bytes_per_step": int(gstat["bytes"] / max(args.steps, 1)),
                              "GBps": round(gstat["bytes"] / max(gstat["seconds"], 1e-9) / 1e9, 3),

@@ -19,9 +19,12 @@ void stereo_lines(const std::vector<olf_keyline>& klL, const uint8_t* descL, con
                   int img_w, int img_h, const olf_stereo_params& P, std::vector<int>& matches_12, std::vector<float>& disp,
                   std::vector<double>& le);
 }
+#include <malloc.h>
 #include <thread>
 #include <atomic>
 #include <chrono>
+thread_local double g_frame_stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+namespace orc { extern thread_local double g_line_stage_ms[2]; }
 using namespace orc;
 
 extern "C" {
@@ -66,22 +69,29 @@ int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, con
     OrbResult rl, rr;
     std::vector<olf_keyline> kl, kr;
     std::vector<uint8_t> dl, dr;
-    auto f0 = [&] { orb_extract(L, p->orb, rl); };
-    auto f1 = [&] { orb_extract(R, p->orb, rr); };
-    auto f2 = [&] { line_extract(L, p->line, false, kl, dl, nullptr); };
-    auto f3 = [&] { line_extract(R, p->line, false, kr, dr, nullptr); };
+    // wall time per stage (ms) of this frame: ORB L, ORB R, LSD L, LBD L, LSD R, LBD R, stereo points, stereo lines (g_frame_stage_ms)
+    double* st = g_frame_stage_ms;
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    auto f0 = [&] { const auto t = std::chrono::steady_clock::now(); orb_extract(L, p->orb, rl); st[0] = ms_since(t); };
+    auto f1 = [&] { const auto t = std::chrono::steady_clock::now(); orb_extract(R, p->orb, rr); st[1] = ms_since(t); };
+    auto f2 = [&] { line_extract(L, p->line, false, kl, dl, nullptr); st[2] = g_line_stage_ms[0]; st[3] = g_line_stage_ms[1]; };
+    auto f3 = [&] { line_extract(R, p->line, false, kr, dr, nullptr); st[4] = g_line_stage_ms[0]; st[5] = g_line_stage_ms[1]; };
     if (threads >= 4) {
         std::thread t0(f0), t1(f1), t2(f2), t3(f3);
         t0.join(); t1.join(); t2.join(); t3.join();
     } else { f0(); f1(); f2(); f3(); }
     std::vector<float> sf, inv_sf, u, d;
     orb_scale_tables(p->orb, sf, inv_sf);
+    const auto t6 = std::chrono::steady_clock::now();
     if (!rl.kps.empty())
         compute_stereo_matches(rl.kps, rl.desc.data(), rr.kps, rr.desc.data(), rl.pyramid, rr.pyramid, sf, inv_sf, p->stereo.bf, p->stereo.fx, u, d, nullptr);
+    st[6] = ms_since(t6);
     std::vector<int> m;
     std::vector<float> dsp;
     std::vector<double> le;
+    const auto t7 = std::chrono::steady_clock::now();
     stereo_lines(kl, dl.data(), kr, dr.data(), w, h, p->stereo, m, dsp, le);
+    st[7] = ms_since(t7);
     if (nL) *nL = (int)rl.kps.size();
     if (nR) *nR = (int)rr.kps.size();
     if (nlL) *nlL = (int)kl.size();
@@ -100,10 +110,20 @@ int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, con
     return OLF_OK;
 }
 
+// the stage times of the calling thread's last orc_stereo_frame (8 doubles, see there)
+void orc_frame_stage_ms(double* out8) { for (int i = 0; i < 8; ++i) out8[i] = g_frame_stage_ms[i]; }
+
 // cpu_baseline "mode B" of bench.py: n_threads workers, each running whole frames (the four extractions back to back) taken from a shared
 // counter, over n_frames frames cycling through n_distinct stereo pairs (imgs: [2 * n_distinct][h][w]); returns stereo frames per second
 double orc_stereo_frames_throughput(const uint8_t* imgs, int n_distinct, int w, int h, const olf_params* p, int n_threads, int n_frames)
 {
+    // every frame allocates (and frees) tens of MB of std::vector; with glibc's default thresholds each of them is an mmap / munmap of fresh,
+    // zero-filled pages, and hundreds of threads faulting pages of ONE address space serialise in the kernel (round 2 measured 0.19 frames/s
+    // per thread against 4 for a single frame on four threads).  Keep freed memory in the per-thread arenas instead: after its first frame a
+    // worker reuses its own pages.
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, -1);
+    mallopt(M_ARENA_MAX, 2 * n_threads + 8);
     std::atomic<int> next(0), failed(0);
     const size_t npx = (size_t)w * h;
     auto worker = [&] {

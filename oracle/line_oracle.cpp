@@ -14,8 +14,12 @@
 //        (cos, sin, atan2, sqrt) are evaluated in double and rounded to float.
 #include "oracle_common.hpp"
 #include <cfloat>
+#include <chrono>
 
 namespace orc {
+
+// wall time of the last line_extract of this thread: [0] LSD, [1] key lines + top-N + LBD (bench.py's per-stage CPU breakdown)
+thread_local double g_line_stage_ms[2] = {0, 0};
 
 static const double kPI = 3.1415926535897932384626433832795;
 static const double NOTDEF = -1024.0, M_3_2_PI = (3 * kPI) / 2, M_2__PI = 2 * kPI, DEG_TO_RADS = kPI / 180;
@@ -398,7 +402,10 @@ void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort,
                   std::vector<olf_keyline>* all_detected)
 {
     std::vector<Vec4f> segs;
+    const auto t0 = std::chrono::steady_clock::now();
     lsd_detect(img, P, segs, nullptr, nullptr);
+    g_line_stage_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();      // LSD
+    const auto t1 = std::chrono::steady_clock::now();
     const double min_length = P.min_line_length * std::min(img.w, img.h);
     make_keylines(segs, img.w, img.h, min_length, kls);
     if (all_detected) *all_detected = kls;
@@ -409,6 +416,7 @@ void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort,
         for (int i = 0; i < P.lsd_nfeatures; ++i) kls[i].class_id = i;
     }
     lbd_compute(img, kls, desc, nullptr, P.conv_gauss_sum256);
+    g_line_stage_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();      // key lines, top-N, LBD
 }
 
 }  // namespace orc

@@ -113,15 +113,21 @@ size_t pack_records_bound(int n_pairs, int cap, int lcap)
     return b;
 }
 
-// ---- copy kernel: 16 bytes per thread and step, grid-stride ---------------------------------------------------------------------
+// ---- copy kernel: one 16-byte element per thread, no loop -- the shape that reaches the part's practical copy rate (tools/micro/copy_sweep.hip
+// on an MI355X: 6.2 TB/s read + write, the 6.29 TB/s of MI355X_MICROARCH.md; grid-stride variants with 256 .. 32 768 blocks 4.3 - 5.5 TB/s,
+// hipMemcpyDtoD 4.8 - 5.2 TB/s)
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_copy16, dim3(256 * 32), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), bytes / 16);
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return OLF_OK;
+    if ((n16 + 255) / 256 > 0x7fffffffull) { set_error("launch_copy16: buffer too large for one launch"); return OLF_ERR_INVALID; }
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
