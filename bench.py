@@ -3,7 +3,7 @@
 
 One "step" = one pass of the whole hot path over one batch of B stereo pairs per GPU, inputs already resident in HBM:
 olf_stereo_frames_dev (ExtractORB x2, ExtractLine x2, ComputeStereoMatches, ComputeStereoMatches_Lines; reference src/Frame.cc:136-221)
-+ the frame-to-frame LBD match (match(), src/LineMatcher.cpp:104-132) and the frame-to-frame dense ORB kNN match against the previous
++ the frame-to-frame LBD match (match(), src/LineMatcher.cpp:104-132) and the frame-to-frame ORB match against the previous
 frame of the batch.  Workloads (--config): C2 640x480 1000+200, C3 KITTI 1242x375 2000+500 (default: the configuration
 the metric is quoted on), C4 EuRoC 752x480 1200+500, C5 1920x1080 4000+1000.
 
@@ -44,6 +44,24 @@ CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD 
 STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
                 "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow",
                 "lsd_rect": "olf::k_lsd_rect", "line_select_lbd": "olf::k_lbd_rows", "stereo_lines": "olf::k_lines_dist", "match_bf": "olf::k_knn2"}
+
+
+def synthetic_vocabulary(k, L, sample_desc, seed=4242):
+    """A full k-ary vocabulary tree of depth L in the arrays ORBVocabulary.from_arrays takes (parent, is_leaf, descriptor, weight), nodes in
+    breadth-first order like TemplatedVocabulary::loadFromTextFile builds them (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425).  The
+    reference's ORBvoc.txt (k = 10, L = 6, 10^6 words) is missing from its checkout: the node descriptors here are drawn from the
+    batch's own ORB descriptors, so a descent spreads the features over the level-2 nodes the way a trained tree does."""
+    n = (k ** (L + 1) - 1) // (k - 1)
+    parent = (np.arange(n, dtype=np.int64) - 1) // k
+    parent[0] = -1
+    leaf = np.zeros(n, np.uint8)
+    leaf[n - k ** L:] = 1
+    rng = np.random.default_rng(seed)
+    desc = sample_desc[rng.integers(0, len(sample_desc), n)].copy()
+    flip = rng.integers(0, 256, n)
+    desc[np.arange(n), flip // 8] ^= (1 << (flip % 8)).astype(np.uint8)
+    weight = np.where(leaf > 0, rng.uniform(0.5, 9.0, n), 0.0)
+    return parent.astype(np.int32), leaf, desc, weight
 
 
 def source_hash():
@@ -170,6 +188,7 @@ def main():
     ap.add_argument("--order", choices=("shuffled", "tiled"), default="shuffled", help="how the batch is drawn from the distinct pairs")
     ap.add_argument("--scene", choices=("default", "long", "bars"), default="default", help="long: fewer, larger shapes; bars: long thin bars -> key lines of about 0.08*W pixels (SURVEY App. D model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bow", action="store_true", help="frame-to-frame ORB matching by the dense kNN stand-in of rounds 1-2 instead of SearchByBoW")
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
@@ -250,6 +269,16 @@ def main():
     fb = FrameBuffers(*[t.data_ptr() for t in (kps, desc, counts, ur, dp, kls, ldesc, lcounts, lm, ldisp, lle)])
     Lh = lib()
     nnr_l = float(params.stereo.min_ratio_12_l)
+    kf_valid = z((B, cap), torch.uint8); kf_valid_b = z((B, cap), torch.bool); f2f_n = z((B,), torch.int32)
+    voc = None
+    if not args.no_bow:
+        # vocabulary of ORBvoc's shape from the descriptors of a few frames of this input (built once, outside the timed region)
+        check(Lh.olf_orb_extract_dev(ctx.handle, imgs.data_ptr(), min(2 * B, 16), kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), torch.cuda.current_stream().cuda_stream), "olf_orb_extract_dev")
+        torch.cuda.synchronize()
+        cn0 = counts[:16].cpu().numpy(); de0 = desc[:16].cpu().numpy()
+        sample = np.concatenate([de0[i, :cn0[i]] for i in range(min(2 * B, 16))])
+        from orb_line_slam_amd.vocabulary import ORBVocabulary
+        voc = ORBVocabulary.from_arrays(10, 6, *synthetic_vocabulary(10, 6, sample), context=ctx)
 
     def step(images):
         s = torch.cuda.current_stream().cuda_stream
@@ -258,9 +287,17 @@ def main():
             # frame i (left image 2i) against frame i-1: match(last.mDescriptors_Line, cur.mDescriptors_Line) (src/Tracking.cc:1308)
             check(Lh.olf_match_bf_dev(ctx.handle, ldesc.data_ptr() + 2 * lcap * 32, lcounts.data_ptr() + 8, 2 * lcap, 2, ldesc.data_ptr(),
                                       lcounts.data_ptr(), 2 * lcap, 2, B - 1, nnr_l, 1, f2f_lines.data_ptr(), s), "olf_match_bf_dev(lines)")
-            # dense ORB kNN(2)+ratio+mutual against the previous frame (BF stand-in for SearchByBoW without a vocabulary)
-            check(Lh.olf_match_bf_dev(ctx.handle, desc.data_ptr() + 2 * cap * 32, counts.data_ptr() + 8, 2 * cap, 2, desc.data_ptr(),
-                                      counts.data_ptr(), 2 * cap, 2, B - 1, 0.7, 1, f2f_orb.data_ptr(), s), "olf_match_bf_dev(orb)")
+            if voc is not None:
+                # configuration 3's matcher: cur.ComputeBoW() + ORBmatcher(0.7).SearchByBoW(previous frame as key frame, cur) (src/Tracking.cc:963-970),
+                # batched on the device; the key frame's map points = its stereo points (mvuRight >= 0)
+                torch.ge(ur, 0, out=kf_valid_b)
+                kf_valid.copy_(kf_valid_b)
+                check(Lh.olf_search_by_bow_batch_dev(ctx.handle, voc._h, B, 2, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), kf_valid.data_ptr(), None,
+                                                     0.7, 1, 4, f2f_orb.data_ptr(), f2f_n.data_ptr(), s), "olf_search_by_bow_batch_dev")
+            else:
+                # dense ORB kNN(2)+ratio+mutual against the previous frame (--no-bow: the round-1/2 stand-in for SearchByBoW)
+                check(Lh.olf_match_bf_dev(ctx.handle, desc.data_ptr() + 2 * cap * 32, counts.data_ptr() + 8, 2 * cap, 2, desc.data_ptr(),
+                                          counts.data_ptr(), 2 * cap, 2, B - 1, 0.7, 1, f2f_orb.data_ptr(), s), "olf_match_bf_dev(orb)")
 
     # ---- the gather of the feature records to rank 0 (N > 1) ---------------------------------------------------------------------
     gather_on = world > 1 and args.gather != "off"
@@ -388,7 +425,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} stereo, {cfg['nf']} ORB + {cfg['nl']} LBD per image, extract + stereo point/line match + "
-                                   f"f2f LBD match + f2f dense ORB kNN match", "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
+                                   f"f2f LBD match + " + ("SearchByBoW vs the previous frame (synthetic k=10 L=6 vocabulary, ComputeBoW included)" if voc is not None else "f2f dense ORB kNN match"), "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
                        "distinct_pairs": nd, "order": args.order, "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
                        "mean_line_pixels": round(mean_len, 1), "source_hash": sh},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
@@ -422,7 +459,11 @@ def main():
             except Exception as e:
                 out["roofline"]["copy_kernel_GBps"] = None
                 print(f"copy ceiling failed: {e}", file=sys.stderr)
+    if rank == 0 and out is not None and voc is not None:
+        out["config"]["search_by_bow_mean_matches"] = round(float(f2f_n[:B - 1].float().mean().item()), 1)
     del imgs, kps, desc, ur, dp, kls, ldesc, lm, ldisp, lle, f2f_lines, f2f_orb
+    if voc is not None:
+        voc.clear()
     ctx.close()
     torch.cuda.empty_cache()
     if rank == 0:

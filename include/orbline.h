@@ -121,6 +121,18 @@ int olf_bow_assemble(const olf_voc* voc, const int32_t* word, const double* weig
 /* transform(features, v, fv, levelsup) for one image's descriptors (host buffers): descent on the GPU, assembly on the host. */
 int olf_bow_transform(olf_ctx* ctx, const olf_voc* voc, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals,
                       int* n_bow, int32_t* fv_nodes, int32_t* fv_offs, int32_t* fv_idx, int* n_fv);
+/* Batched, device-resident ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches) (src/ORBmatcher.cc:161-290,
+ * Tracking::TrackReferenceKeyFrame, src/Tracking.cc:963-970) over consecutive frames, Frame::ComputeBoW (src/Frame.cc:585-597) of every frame
+ * included -- no host step between a frame's descriptors and its matches.  Frame j = image j * img_stride of the key point / descriptor / count
+ * buffers of olf_orb_extract_dev (stride olf_orb_capacity(); img_stride 2 = the left images of a stereo batch); pair j: pKF = frame j, F = frame
+ * j + 1, j < n_frames - 1.  d_mp_valid / d_mp_bad [n_frames][capacity] bytes: vpMapPointsKF[i] != NULL / isBad() of a frame in its key-frame
+ * role (NULL: every feature holds a good map point).  levelsup: 4 in the reference.  d_matches [n_frames - 1][capacity]: per feature of F the
+ * index of the pKF feature whose map point it received (-1 = NULL); d_nmatches [n_frames - 1] = the reference's return values.  The greedy
+ * state of the reference (a feature of F that holds a match is skipped, :214) is kept: inside a vocabulary node the key frame's features are
+ * walked in order by one wave; different nodes share no feature and run side by side. */
+int olf_search_by_bow_batch_dev(olf_ctx* ctx, const olf_voc* voc, int n_frames, int img_stride, const olf_keypoint* d_kps, const uint8_t* d_desc,
+                                const int32_t* d_counts, const uint8_t* d_mp_valid, const uint8_t* d_mp_bad, float nnratio, int check_orientation,
+                                int levelsup, int32_t* d_matches, int32_t* d_nmatches, void* stream);
 
 /* ---- ORBextractor (include/ORBextractor.h:52-118, src/ORBextractor.cc) -------------------- */
 /* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /

@@ -162,6 +162,7 @@ def lib():
         L.olf_bow_words_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_bow_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.olf_search_by_bow_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.olf_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.olf_profile_enable.argtypes = [C.c_void_p, C.c_int]

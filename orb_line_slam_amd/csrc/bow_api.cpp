@@ -24,6 +24,10 @@ int launch_bow_descend(const uint8_t* slotDesc, const int* childOff, const int* 
                        const uint8_t* desc, int n, int nid_level, int* word, double* weight, int* nodeOut, hipStream_t s);
 hipStream_t ctx_stream(olf_ctx* c);
 int ctx_scratch(olf_ctx* c, int slot, size_t bytes, void** out);
+int launch_search_by_bow_batch(const uint8_t* slotDesc, const int* childOff, const int* slotNode, const double* nodeWeight, int nid_level, int n_frames,
+                               int img_stride, int cap, const olf_keypoint* d_kps, const uint8_t* d_desc, const int* d_counts, const uint8_t* d_mp_valid,
+                               const uint8_t* d_mp_bad, float nnratio, int check_ori, int* d_nodes, unsigned long long* d_sorted, int* d_m, int* d_matches,
+                               int* d_nmatches, hipStream_t s);
 }
 
 extern "C" {
@@ -181,6 +185,29 @@ int olf_bow_assemble(const olf_voc* v, const int32_t* word, const double* weight
     fv_offs[nf] = (int)byNode.size();
     *n_fv = nf;
     return OLF_OK;
+}
+
+int olf_search_by_bow_batch_dev(olf_ctx* c, const olf_voc* v, int n_frames, int img_stride, const olf_keypoint* d_kps, const uint8_t* d_desc,
+                                const int32_t* d_counts, const uint8_t* d_mp_valid, const uint8_t* d_mp_bad, float nnratio, int check_orientation, int levelsup,
+                                int32_t* d_matches, int32_t* d_nmatches, void* stream)
+{
+    if (!c || !v || !d_kps || !d_desc || !d_counts || !d_matches || !d_nmatches || n_frames < 0 || img_stride < 1 || levelsup < 0) {
+        set_error("olf_search_by_bow_batch_dev: bad argument"); return OLF_ERR_INVALID;
+    }
+    if (v->n_words == 0) { set_error("olf_search_by_bow_batch_dev: empty vocabulary"); return OLF_ERR_INVALID; }
+    if (n_frames < 2) return OLF_OK;
+    const int cap = olf_orb_capacity(c);
+    if (cap > 4096) { set_error("olf_search_by_bow_batch_dev: more than 4096 features per frame (the per-frame node sort runs in 32 KB of LDS)"); return OLF_ERR_CAPACITY; }
+    void* st = nullptr;
+    const size_t bn = (((size_t)n_frames * cap * 4) + 63) & ~(size_t)63, bs = (size_t)n_frames * cap * 8;
+    const int rc = ctx_scratch(c, 2, bn + bs + (size_t)n_frames * 4 + 64, &st);
+    if (rc != OLF_OK) return rc;
+    int* d_nodes = (int*)st;
+    unsigned long long* d_sorted = (unsigned long long*)((uint8_t*)st + bn);
+    int* d_m = (int*)((uint8_t*)st + bn + bs);
+    return launch_search_by_bow_batch(v->d_slotDesc, v->d_childOff, v->d_slotNode, v->d_nodeWeight, v->L - levelsup, n_frames, img_stride, cap, d_kps, d_desc,
+                                      d_counts, d_mp_valid, d_mp_bad, nnratio, check_orientation ? 1 : 0, d_nodes, d_sorted, d_m, d_matches, d_nmatches,
+                                      stream ? (hipStream_t)stream : ctx_stream(c));
 }
 
 int olf_bow_transform(olf_ctx* c, const olf_voc* v, const uint8_t* desc, int n, int levelsup, int32_t* bow_ids, double* bow_vals, int* n_bow,

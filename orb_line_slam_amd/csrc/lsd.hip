@@ -912,6 +912,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         }
     }
     OLF_HIP_CHECK(hipGetLastError());
+    if (b.sortEvent) OLF_HIP_CHECK(hipEventRecord(b.sortEvent, s));
     // the seed order: bins high to low; inside a bin raster order (a stable radix sort of the defined pixels' keys) or libstdc++'s std::sort order
     // over all pixels (convention C.9)
     { int rc = g.seedOrder == 1 ? launch_lsd_seedsort(g, b, n_images, s, -1, -1, -1) : launch_lsd_sort(g, b, n_images, s); if (rc != OLF_OK) return rc; }

@@ -104,3 +104,63 @@ def test_search_by_bow_with_transform(oracle):
     n_o, m_o = oracle.search_by_bow(last, cur, 0.8)
     n_g, m_g = ola.ORBmatcher(0.8, True).SearchByBoW(last, cur)
     assert n_g == n_o and np.array_equal(m_g, m_o) and n_g > 30
+
+
+@pytest.mark.parametrize("k,L,levelsup,check", [(10, 3, 2, True), (10, 6, 4, True), (4, 4, 2, False)])
+def test_search_by_bow_batch_on_device(oracle, k, L, levelsup, check):
+    """olf_search_by_bow_batch_dev: Frame::ComputeBoW + ORBmatcher::SearchByBoW(prev frame as key frame, frame) for a batch of consecutive frames
+    without leaving the device, against the oracle's SearchByBoW on the oracle's own feature vectors, pair by pair.  Some key-frame features hold
+    no map point, some a bad one; a few words have weight 0 (their features are not in the FeatureVector)."""
+    import torch
+    import ctypes as C
+    from orb_line_slam_amd import synth
+    from orb_line_slam_amd._lib import FrameBuffers, check as chk, lib
+    w, h, B = 1242, 375, 5
+    p = oracle.full_params(2000, 100)
+    ctx = _lib.Context(p, w, h, 2 * B)
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    imgs = synth.stereo_batch(211, B, w, h)
+    for i in range(1, B):                                            # consecutive frames: the same scene shifted by a few pixels
+        imgs[2 * i] = np.roll(imgs[0], 2 * i, axis=1)
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(imgs).to(dev)
+    kps = torch.zeros((2 * B, cap, 28), dtype=torch.uint8, device=dev); desc = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+    L_ = lib()
+    s = torch.cuda.current_stream().cuda_stream
+    chk(L_.olf_orb_extract_dev(ctx.handle, d_img.data_ptr(), 2 * B, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), s), "olf_orb_extract_dev")
+    torch.cuda.synchronize()
+    kp_h = kps.cpu().numpy().view(ola.KEYPOINT_DTYPE).reshape(2 * B, cap); de_h = desc.cpu().numpy(); cn_h = counts.cpu().numpy()
+    # vocabulary whose centroids are real descriptors; every 7th word gets weight 0
+    parent, leaf, vdesc, weight = oracle.random_vocabulary(k, L, 31)
+    rng = np.random.default_rng(5)
+    src = np.concatenate([de_h[2 * i, :cn_h[2 * i]] for i in range(B)])
+    vdesc[1:] = src[rng.integers(0, len(src), len(parent) - 1)]
+    weight = weight.copy(); words = np.flatnonzero(leaf); weight[words[::7]] = 0.0
+    G = ola.ORBVocabulary.from_arrays(k, L, parent, leaf, vdesc, weight, context=ctx)
+    V = oracle.OracleVoc.create(k, L, parent, leaf, vdesc, weight)
+    valid = rng.random((B, cap)) < 0.85; bad = rng.random((B, cap)) < 0.05
+    d_valid = torch.from_numpy(valid.astype(np.uint8)).to(dev); d_bad = torch.from_numpy(bad.astype(np.uint8)).to(dev)
+    m = torch.full((B - 1, cap), -7, dtype=torch.int32, device=dev); nm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
+    chk(L_.olf_search_by_bow_batch_dev(ctx.handle, G._h, B, 2, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), d_valid.data_ptr(), d_bad.data_ptr(),
+                                       0.7, int(check), levelsup, m.data_ptr(), nm.data_ptr(), s), "olf_search_by_bow_batch_dev")
+    torch.cuda.synchronize()
+    m_h, nm_h = m.cpu().numpy(), nm.cpu().numpy()
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    views = []
+    for i in range(B):
+        n = int(cn_h[2 * i])
+        v = ola.FrameView(kp_h[2 * i, :n], de_h[2 * i, :n], None, sf, bounds=(0.0, float(w), 0.0, float(h)))
+        v.mp_valid, v.mp_bad = valid[i, :n].copy(), bad[i, :n].copy()
+        _, v.mFeatVec = V.transform(v.mDescriptors, levelsup)
+        views.append(v)
+    total = 0
+    for j in range(B - 1):
+        n_o, m_o = oracle.search_by_bow(views[j], views[j + 1], 0.7, checkOri=check)
+        nF = views[j + 1].N
+        assert nm_h[j] == n_o, (j, nm_h[j], n_o)
+        assert np.array_equal(m_h[j, :nF], m_o), (j, int(np.argmax(m_h[j, :nF] != m_o)))
+        assert (m_h[j, nF:] == -1).all()
+        total += n_o
+    assert total > 100 * (B - 1)
+    ctx.close()
