@@ -146,7 +146,6 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // the chunks of an image follow each other on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own): the
 // halo rows are then L2 hits.
 constexpr float kDegUndef = -1000.f;
-constexpr int KEYS_LUT = 1024;        // ALLKEYS: bins of the undefined pixels by gx^2 + gy^2 (< nThr; 110 with the reference's parameters)
 constexpr int KEYS_THREADS = 512;      // 8 waves share the 36 KB of LDS a chunk needs: 4 blocks = 32 waves per CU (256 threads: 14.9 ms per 6144 images, 512: 11.5, 1024: 15.5)
 // ALLKEYS (convention C.9, variant 1 -- OpenCV >= 3.3): the key of EVERY pixel with x < Ws - 1, y < Hs - 1, defined or not, at its raster position
 // y * (Ws - 1) + x of `keys` -- the vector ll_angle hands to std::sort; lsd_seedsort.hip replays that sort and writes the seed list and its
@@ -213,21 +212,17 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
     if (ALLKEYS) {
-        // the undefined pixels of the chunk (four out of five): gx^2 + gy^2 < nThr, so their bins come from a small table (one double square root
-        // per table entry and block instead of one per pixel: 16.9 -> 12 ms per 6144 images); the defined ones are keyed by the dense loop below
-        __shared__ uint16_t s_lut[KEYS_LUT];
-        const bool useLut = g.nThr <= KEYS_LUT;
-        if (useLut) for (int t = threadIdx.x; t < g.nThr; t += KEYS_THREADS) s_lut[t] = (uint16_t)(int)(sqrt((double)t / 4.0) * bin_coef);
-        __syncthreads();
+        // (a per-block table of the undefined pixels' bins -- gx^2 + gy^2 < nThr -- with the defined ones keyed by the dense loop below was
+        // slower, 22.8 against 16.9 ms per 6144 images: the dense loop's stores then scatter and nearly every wave still holds a defined pixel)
         uint32_t* kall = keys + (size_t)img * Ps;
         for (int li = threadIdx.x; li < LG_CHUNK && c0 + li < Ps; li += KEYS_THREADS) {
             const int idx = c0 + li;
             const int y = idx / Ws, x = idx - y * Ws;
-            const uint32_t p = grad[idx];
-            if (x < Ws - 1 && y < Hs - 1 && (p & kNotDef)) {
+            if (x < Ws - 1 && y < Hs - 1) {
+                const uint32_t p = grad[idx];
                 const int gx = unpack_gx(p), gy = unpack_gy(p);
-                const int nn = gx * gx + gy * gy;
-                const int bin = useLut ? (int)s_lut[nn] : (int)(sqrt((double)nn / 4.0) * bin_coef);
+                const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const int bin = (int)(norm * bin_coef);
                 kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
             }
         }
@@ -260,8 +255,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         }
         if (iso) grad[idx] = p | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
-        if (ALLKEYS) { if (x < Ws - 1 && y < Hs - 1) keys[(size_t)img * Ps + y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx; }
-        else kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+        if (!ALLKEYS) kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
     }
     if (!ALLKEYS && chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
