@@ -409,8 +409,9 @@ def main():
         dom_ms = stages[dom]["ms_per_step"] / max(stages[dom]["calls"] // args.steps, 1)
         per_launch_bytes = ab["stage"].get(dom, 0) * 2 * B
         achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/*_pmc_hbm_traffic.json, per
-        # image), valid only for the sources it was collected on: the summary carries a hash of csrc/, anything else gives null
+        # HBM traffic of the dominant kernel: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/*_pmc_hbm_traffic.json, per
+        # image; the factor 2 is the calibration of profiles/r3_fetch_calibration.txt: the counter tallies 128-byte read requests at 64 bytes), valid only
+        # for the sources it was collected on: the summary carries a hash of csrc/, anything else gives null
         traffic, sh = None, source_hash()
         try:
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
