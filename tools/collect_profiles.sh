@@ -23,8 +23,8 @@ rm -rf /tmp/pb
 OLF_LSD_NW=0 OLF_ONE_STREAM=1 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
 python $R/tools/pmc_budget.py /tmp/pb 1024 > $O/${T}_valu_budget_per_kernel.txt 2>&1
 OLF_ONE_STREAM=1 python $R/tools/grow_sweep.py 1 8 128 512 1024 2048 3072 > $O/${T}_grow_sweep.txt 2>&1
-python $R/tools/soak.py $SOAK > $O/${T}_soak.txt 2>&1; tail -2 $O/${T}_soak.txt
-python $R/tools/fuzz.py 500 11 2>/dev/null | tail -8 > $O/${T}_fuzz_500configs.txt; tail -1 $O/${T}_fuzz_500configs.txt
+timeout 900 python $R/tools/soak.py $SOAK > $O/${T}_soak.txt 2>&1; tail -2 $O/${T}_soak.txt
+timeout 900 python $R/tools/fuzz.py 500 11 2>/dev/null | tail -8 > $O/${T}_fuzz_500configs.txt; tail -1 $O/${T}_fuzz_500configs.txt
 python $R/tools/fuzz_match.py 300 5 2>/dev/null | tail -2 > $O/${T}_fuzz_match_300cases.txt
 python $R/tools/pcie_rate.py 2048 8 > $O/${T}_pcie_rate.txt 2>&1; tail -2 $O/${T}_pcie_rate.txt
 python $R/tools/pair_latency.py > $O/${T}_pair_latency.txt 2>&1

@@ -54,6 +54,7 @@ for it in range(N):
     p.line.lsd_quant = float(rng.choice([1.0, 2.0, 3.0]))
     p.line.lsd_ang_th = float(rng.choice([15.0, 22.5, 30.0]))
     p.line.lsd_n_bins = int(rng.choice([256, 512, 1024]))
+    p.line.conv_seed_order = int(rng.random() < 0.7)       # convention C.9: mostly the std::sort order (the default), sometimes the raster order
     p.stereo.fx, p.stereo.bf = float(rng.uniform(300, 900)), float(rng.uniform(30, 400))
     p.stereo.best_lr_matches = int(rng.integers(0, 2))
     kind = int(rng.integers(0, 6))
