@@ -525,6 +525,14 @@ int olf_debug_seed_sort(olf_ctx* c, const uint32_t* keys, int n, int kthr, int d
     return OLF_OK;
 }
 
+// debug / tests: which seed-sort kernel runs (-1: chosen from the batch size; 0: one wave per image; 1 / 2: 4 / 8 waves per image)
+int olf_debug_seed_sort_mode(olf_ctx* c, int mode)
+{
+    if (!c || mode < -1 || mode > 2) { set_error("olf_debug_seed_sort_mode: bad argument"); return OLF_ERR_INVALID; }
+    c->lb.forceSortMode = mode;
+    return OLF_OK;
+}
+
 // debug / tests: cap the chunk pool of the multi-wave growth (0: the whole pool) so that the fall-back to the one-wave agent can be exercised
 int olf_debug_lsd_pool(olf_ctx* c, int pool_chunks)
 {

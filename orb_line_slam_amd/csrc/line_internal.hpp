@@ -76,6 +76,7 @@ struct LineDeviceBufs {
     hipEvent_t sortEvent = nullptr;  // when set, launch_lsd_front records it in front of the seed ordering (the dense, bandwidth-bound part of the front is through)
     int* growFmt = nullptr;        // [n] after the multi-wave growth: 0 chunk chains, -1 given up (pool exhausted), 1 grown again by the one-wave agent (contiguous log)
     int poolChunks = 0;            // olf_debug_lsd_pool: > 0 caps the chunk pool the multi-wave kernel may use (tests of the fall-back)
+    int forceSortMode = -1;        // olf_debug_seed_sort_mode: 0 one wave per image, 1 / 2 the 4- / 8-wave kernel of lsd_seedsort.hip; -1: by batch size
     int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
 };

@@ -383,64 +383,105 @@ enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OT
 #define SSCNT(i, v)
 #endif
 
-__global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
-                                                     const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
+// The sort of one image.  NW = 1: one wave, the ranges still to do on a stack held one per lane in registers (the batch kernel).  NW > 1: the NW waves
+// of a workgroup share the image -- after a partition the two parts are independent, and a finished element's place in the seed list is its place in
+// the sorted array, so no wave needs to know what the others have emitted: ranges that stream from memory go through a stack in LDS that any idle
+// wave pops from, a range that fits a wave's LDS buffer is finished by that wave alone (its own register stack).  NEM: tiles per streamed block --
+// one wave alone is bound by the latency of a block step, not by issue slots, so the few-images variant uses larger blocks.
+template <int NW, int NEM>
+__device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
+                                              const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
+                                              uint32_t* s_buf, uint32_t* s_x, int* ctl)
 {
 #ifdef OLF_SS_PROF
     long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
 #endif
-    __shared__ __align__(8) uint32_t s_buf[SS_CAP];
-    __shared__ __align__(8) uint32_t s_x[4 * 64 * SS_NE_LDS];      // LDS path: the two stopper queues; memory path: the two staged blocks
-    static_assert(4 * 64 * SS_NE_MEM <= SS_CAP && 2 * 64 * SS_NE_MEM <= 4 * 64 * SS_NE_LDS, "memory path: queues in the range buffer, staged blocks in s_x");
-    const LineGeom& g = *gp;
-    const int img = blockIdx.x, lane = threadIdx.x;
+    constexpr int CAP = NEM > SS_NE_MEM ? 4 * 64 * NEM : SS_CAP;          // elements of a range a wave keeps in LDS (= the words of its range buffer)
+    constexpr int SHCAP = 256;                                            // entries of the shared stack (NW > 1)
+    const int lane = threadIdx.x & 63;
     SsCtx c;
     c.A = keysInAll + (size_t)img * g.Ps;
     c.out = keysOutAll + (size_t)img * g.Ps;
     c.sbuf = s_buf; c.ldsFirst = 0; c.lane = lane;
     const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
-    uint32_t Kthr;
+    uint32_t Kthr = 0;
+    bool empty = n <= 0;
     if (kthrOverride >= 0) Kthr = (uint32_t)kthrOverride;
     else {
         const int mN = maxN[img * 32];
-        if (mN <= 0) { if (lane == 0) keyCount[img * 32] = 0; return; }      // no defined pixel: no seed
-        // the smallest bin a defined pixel can fall into (ll_angle: bin = int(norm * bin_coef), norm > rho <=> gx^2 + gy^2 >= nThr), as k_lsd_keys bins it
-        const double max_grad = sqrt((double)mN / 4.0);
-        const double bin_coef = (double)(g.nBins - 1) / max_grad;
-        const double normT = sqrt((double)g.nThr / 4.0);
-        const int binT = (int)(normT * bin_coef);
-        Kthr = (uint32_t)(g.nBins - 1 - binT);
+        if (mN <= 0) empty = true;                                        // no defined pixel: no seed
+        else {
+            // the smallest bin a defined pixel can fall into (ll_angle: bin = int(norm * bin_coef), norm > rho <=> gx^2 + gy^2 >= nThr), as k_lsd_keys bins it
+            const double max_grad = sqrt((double)mN / 4.0);
+            const double bin_coef = (double)(g.nBins - 1) / max_grad;
+            const double normT = sqrt((double)g.nThr / 4.0);
+            const int binT = (int)(normT * bin_coef);
+            Kthr = (uint32_t)(g.nBins - 1 - binT);
+        }
     }
-    if (n <= 0) { if (lane == 0) keyCount[img * 32] = 0; return; }
+    if (empty) { if (threadIdx.x == 0) keyCount[img * 32] = 0; return; }
     const int depth0 = depthOverride >= 0 ? depthOverride : 2 * (31 - __builtin_clz((unsigned)n));
     // the ranges still to do (right siblings on the path), one per lane: at most depth0 + 1 <= 43 of them
     int stF = 0, stL = 0, stD = 0;
     uint32_t stLb = 0, stUb = 0;
     int sp = 0;
 #define SS_PUSH(F, L, D, LB, UB) do { if (lane == sp) { stF = (F); stL = (L); stD = (D); stLb = (LB); stUb = (UB); } ++sp; } while (0)
-    SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
-    int outPos = 0;
-    bool inLDS = false;
+    // shared stack (NW > 1): ctl[0] lock, [1] entries, [2] waves holding work, [3] seeds listed; then five arrays of SHCAP words
+    int* const shF = ctl + 4; int* const shL = shF + SHCAP; int* const shD = shL + SHCAP; int* const shLb = shD + SHCAP; int* const shUb = shLb + SHCAP;
+#define SS_LOCK() do { if (lane == 0) { int _sp = 0; while (atomicCAS(&ctl[0], 0, 1) != 0) { __builtin_amdgcn_s_sleep(2); if (++_sp > (1 << 22)) { atomicOr(status, 128); break; } } } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#define SS_UNLOCK() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) atomicExch(&ctl[0], 0); } while (0)
+    if (NW == 1) SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
+    else {
+        if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; ctl[3] = 0; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
+        __syncthreads();
+    }
+    int listedEnd = 0;                 // one past the last seed this wave has listed
+    bool inLDS = false, holding = false;
     int ldsLast = 0;
-    while (sp > 0) {
-        --sp;
-        int first = __builtin_amdgcn_readlane(stF, sp), last = __builtin_amdgcn_readlane(stL, sp), depth = __builtin_amdgcn_readlane(stD, sp);
-        uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)stLb, sp), ub = (uint32_t)__builtin_amdgcn_readlane((int)stUb, sp);     // lb <= K <= ub for every element of the range
+    int guard = 0;
+    for (;;) {
+        if (NW > 1 && ++guard > (1 << 24)) { if (lane == 0) atomicOr(status, 64); break; }      // watchdog: a wave that found neither work nor the end
+        int first, last, depth;
+        uint32_t lb, ub;
+        if (sp > 0) {
+            --sp;
+            first = __builtin_amdgcn_readlane(stF, sp); last = __builtin_amdgcn_readlane(stL, sp); depth = __builtin_amdgcn_readlane(stD, sp);
+            lb = (uint32_t)__builtin_amdgcn_readlane((int)stLb, sp); ub = (uint32_t)__builtin_amdgcn_readlane((int)stUb, sp);     // lb <= K <= ub for every element of the range
+        } else if (NW == 1) break;
+        else {
+            inLDS = false;
+            int got = 0, done = 0, f = 0, l = 0, d = 0, a = 0, b = 0;
+            SS_LOCK();
+            if (lane == 0) {
+                if (holding) atomicSub(&ctl[2], 1);
+                const int e = atomicAdd(&ctl[1], 0);
+                if (e > 0) { f = shF[e - 1]; l = shL[e - 1]; d = shD[e - 1]; a = shLb[e - 1]; b = shUb[e - 1]; atomicExch(&ctl[1], e - 1); atomicAdd(&ctl[2], 1); got = 1; }
+                else if (atomicAdd(&ctl[2], 0) == 0) done = 1;
+            }
+            SS_UNLOCK();
+            got = ssU(got); done = ssU(done);
+            holding = got != 0;
+            if (done) break;
+            if (!got) { __builtin_amdgcn_s_sleep(8); continue; }
+            first = ssU(f); last = ssU(l); depth = ssU(d); lb = (uint32_t)ssU(a); ub = (uint32_t)ssU(b);
+        }
         first = ssU(first); last = ssU(last); depth = ssU(depth); lb = (uint32_t)ssU((int)lb); ub = (uint32_t)ssU((int)ub);
         if (inLDS && first >= ldsLast) inLDS = false;
         for (;;) {
             const int m = last - first;
             if (lb > Kthr) break;                                     // only undefined pixels: never seeds, never leave the range
             SSPROF(SP_OTHER);
-            if (m <= 16) { outPos = inLDS ? ss_emit_leaf<true>(c, first, last, Kthr, outPos) : ss_emit_leaf<false>(c, first, last, Kthr, outPos); SSPROF(SP_LEAF); SSCNT(SP_N_LEAF, 1); break; }
-            if (lb == ub && ss_equal_levels(m) <= depth) { outPos = inLDS ? ss_emit_equal<true>(c, first, last, outPos) : ss_emit_equal<false>(c, first, last, outPos); SSPROF(SP_EQUAL); SSCNT(SP_N_EQUAL, 1); SSCNT(SP_V_EQUAL, m); break; }
-            if (depth == 0) {
+            // (a finished element's place in the seed list is its place in the sorted array: the listed elements are the array's prefix)
+            int end = first;
+            if (m <= 16) { end = inLDS ? ss_emit_leaf<true>(c, first, last, Kthr, first) : ss_emit_leaf<false>(c, first, last, Kthr, first); SSPROF(SP_LEAF); SSCNT(SP_N_LEAF, 1); }
+            else if (lb == ub && ss_equal_levels(m) <= depth) { end = inLDS ? ss_emit_equal<true>(c, first, last, first) : ss_emit_equal<false>(c, first, last, first); SSPROF(SP_EQUAL); SSCNT(SP_N_EQUAL, 1); SSCNT(SP_V_EQUAL, m); }
+            else if (depth == 0) {
                 if (lane == 0) { if (inLDS) ss_heapsort<true>(c, first, last); else ss_heapsort<false>(c, first, last); }
                 __builtin_amdgcn_wave_barrier();
-                outPos = inLDS ? ss_emit_sorted<true>(c, first, last, Kthr, outPos) : ss_emit_sorted<false>(c, first, last, Kthr, outPos);
-                break;
-            }
-            if (!inLDS && m <= SS_CAP) {
+                end = inLDS ? ss_emit_sorted<true>(c, first, last, Kthr, first) : ss_emit_sorted<false>(c, first, last, Kthr, first);
+            } else end = -1;
+            if (end >= 0) { end = ssU(end); if (end > first) listedEnd = max(listedEnd, end); break; }
+            if (!inLDS && m <= CAP) {
                 for (int i0 = 0; i0 < m; i0 += 256) {
                     uint32_t t[4];
 #pragma unroll
@@ -477,26 +518,90 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
             const bool dropRight = Kp > Kthr;
             uint2* const qx = reinterpret_cast<uint2*>(s_x);
             uint2* const qb = reinterpret_cast<uint2*>(s_buf);
-            if (!inLDS) cut = ss_partition<false, SS_NE_MEM>(c, qb, qb + 64 * SS_NE_MEM, s_x, s_x + 64 * SS_NE_MEM, first + 1, last, Kp, dropRight);
+            if (!inLDS) cut = ss_partition<false, NEM>(c, qb, qb + 64 * NEM, s_x, s_x + 64 * NEM, first + 1, last, Kp, dropRight);
             else if (m <= 65) cut = ss_partition<true, 1>(c, qx, qx + 64, nullptr, nullptr, first + 1, last, Kp, dropRight);       // small ranges: no work on empty slots
             else cut = ss_partition<true, SS_NE_LDS>(c, qx, qx + 64 * SS_NE_LDS, nullptr, nullptr, first + 1, last, Kp, dropRight);
             if (inLDS) { SSPROF(SP_PART_LDS); SSCNT(SP_N_PART_LDS, 1); SSCNT(SP_V_PART_LDS, m); } else { SSPROF(SP_PART_MEM); SSCNT(SP_N_PART_MEM, 1); SSCNT(SP_V_PART_MEM, m); }
-            SS_PUSH(cut, last, depth, max(lb, Kp), ub);               // [cut, last): K >= Kp
+            // [cut, last): K >= Kp -- for the wave itself when the range sits in its LDS buffer, else for whichever wave is idle
+            if (NW == 1 || inLDS) SS_PUSH(cut, last, depth, max(lb, Kp), ub);
+            else if (max(lb, Kp) <= Kthr) {
+                SS_LOCK();
+                if (lane == 0) {
+                    const int e = atomicAdd(&ctl[1], 0);
+                    if (e < SHCAP) { shF[e] = cut; shL[e] = last; shD[e] = depth; shLb[e] = (int)max(lb, Kp); shUb[e] = (int)ub; atomicExch(&ctl[1], e + 1); }
+                    else atomicOr(status, 32);      // cannot happen: every wave adds at most its path's right siblings
+                }
+                SS_UNLOCK();
+            }
             last = cut; ub = min(ub, Kp);                             // [first, cut): K <= Kp (the pivot sits at first)
-            outPos = ssU(outPos);
         }
     }
 #undef SS_PUSH
+#undef SS_LOCK
+#undef SS_UNLOCK
 #ifdef OLF_SS_PROF
     SSPROF(SP_OTHER);
-    if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); for (int q = 0; q < SP_N; ++q) o[q] = sp_acc[q]; }
+    if (NW == 1 && lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); for (int q = 0; q < SP_N; ++q) o[q] = sp_acc[q]; }
 #endif
-    if (lane == 0) keyCount[img * 32] = outPos;
+    if (NW == 1) { if (lane == 0) keyCount[img * 32] = listedEnd; }
+    else {
+        if (lane == 0) atomicMax(&ctl[3], listedEnd);
+        __syncthreads();
+        if (threadIdx.x == 0) keyCount[img * 32] = ctl[3];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
+                                                     const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
+{
+    __shared__ __align__(8) uint32_t s_buf[SS_CAP];
+    __shared__ __align__(8) uint32_t s_x[4 * 64 * SS_NE_LDS];      // LDS path: the two stopper queues; memory path: the two staged blocks
+    static_assert(4 * 64 * SS_NE_MEM <= SS_CAP && 2 * 64 * SS_NE_MEM <= 4 * 64 * SS_NE_LDS, "memory path: queues in the range buffer, staged blocks in s_x");
+    ss_sort_image<1, SS_NE_MEM>(*gp, blockIdx.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, nullptr);
+}
+
+// few images (the drop-in's online shape: one stereo pair per call): NW waves per image, blocks of NEM tiles
+template <int NW, int NEM>
+__global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
+                                                            const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
+{
+    extern __shared__ __align__(8) uint32_t s_dyn[];
+    constexpr int BUFW = 4 * 64 * NEM, XW = 2 * 64 * NEM;
+    static_assert(XW >= 4 * 64 * SS_NE_LDS, "the LDS path's queues fit the staging area");
+    const int wv = threadIdx.x >> 6;
+    // the staging areas first: global_load_lds takes its LDS base from 16 bits of M0, so a staged block must lie in the first 64 KB of the
+    // workgroup's LDS (with the areas behind the range buffers, the waves above 64 KB staged their blocks into other waves' buffers)
+    uint32_t* s_x = s_dyn + (size_t)wv * XW;
+    uint32_t* s_buf = s_dyn + (size_t)NW * XW + (size_t)wv * BUFW;
+    int* ctl = reinterpret_cast<int*>(s_dyn + (size_t)NW * (BUFW + XW));
+    static_assert((size_t)NW * XW * 4 <= 65536, "staged blocks within reach of M0");
+    ss_sort_image<NW, NEM>(*gp, blockIdx.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl);
+}
+
+template <int NW, int NEM>
+static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
+{
+    const size_t lds = ((size_t)NW * (4 * 64 * NEM + 2 * 64 * NEM) + 4 + 5 * 256) * 4;
+    if (lds > 64 * 1024)       // per launch: the attribute belongs to the device the launch goes to
+        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM>), dim3(n_images), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride,
+                       kthrOverride, depthOverride);
+    return OLF_OK;
 }
 
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
-    hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride);
+    // OLF_SS_MW: 0 forces the one-wave kernel, 1 / 2 the 4- / 8-wave variant (A/B measurements); default: by batch size
+    static const int forced = [] { const char* e = getenv("OLF_SS_MW"); return e ? atoi(e) : -1; }();
+    // up to 256 images: 8 waves per image (101 KB of LDS, one workgroup per CU); up to 768: 4 waves (53 KB, three per CU); beyond: the batch kernel.
+    // One stereo pair through olf_stereo_frames, host to host: 25.6 ms with the one-wave kernel, 16.5 ms with 4 waves, 15.1 ms with 8
+    const int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 768 ? 1 : 0);
+    int rc = OLF_OK;
+    if (mode == 1) rc = launch_seedsort_mw<4, 8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else if (mode == 2) rc = launch_seedsort_mw<8, 8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else
+        hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride);
+    if (rc != OLF_OK) return rc;
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
