@@ -196,7 +196,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         for (int k = 0; k < SPAN / 64; ++k) {
             const int li = wv * SPAN + k * 64 + lane;
             const bool def = c0 + li < Ps && s_deg[c0 + li - lo] != kDegUndef;
-            const unsigned long long m = __ballot(def);
+            const unsigned long long m = wave_vote(def);
             if (def) s_list[wv * SPAN + wc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
             wc += __popcll(m);
         }
@@ -437,10 +437,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         int maskEpoch = flushEpoch;      // the window's USED bits as loaded here are complete up to this flush count
         const bool isoSeed = (wseed & kIso) != 0;
 #ifdef OLF_STATS
-        ++st_win; st_seedl += __popcll(__ballot(valid)); st_isos += __popcll(__ballot(valid && isoSeed));
+        ++st_win; st_seedl += __popcll(wave_vote(valid)); st_isos += __popcll(wave_vote(valid && isoSeed));
 #endif
         // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; ll_angle's seed loop skips them)
-        unsigned long long mask = __ballot(valid && !(wseed & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
+        unsigned long long mask = wave_vote(valid && !(wseed & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
         // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
         // are per-(gx, gy) table entries
         double seedAng = 0;
@@ -449,16 +449,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
             {
-                const unsigned long long isoM = __ballot(isoSeed) & mask;
+                const unsigned long long isoM = wave_vote(isoSeed) & mask;
                 const unsigned long long grow = mask & ~isoM;
                 const unsigned long long lead = isoM & (grow ? ((1ull << __builtin_ctzll(grow)) - 1ull) : ~0ull);
                 if (lead) {
                     const bool mine = (lead >> lane) & 1ull;
                     const int slot = addr & (PEND - 1);
-                    if (__ballot(mine && s_pend[slot] != -1)) PEND_FLUSH();
+                    if (wave_vote(mine && s_pend[slot] != -1)) PEND_FLUSH();
                     if (mine) { grad[addr] = wseed | kUsed; s_pend[slot] = addr; }
                     __builtin_amdgcn_wave_barrier();
-                    if (__ballot(mine && s_pend[slot] != addr)) PEND_FLUSH();
+                    if (wave_vote(mine && s_pend[slot] != addr)) PEND_FLUSH();
                     mask &= ~lead;
                     if (!mask) break;
                 }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
                 // that same angle, as in the reference), the angle is updated and the rest is re-tested.
                 PSTAMP(p_table);
-                unsigned long long cm = __ballot(cand);
+                unsigned long long cm = wave_vote(cand);
                 unsigned long long acc = 0;
 #ifdef OLF_STATS
                 st_cand += __popcll(cm);
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
                     const double nth = fabs(d_sub(reg_angle, ang));
                     const bool was = nth <= prec || nth >= precWrap;
-                    const unsigned long long al = __ballot(was) & cm;      // cm only ever holds live candidates
+                    const unsigned long long al = wave_vote(was) & cm;      // cm only ever holds live candidates
                     if (!al) break;
                     if ((al & (al - 1ull)) == 0) {
                         // a single aligned candidate: the plain sequential step
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         sumdx = (float)d_add((double)sumdx, cs_c);
                         sumdy = (float)d_add((double)sumdy, sn_c);
                         reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
-                        cm &= ~__ballot(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
+                        cm &= ~wave_vote(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
                         continue;
                     }
                     // Several candidates are aligned under the current (exact) angle.  Speculate that they are accepted in lane order: the
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         if (lane == j) { psx = sx; psy = sy; }
                         const bool tw = a == a_c;                                // c and the other FIFO entries' views of the same pixel
                         if (tw && lane != c) dupStep = j;                        // (a lane can only ever equal one accepted pixel)
-                        todo &= ~__ballot(tw);
+                        todo &= ~wave_vote(tw);
                         spec |= 1ull << c;
                         ++j;
                     }
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     if (g == 0) thg = reg_angle;
                     const double n2 = fabs(d_sub(thg, ang));
                     const bool re = n2 <= prec || n2 >= precWrap;
-                    const unsigned long long mis = __ballot(re != was && !(dupStep < g)) & cm;
+                    const unsigned long long mis = wave_vote(re != was && !(dupStep < g)) & cm;
                     const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
                     const unsigned long long okAcc = spec & bm;
                     const int t = __popcll(okAcc);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     acc |= okAcc;
                     n += t;
                     cm &= ~bm;                                         // everything before the first changed decision is decided
-                    cm &= ~__ballot(dupStep < t);                      // other views of the committed pixels
+                    cm &= ~wave_vote(dupStep < t);                      // other views of the committed pixels
                     sumdx = __int_as_float(rlane(__float_as_int(psx), t - 1));
                     sumdy = __int_as_float(rlane(__float_as_int(psy), t - 1));
                     reg_angle = rlane_d(th, t - 1);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 if (acc) {
                     const bool mine = (acc >> lane) & 1ull;
                     const int slot = a & (PEND - 1);
-                    if (__ballot(mine && s_pend[slot] != -1)) PEND_FLUSH();
+                    if (wave_vote(mine && s_pend[slot] != -1)) PEND_FLUSH();
                     if (mine) {
                         const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
                         grad[a] = pw | kUsed;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     }
                     __builtin_amdgcn_wave_barrier();
                     // two accepted pixels of this batch hashing to one slot: only one survived in the table -> make both visible
-                    if (__ballot(mine && s_pend[slot] != a)) PEND_FLUSH();
+                    if (wave_vote(mine && s_pend[slot] != a)) PEND_FLUSH();
                 }
                 i += nb;
                 __builtin_amdgcn_wave_barrier();
@@ -631,15 +631,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
             // seeds later in this 64-key window may have been consumed by the region just grown
 #ifdef OLF_STATS
-            st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(__ballot(valid && lane > l));
+            st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(wave_vote(valid && lane > l));
 #endif
             if (n == 1) mask &= mask - 1;
             else if (maskEpoch == flushEpoch) {
                 // no flush since the window's words were loaded: whatever has been marked since is still in the pending table -- no need to
                 // gather the 64 (spatially random) seed words again
-                mask &= ~((2ull << l) - 1ull) & __ballot(s_pend[addr & (PEND - 1)] != addr);
+                mask &= ~((2ull << l) - 1ull) & wave_vote(s_pend[addr & (PEND - 1)] != addr);
             } else {
-                mask = __ballot(valid && lane > l && !(grad[addr] & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
+                mask = wave_vote(valid && lane > l && !(grad[addr] & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
                 maskEpoch = flushEpoch;
             }
         }
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
         const int r = r0 + tid;
         SegCand c; c.keep = 0;
         if (r < nreg) c = cand[r];
-        const unsigned long long km = __ballot(c.keep != 0);
+        const unsigned long long km = wave_vote(c.keep != 0);
         if (lane == 0) s_wave[wave] = __popcll(km);
         __syncthreads();
         int pos = s_base + __popcll(km & ((1ull << lane) - 1ull));

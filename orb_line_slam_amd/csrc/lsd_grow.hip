@@ -170,10 +170,10 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
         const uint32_t iv = in ? WG_LOAD(c.eInval + slot) : 0u;
         const int n = in ? WG_LOAD(c.eN + slot) : 0;
         const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE);       // DONE with a steal noted: has to be re-run first
-        const unsigned long long cm = __ballot(can);
+        const unsigned long long cm = wave_vote(can);
         const int run = cm == ~0ull ? 64 : __builtin_ctzll(~cm);
         const unsigned long long low = run >= 64 ? ~0ull : ((1ull << run) - 1ull);
-        unsigned long long big = __ballot(st == ST_DONE && n >= c.minRegSize) & low;
+        unsigned long long big = wave_vote(st == ST_DONE && n >= c.minRegSize) & low;
         int nr = lds_u(c.ctl + C_NREG);
         while (big) {
             const int l = __builtin_ctzll(big);
@@ -233,7 +233,7 @@ __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, cons
         const uint32_t wm = cl.wm;
         // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; they are never seeds)
         const bool live = valid && !(w & kNotDef) && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
-        const unsigned long long m = __ballot(live);
+        const unsigned long long m = wave_vote(live);
         if (live) {
             s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
             claim = iso && o == MW_FREE;
@@ -278,7 +278,7 @@ __device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* pre
         const int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
         const uint32_t bl = WG_LOAD(c.eBlock + slot), iv = WG_LOAD(c.eInval + slot);
         const bool el = st == ST_READY || (st == ST_PARKED && bl < wm) || (st == ST_DONE && iv != MW_FREE && iv < wm);
-        unsigned long long m = __ballot(el);
+        unsigned long long m = wave_vote(el);
         while (m) {
             const int l = __builtin_ctzll(m);
             const int s = (base + l) & c.mask;
@@ -359,7 +359,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
     // ours now and that region is told
 #define MW_PENDING() do { \
         if (pMine && pOld != MW_FREE && pOld > T) mw_notify(c, pOld, rank); \
-        const unsigned long long _bad = __ballot(pMine && pOld <= T); \
+        const unsigned long long _bad = wave_vote(pMine && pOld <= T); \
         pMine = false; \
         if (_bad) { const uint32_t _o = (uint32_t)rlane((int)pOld, __builtin_ctzll(_bad)); blocker = _o == T ? 0u : (_o >> MW_SLOT_BITS); fail = true; \
                     seedLost = n == 1 && i == 0 && _bad == 1ull; \
@@ -402,8 +402,8 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             ang = t->ang;
             cs = t->cs; sn = t->sn;
         }
-        unsigned long long cm = __ballot(cand);
-        const unsigned long long conM = __ballot(con);
+        unsigned long long cm = wave_vote(cand);
+        const unsigned long long conM = wave_vote(con);
         PROF(PF_GATHER);
         unsigned long long acc = 0;
         const int n0 = n;
@@ -411,7 +411,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             // isaligned(): see k_lsd_grow (lsd.hip) -- wrapped test against precWrap, candidates in lane order = the reference's visiting order
             const double nth = fabs(d_sub(reg_angle, ang));
             const bool was = nth <= prec || nth >= precWrap;
-            const unsigned long long al = __ballot(was) & cm;
+            const unsigned long long al = wave_vote(was) & cm;
             if (!al) break;
             if ((al & (al - 1ull)) == 0) {
                 const int cc = __builtin_ctzll(al);
@@ -423,7 +423,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
                 sumdx = (float)d_add((double)sumdx, cs_c);
                 sumdy = (float)d_add((double)sumdy, sn_c);
                 reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
-                cm &= ~__ballot(a == a_c);
+                cm &= ~wave_vote(a == a_c);
                 continue;
             }
             // speculative round (see lsd.hip): all aligned candidates assumed accepted in lane order, one fastAtan2 for all their angles, every
@@ -440,7 +440,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
                 if (lane == j) { psx = sx; psy = sy; }
                 const bool tw = a == a_c;
                 if (tw && lane != cc) dupStep = j;
-                todo &= ~__ballot(tw);
+                todo &= ~wave_vote(tw);
                 spec |= 1ull << cc;
                 ++j;
             }
@@ -450,14 +450,14 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             if (gq == 0) thg = reg_angle;
             const double n2 = fabs(d_sub(thg, ang));
             const bool re = n2 <= prec || n2 >= precWrap;
-            const unsigned long long mis = __ballot(re != was && !(dupStep < gq)) & cm;
+            const unsigned long long mis = wave_vote(re != was && !(dupStep < gq)) & cm;
             const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
             const unsigned long long okAcc = spec & bm;
             const int tt = __popcll(okAcc);
             acc |= okAcc;
             n += tt;
             cm &= ~bm;
-            cm &= ~__ballot(dupStep < tt);
+            cm &= ~wave_vote(dupStep < tt);
             sumdx = __int_as_float(rlane(__float_as_int(psx), tt - 1));
             sumdy = __int_as_float(rlane(__float_as_int(psy), tt - 1));
             reg_angle = rlane_d(th, tt - 1);

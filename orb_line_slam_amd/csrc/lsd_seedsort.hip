@@ -93,7 +93,7 @@ __device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t* XL, uint32_t* X
         swG[u] = false; swLE[u] = false;
         if (jG[u] >= 0 && jG[u] < nLE) swG[u] = pos < (int)XR[jG[u]];
         if (jLE[u] >= 0 && jLE[u] < nG) swLE[u] = (int)XL[jLE[u]] < pos;       // (an element equal to the pivot is in both sets but can only swap as one of them)
-        s += (int)__popcll(__ballot(swG[u]));
+        s += (int)__popcll(wave_vote(swG[u]));
     }
     s = ssU(s);
     __builtin_amdgcn_wave_barrier();
@@ -109,7 +109,7 @@ __device__ __forceinline__ int ss_zone(const SsCtx& c, uint32_t* XL, uint32_t* X
         const int pos = B.base + 64 * u + lane;
         if (swG[u]) { B.v[u] = XR[jG[u]]; ss_st<LDS>(c, pos, B.v[u]); }
         if (swLE[u]) { B.v[u] = XL[jLE[u]]; ss_st<LDS>(c, pos, B.v[u]); }
-        const unsigned long long cand = __ballot(jG[u] == s || (s >= 1 && jLE[u] == s - 1));
+        const unsigned long long cand = wave_vote(jG[u] == s || (s >= 1 && jLE[u] == s - 1));
         if (cand) cut = min(cut, B.base + 64 * u + (int)__builtin_ctzll(cand));
     }
     __builtin_amdgcn_wave_barrier();
@@ -163,7 +163,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
             for (int u = 0; u < NE; ++u) {
                 const int pos = lc + 64 * u + lane;
                 const bool st = pos < L.lim && ssK(L.v[u]) >= Kp;
-                const unsigned long long m = __ballot(st);
+                const unsigned long long m = wave_vote(st);
                 L.rk[u] = st ? run + ss_rank_below(m) : -1;
                 if (st) QL[L.rk[u]] = make_uint2((uint32_t)pos, L.v[u]);
                 run += (int)__popcll(m);
@@ -197,7 +197,7 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
             for (int u = NE - 1; u >= 0; --u) {
                 const int pos = R.base + 64 * u + lane;
                 const bool st = pos >= R.lim && ssK(R.v[u]) <= Kp;
-                const unsigned long long m = __ballot(st);
+                const unsigned long long m = wave_vote(st);
                 const int cnt = (int)__popcll(m);
                 R.rk[u] = st ? run + cnt - 1 - ss_rank_below(m) : -1;
                 if (st) QR[R.rk[u]] = make_uint2((uint32_t)pos, R.v[u]);
@@ -228,13 +228,13 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
         // the right scan walks into the left side's last block from above: the zone is [first pending stopper, end of that block)
         int l0 = lc;
 #pragma unroll
-        for (int u = 0; u < NE; ++u) { const unsigned long long mm = __ballot(L.rk[u] == L.c); if (mm) l0 = L.base + 64 * u + (int)__builtin_ctzll(mm); }
+        for (int u = 0; u < NE; ++u) { const unsigned long long mm = wave_vote(L.rk[u] == L.c); if (mm) l0 = L.base + 64 * u + (int)__builtin_ctzll(mm); }
         int jG[NE], jLE[NE], run = 0;
 #pragma unroll
         for (int u = NE - 1; u >= 0; --u) {
             const int pos = L.base + 64 * u + lane;
             const bool le = pos < L.lim && pos >= l0 && ssK(L.v[u]) <= Kp;
-            const unsigned long long m = __ballot(le);
+            const unsigned long long m = wave_vote(le);
             const int cnt = (int)__popcll(m);
             jLE[u] = le ? run + cnt - 1 - ss_rank_below(m) : -1;
             run += cnt;
@@ -246,13 +246,13 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
         // the left scan walks into the right side's last block from below: the zone is [start of that block, last pending stopper]
         int r0 = rc;
 #pragma unroll
-        for (int u = 0; u < NE; ++u) { const unsigned long long mm = __ballot(R.rk[u] == R.c); if (mm) r0 = R.base + 64 * u + (int)__builtin_ctzll(mm); }
+        for (int u = 0; u < NE; ++u) { const unsigned long long mm = wave_vote(R.rk[u] == R.c); if (mm) r0 = R.base + 64 * u + (int)__builtin_ctzll(mm); }
         int jG[NE], jLE[NE], run = 0;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
             const int pos = R.base + 64 * u + lane;
             const bool ge = pos >= R.lim && pos <= r0 && ssK(R.v[u]) >= Kp;
-            const unsigned long long m = __ballot(ge);
+            const unsigned long long m = wave_vote(ge);
             jG[u] = ge ? run + ss_rank_below(m) : -1;
             run += (int)__popcll(m);
             jLE[u] = R.rk[u] >= R.c ? R.rk[u] - R.c : -1;
@@ -356,7 +356,7 @@ __device__ __forceinline__ int ss_emit_leaf(const SsCtx& c, int first, int last,
     }
     const bool listed = lane < m && k <= Kthr;
     if (listed) c.out[outPos + rank] = v;
-    return outPos + (int)__popcll(__ballot(listed));
+    return outPos + (int)__popcll(wave_vote(listed));
 }
 
 // a sorted range: its listed elements are a prefix
@@ -368,7 +368,7 @@ __device__ __forceinline__ int ss_emit_sorted(const SsCtx& c, int first, int las
         const uint32_t v = p < last ? ss_ld<LDS>(c, p) : 0xffffffffu;
         const bool listed = p < last && ssK(v) <= Kthr;
         if (listed) c.out[outPos + p - first] = v;
-        cnt += (int)__popcll(__ballot(listed));
+        cnt += (int)__popcll(wave_vote(listed));
     }
     return outPos + cnt;
 }

@@ -21,10 +21,10 @@ constexpr int SORT_CHUNK = 8192, RB = 32;
 // lanes of the wave whose digit equals this lane's (valid lanes only)
 __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid)
 {
-    unsigned long long m = __ballot(valid);
+    unsigned long long m = wave_vote(valid);
 #pragma unroll
     for (int bit = 0; bit < 5; ++bit) {
-        const unsigned long long bm = __ballot((d >> bit) & 1u);
+        const unsigned long long bm = wave_vote((d >> bit) & 1u);
         m &= ((d >> bit) & 1u) ? bm : ~bm;
     }
     return m;

@@ -32,6 +32,12 @@ namespace olf {
 
 void set_error(const std::string& s);
 
+#ifdef __HIPCC__
+// Wave-wide vote.  hip's __ballot() converts the predicate to an int first and compares that with 0 (a v_cndmask + v_cmp_ne pair per vote);
+// the wave64 builtin takes the compare's lane mask as it is.
+__device__ __forceinline__ unsigned long long wave_vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
+
 constexpr int kEdge = 19;          // EDGE_THRESHOLD   src/ORBextractor.cc:76
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD-3 src/ORBextractor.cc:775
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE  src/ORBextractor.cc:75

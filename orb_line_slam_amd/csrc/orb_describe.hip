@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1f, b), __fmul_rn(y1f, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1f, a), __fmul_rn(y1f, b)));
         const int t0 = pb[r0 * (PDW * 4) + c0], t1 = pb[r1 * (PDW * 4) + c1];
-        bits[j] = __ballot(t0 < t1);
+        bits[j] = wave_vote(t0 < t1);
     }
     if (lane == 0) {
         unsigned long long* d = reinterpret_cast<unsigned long long*>(desc + ((size_t)img * out_cap + outIdx) * OLF_DESC_BYTES);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
             const bool b0 = n0 > hiT, b4 = n4 > hiT, b8 = n8 > hiT, b12 = n12 > hiT;
             const bool d0 = n0 < loT, d4 = n4 < loT, d8 = n8 < loT, d12 = n12 < loT;
             const bool pass = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) && gx >= xBeg && gx < xEnd && gy >= yBeg && gy < yEnd;
-            const unsigned long long pm = __ballot(pass);
+            const unsigned long long pm = wave_vote(pass);
             if (pm) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_nc, __popcll(pm));
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ g
     if (n <= 64) {
         // the common case: one key per lane, rank = number of smaller keys (keys are distinct: one per pixel), no LDS, no barriers
         uint32_t k = lane < n ? slot[lane] : 0xffffffffu;
-        const bool anyIni = __ballot(lane < n && (int)(k & 0xffu) >= g.iniTh) != 0;
+        const bool anyIni = wave_vote(lane < n && (int)(k & 0xffu) >= g.iniTh) != 0;
         if (anyIni && (int)(k & 0xffu) < g.iniTh) k = 0xffffffffu;
-        const int kept = __popcll(__ballot(k != 0xffffffffu));
+        const int kept = __popcll(wave_vote(k != 0xffffffffu));
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)k, j) < k;
         if (k != 0xffffffffu) slot[rank] = (((k >> 8) & 0xfffu) << 20) | ((k >> 20) << 8) | (k & 0xffu);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ g
         s_k[i] = k;
         anyIni |= i < n && (int)(k & 0xffu) >= g.iniTh;
     }
-    anyIni = __ballot(anyIni) != 0;
+    anyIni = wave_vote(anyIni) != 0;
     __builtin_amdgcn_wave_barrier();
     int kept = n;
     if (anyIni) {
