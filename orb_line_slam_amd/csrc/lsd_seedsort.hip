@@ -388,25 +388,32 @@ enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OT
 // the sorted array, so no wave needs to know what the others have emitted: ranges that stream from memory go through a stack in LDS that any idle
 // wave pops from, a range that fits a wave's LDS buffer is finished by that wave alone (its own register stack).  NEM: tiles per streamed block --
 // one wave alone is bound by the latency of a block step, not by issue slots, so the few-images variant uses larger blocks.
-template <int NW, int NEM>
-__device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
+// NI > 1 (= NW): the workgroup sorts NI images, one per wave to begin with, and the shared stack holds the streamed ranges of all of them (the image's
+// slot travels in the entry's depth word): a wave that runs out of work takes over a range of a neighbour's image, so the launch ends near the *mean*
+// sorting time of the images of a CU instead of the slowest one's (the big batch).
+template <int NW, int NEM, int NI = 1>
+__device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_images, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                               const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
                                               uint32_t* s_buf, uint32_t* s_x, int* ctl)
 {
+    static_assert(NI == 1 || NI == NW, "one wave per image of the group");
 #ifdef OLF_SS_PROF
     long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
 #endif
     constexpr int CAP = NEM > SS_NE_MEM ? 4 * 64 * NEM : SS_CAP;          // elements of a range a wave keeps in LDS (= the words of its range buffer)
-    constexpr int SHCAP = 256;                                            // entries of the shared stack (NW > 1)
+    constexpr int SHCAP = NI > 1 ? 64 : 256;                              // entries of the shared stack (NW > 1)
     const int lane = threadIdx.x & 63;
+    const int img0 = img;                                                 // NI > 1: the group's first image; this wave starts on image img0 + wave
+    if (NI > 1) img = img0 + ssU((int)(threadIdx.x >> 6));      // (pinned: the wave index is uniform, the compiler does not know it)
     SsCtx c;
     c.A = keysInAll + (size_t)img * g.Ps;
     c.out = keysOutAll + (size_t)img * g.Ps;
     c.sbuf = s_buf; c.ldsFirst = 0; c.lane = lane;
     const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
     uint32_t Kthr = 0;
-    bool empty = n <= 0;
-    if (kthrOverride >= 0) Kthr = (uint32_t)kthrOverride;
+    bool empty = n <= 0 || img >= n_images;
+    if (empty) {}
+    else if (kthrOverride >= 0) Kthr = (uint32_t)kthrOverride;
     else {
         const int mN = maxN[img * 32];
         if (mN <= 0) empty = true;                                        // no defined pixel: no seed
@@ -419,7 +426,7 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32
             Kthr = (uint32_t)(g.nBins - 1 - binT);
         }
     }
-    if (empty) { if (threadIdx.x == 0) keyCount[img * 32] = 0; return; }
+    if (NI == 1 && empty) { if (threadIdx.x == 0) keyCount[img * 32] = 0; return; }
     const int depth0 = depthOverride >= 0 ? depthOverride : 2 * (31 - __builtin_clz((unsigned)n));
     // the ranges still to do (right siblings on the path), one per lane: at most depth0 + 1 <= 43 of them
     int stF = 0, stL = 0, stD = 0;
@@ -430,12 +437,25 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32
     int* const shF = ctl + 4; int* const shL = shF + SHCAP; int* const shD = shL + SHCAP; int* const shLb = shD + SHCAP; int* const shUb = shLb + SHCAP;
 #define SS_LOCK() do { if (lane == 0) { int _sp = 0; while (atomicCAS(&ctl[0], 0, 1) != 0) { __builtin_amdgcn_s_sleep(2); if (++_sp > (1 << 22)) { atomicOr(status, 128); break; } } } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define SS_UNLOCK() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); if (lane == 0) atomicExch(&ctl[0], 0); } while (0)
+    // NI > 1: per image slot the seeds listed so far and its Kthr, behind the stack's arrays
+    int* const cntS = shUb + SHCAP; int* const kthS = cntS + 8; int* const okS = kthS + 8;
+    int curSlot = NI > 1 ? ssU((int)(threadIdx.x >> 6)) : 0;
     if (NW == 1) SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
-    else {
+    else if (NI == 1) {
         if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; ctl[3] = 0; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
         __syncthreads();
+    } else {
+        if (lane == 0) { cntS[curSlot] = 0; kthS[curSlot] = (int)Kthr; okS[curSlot] = empty ? 0 : 1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int e = 0;
+            for (int i = NI - 1; i >= 0; --i)      // (slot 0 on top)
+                if (okS[i]) { shF[e] = 0; shL[e] = n; shD[e] = depth0 | (i << 8); shLb[e] = 0; shUb[e] = g.nBins - 1; ++e; }
+            ctl[0] = 0; ctl[1] = e; ctl[2] = 0; ctl[3] = 0;
+        }
+        __syncthreads();
     }
-    int listedEnd = 0;                 // one past the last seed this wave has listed
+    int listedEnd = 0;                 // one past the last seed this wave has listed (of the image it is working on)
     bool inLDS = false, holding = false;
     int ldsLast = 0;
     int guard = 0;
@@ -450,20 +470,41 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32
         } else if (NW == 1) break;
         else {
             inLDS = false;
+            if (holding) { if (lane == 0) atomicSub(&ctl[2], 1); holding = false; }
+            // An idle wave looks at the counters WITHOUT the lock and only takes it when there is an entry to pop or the end to confirm: idle waves
+            // that poll through the lock form a convoy that a working wave with a range to push never gets into (seen with 3 idle waves of 4:
+            // 4 M failed attempts in a row -- the hardware's timing is deterministic enough to phase-lock).
+            for (int idle = 0;; ++idle) {
+                const int e = ssU(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const int bz = ssU(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (e > 0 || bz == 0) break;
+                __builtin_amdgcn_s_sleep(16);
+                if (idle > (1 << 21)) { if (lane == 0) atomicOr(status, 64); break; }
+            }
             int got = 0, done = 0, f = 0, l = 0, d = 0, a = 0, b = 0;
             SS_LOCK();
             if (lane == 0) {
-                if (holding) atomicSub(&ctl[2], 1);
                 const int e = atomicAdd(&ctl[1], 0);
-                if (e > 0) { f = shF[e - 1]; l = shL[e - 1]; d = shD[e - 1]; a = shLb[e - 1]; b = shUb[e - 1]; atomicExch(&ctl[1], e - 1); atomicAdd(&ctl[2], 1); got = 1; }
+                if (e > 0) { f = shF[e - 1]; l = shL[e - 1]; d = shD[e - 1]; a = shLb[e - 1]; b = shUb[e - 1]; atomicAdd(&ctl[2], 1); atomicExch(&ctl[1], e - 1); got = 1; }
                 else if (atomicAdd(&ctl[2], 0) == 0) done = 1;
             }
             SS_UNLOCK();
             got = ssU(got); done = ssU(done);
             holding = got != 0;
             if (done) break;
-            if (!got) { __builtin_amdgcn_s_sleep(8); continue; }
+            if (!got) continue;
             first = ssU(f); last = ssU(l); depth = ssU(d); lb = (uint32_t)ssU(a); ub = (uint32_t)ssU(b);
+            if (NI > 1) {
+                const int slot = depth >> 8;
+                depth &= 255;
+                if (slot != curSlot) {
+                    if (lane == 0 && listedEnd > 0) atomicMax(&cntS[curSlot], listedEnd);
+                    listedEnd = 0; curSlot = slot;
+                    c.A = keysInAll + (size_t)(img0 + slot) * g.Ps;
+                    c.out = keysOutAll + (size_t)(img0 + slot) * g.Ps;
+                }
+                Kthr = (uint32_t)ssU(kthS[slot]);
+            }
         }
         first = ssU(first); last = ssU(last); depth = ssU(depth); lb = (uint32_t)ssU((int)lb); ub = (uint32_t)ssU((int)ub);
         if (inLDS && first >= ldsLast) inLDS = false;
@@ -525,13 +566,17 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32
             // [cut, last): K >= Kp -- for the wave itself when the range sits in its LDS buffer, else for whichever wave is idle
             if (NW == 1 || inLDS) SS_PUSH(cut, last, depth, max(lb, Kp), ub);
             else if (max(lb, Kp) <= Kthr) {
+                int full = 0;
                 SS_LOCK();
                 if (lane == 0) {
                     const int e = atomicAdd(&ctl[1], 0);
-                    if (e < SHCAP) { shF[e] = cut; shL[e] = last; shD[e] = depth; shLb[e] = (int)max(lb, Kp); shUb[e] = (int)ub; atomicExch(&ctl[1], e + 1); }
-                    else atomicOr(status, 32);      // cannot happen: every wave adds at most its path's right siblings
+                    if (e < SHCAP) { shF[e] = cut; shL[e] = last; shD[e] = NI > 1 ? depth | (curSlot << 8) : depth; shLb[e] = (int)max(lb, Kp); shUb[e] = (int)ub; atomicExch(&ctl[1], e + 1); }
+                    else full = 1;
                 }
                 SS_UNLOCK();
+                // a full stack: the wave keeps the range for itself (its own stack is emptied before it looks at the shared one again, so the
+                // range is still of the image the wave is on)
+                if (ssU(full)) SS_PUSH(cut, last, depth, max(lb, Kp), ub);
             }
             last = cut; ub = min(ub, Kp);                             // [first, cut): K <= Kp (the pivot sits at first)
         }
@@ -544,7 +589,11 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, uint32
     if (NW == 1 && lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); for (int q = 0; q < SP_N; ++q) o[q] = sp_acc[q]; }
 #endif
     if (NW == 1) { if (lane == 0) keyCount[img * 32] = listedEnd; }
-    else {
+    else if (NI > 1) {
+        if (lane == 0 && listedEnd > 0) atomicMax(&cntS[curSlot], listedEnd);
+        __syncthreads();
+        if (threadIdx.x < NI && img0 + (int)threadIdx.x < n_images) keyCount[(img0 + (int)threadIdx.x) * 32] = cntS[threadIdx.x];
+    } else {
         if (lane == 0) atomicMax(&ctl[3], listedEnd);
         __syncthreads();
         if (threadIdx.x == 0) keyCount[img * 32] = ctl[3];
@@ -557,13 +606,14 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
     __shared__ __align__(8) uint32_t s_buf[SS_CAP];
     __shared__ __align__(8) uint32_t s_x[4 * 64 * SS_NE_LDS];      // LDS path: the two stopper queues; memory path: the two staged blocks
     static_assert(4 * 64 * SS_NE_MEM <= SS_CAP && 2 * 64 * SS_NE_MEM <= 4 * 64 * SS_NE_LDS, "memory path: queues in the range buffer, staged blocks in s_x");
-    ss_sort_image<1, SS_NE_MEM>(*gp, blockIdx.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, nullptr);
+    ss_sort_image<1, SS_NE_MEM>(*gp, blockIdx.x, gridDim.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, nullptr);
 }
 
 // few images (the drop-in's online shape: one stereo pair per call): NW waves per image, blocks of NEM tiles
-template <int NW, int NEM>
+template <int NW, int NEM, int NI>
 __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
-                                                            const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
+                                                            const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
+                                                            int n_images)
 {
     extern __shared__ __align__(8) uint32_t s_dyn[];
     constexpr int BUFW = 4 * 64 * NEM, XW = 2 * 64 * NEM;
@@ -575,30 +625,60 @@ __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __r
     uint32_t* s_buf = s_dyn + (size_t)NW * XW + (size_t)wv * BUFW;
     int* ctl = reinterpret_cast<int*>(s_dyn + (size_t)NW * (BUFW + XW));
     static_assert((size_t)NW * XW * 4 <= 65536, "staged blocks within reach of M0");
-    ss_sort_image<NW, NEM>(*gp, blockIdx.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl);
+    ss_sort_image<NW, NEM, NI>(*gp, blockIdx.x * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl);
 }
 
-template <int NW, int NEM>
+// the batch in image groups: NI waves, NI images, the one-wave kernel's block size and LDS per wave -- and its six waves per SIMD
+template <int NI>
+__global__ __launch_bounds__(64 * NI) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void k_lsd_seedsort_grp(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
+                        const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride, int n_images)
+{
+    extern __shared__ __align__(8) uint32_t s_dyn[];
+    constexpr int BUFW = SS_CAP, XW = 4 * 64 * SS_NE_LDS;
+    const int wv = threadIdx.x >> 6;
+    uint32_t* s_x = s_dyn + (size_t)wv * XW;                              // (staging areas first: within reach of M0)
+    uint32_t* s_buf = s_dyn + (size_t)NI * XW + (size_t)wv * BUFW;
+    int* ctl = reinterpret_cast<int*>(s_dyn + (size_t)NI * (BUFW + XW));
+    ss_sort_image<NI, SS_NE_MEM, NI>(*gp, blockIdx.x * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl);
+}
+
+template <int NI>
+static int launch_seedsort_grp(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
+{
+    const size_t lds = ((size_t)NI * (SS_CAP + 4 * 64 * SS_NE_LDS) + 4 + 5 * 64 + 24) * 4;
+    hipLaunchKernelGGL((k_lsd_seedsort_grp<NI>), dim3((n_images + NI - 1) / NI), dim3(64 * NI), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
+                       nOverride, kthrOverride, depthOverride, n_images);
+    return OLF_OK;
+}
+
+template <int NW, int NEM, int NI>
 static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
-    const size_t lds = ((size_t)NW * (4 * 64 * NEM + 2 * 64 * NEM) + 4 + 5 * 256) * 4;
+    // per wave: range buffer + staging area; then lock / counters, the shared stack's five arrays (256 entries, 64 for image groups) and the groups' slots
+    const size_t lds = ((size_t)NW * (4 * 64 * NEM + 2 * 64 * NEM) + 4 + 5 * (NI > 1 ? 64 : 256) + 24) * 4;
     if (lds > 64 * 1024)       // per launch: the attribute belongs to the device the launch goes to
-        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM>), dim3(n_images), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride,
-                       kthrOverride, depthOverride);
+        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3((n_images + NI - 1) / NI), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
+                       nOverride, kthrOverride, depthOverride, n_images);
     return OLF_OK;
 }
 
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
-    // OLF_SS_MW: 0 forces the one-wave kernel, 1 / 2 the 4- / 8-wave variant (A/B measurements); default: by batch size
+    // OLF_SS_MW: 0 forces the one-wave kernel, 1 / 2 the 4- / 8-wave variant, 3 / 4 groups of 4 / 8 images (A/B measurements); default: by batch size
     static const int forced = [] { const char* e = getenv("OLF_SS_MW"); return e ? atoi(e) : -1; }();
-    // up to 256 images: 8 waves per image (101 KB of LDS, one workgroup per CU); up to 768: 4 waves (53 KB, three per CU); beyond: the batch kernel.
+    // up to 256 images: 8 waves per image (101 KB of LDS, one workgroup per CU); up to 768: 4 waves (53 KB, three per CU); beyond: one wave per image --
+    // alone (mode 0).  Modes 3 / 4 (groups of 4 / 8 images whose waves take over each other's streamed ranges) are opt-in: on 6144 copies of 32 images
+    // the kernel goes 43.5 -> 37.9 ms (groups of 8; 40.2 with 4; equal at 1536 images), on the bench's 512 distinct pairs the front does not move
+    // (71.3 against 71.7 ms) and the step is 278.9 against 276.8 ms -- the launch is bound by issue slots, not by its slowest image.
     // One stereo pair through olf_stereo_frames, host to host: 25.6 ms with the one-wave kernel, 16.5 ms with 4 waves, 15.1 ms with 8
     const int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 768 ? 1 : 0);
     int rc = OLF_OK;
-    if (mode == 1) rc = launch_seedsort_mw<4, 8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
-    else if (mode == 2) rc = launch_seedsort_mw<8, 8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    if (mode == 1) rc = launch_seedsort_mw<4, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else if (mode == 2) rc = launch_seedsort_mw<8, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else if (mode == 3) rc = launch_seedsort_grp<4>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else if (mode == 4) rc = launch_seedsort_grp<8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else
         hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride);
     if (rc != OLF_OK) return rc;

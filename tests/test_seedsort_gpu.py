@@ -55,23 +55,26 @@ def test_sort_kernel_equals_std_sort_on_random_arrays(oracle, sorter):
 
 
 def test_sort_kernel_variants_agree(oracle):
-    """one wave per image (the batch kernel) and 4 / 8 cooperating waves per image (few images; ranges handed from wave to wave through a stack
-    in LDS, larger blocks) give the same list: arrays that keep every wave busy, and the line path on a KITTI-sized pair under each variant"""
-    ex = ola.Lineextractor(500, 0.025, max_images=2)
-    ctx = ex._context(1242, 375, 2)
+    """one wave per image (the batch kernel), 4 / 8 cooperating waves per image (few images; ranges handed from wave to wave through a stack
+    in LDS, larger blocks) and groups of 4 / 8 images per workgroup whose waves take over each other's ranges give the same list: arrays that
+    keep every wave busy, and the line path on seven KITTI-sized images (a group that is not full, an image without any seed) under each variant"""
+    ex = ola.Lineextractor(500, 0.025, max_images=7)
+    ctx = ex._context(1242, 375, 7)
     rng = np.random.default_rng(8)
     cases = [_keys(rng, n, nk, mode) for n, nk, mode in [(400000, 1024, 4), (668561, 1024, 4), (100000, 1024, 0), (250000, 7, 0), (70000, 1, 0), (5000, 1024, 5)]]
     p = oracle.full_params(2000, 500)
-    imgs = synth.stereo_batch(17, 1, 1242, 375)
+    imgs = np.concatenate([synth.stereo_batch(17, 3, 1242, 375), np.full((1, 375, 1242), 90, np.uint8)])
+    imgs = imgs[[0, 1, 6, 2, 3, 4, 5]]
     want_lines = [oracle.line_extract(im, p.line) for im in imgs]
-    for mode in (0, 1, 2):
+    assert len(want_lines[2]["kls"]) == 0 and len(want_lines[0]["kls"]) > 100
+    for mode in (0, 1, 2, 3, 4):
         _lib.check(_lib.lib().olf_debug_seed_sort_mode(ctx.handle, mode), "olf_debug_seed_sort_mode")
         for keys in cases:
             out = np.zeros(len(keys), np.uint32); n = C.c_int32()
             _lib.check(_lib.lib().olf_debug_seed_sort(ctx.handle, _lib.ptr(keys), len(keys), 1023, -1, _lib.ptr(out), C.byref(n)), "olf_debug_seed_sort")
             assert n.value == len(keys) and np.array_equal(out, oracle.std_sort_keys(keys)), (mode, len(keys))
         kls, desc, counts = ex.extract_batch(imgs)
-        for i in range(2):
+        for i in range(len(imgs)):
             c = int(counts[i])
             assert np.array_equal(kls[i, :c], want_lines[i]["kls"]) and np.array_equal(desc[i, :c], want_lines[i]["desc"]), (mode, i)
     _lib.check(_lib.lib().olf_debug_seed_sort_mode(ctx.handle, -1), "olf_debug_seed_sort_mode")
