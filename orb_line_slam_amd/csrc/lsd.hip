@@ -482,6 +482,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             int iters = 0;
 #endif
             int i = 0;
+            // the check that two pixels accepted in one iteration did not hash to one table slot is read back after the commit's writes but only
+            // looked at below the next iteration's ring read (one LDS round trip less on the agent's dependent chain)
+            bool chkOn = false;
+            int chkA = -1, chkV = -1;
+#define PEND_VERIFY() do { if (chkOn) { if (wave_vote(chkV != chkA)) PEND_FLUSH(); chkOn = false; } } while (0)
             while (i < n) {
 #ifdef OLF_TIMING
                 ++iters;
@@ -491,21 +496,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
                 ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2; if (n - i > RING) ++st_mem;
 #endif
-                if (n - i > RING) __threadfence_block();   // window left the ring: read the FIFO from memory
                 // one predicate, no nested regions: every lane forms an address (0 when it has nothing to look at) and loads; only the
                 // table lookups, which cost real cache traffic, are skipped for non-candidates
 #ifdef OLF_TIMING2
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
 #endif
                 bool cand = lane < 63 && e < nb && k != 4;
-                const uint32_t rp = (n - i > RING) ? reg[rbase + i + (cand ? e : 0)].x : s_ring[(i + e) & (RING - 1)];
+                // (the ring read is unconditional and the memory read a rare wave-uniform branch: as one conditional expression the two became a
+                // generic-pointer flat load, in front of which the compiler waits for the previous iteration's stores to be acknowledged)
+                uint32_t rp = s_ring[(i + e) & (RING - 1)];
+                asm volatile("" : "+v"(rp));        // (keeps the two loads from being merged again)
+                PEND_VERIFY();
+                if (n - i > RING) { __threadfence_block(); rp = reg[rbase + i + (cand ? e : 0)].x; __builtin_amdgcn_s_waitcnt(0x0F70); }   // window left the ring: read the FIFO from memory
                 const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                 cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
                 const int a = cand ? yy * Ws + xx : 0;
                 PSTAMP(p_ring);
                 const uint32_t pw = grad[a];
+                const int pendv = s_pend[a & (PEND - 1)];      // (unconditional: issued beside the gradient load instead of behind it; the commit reuses it)
                 const int xy = xx | (yy << 16);
-                cand = cand && !(pw & (kUsed | kNotDef)) && s_pend[a & (PEND - 1)] != a;
+                cand = cand && !(pw & (kUsed | kNotDef)) && pendv != a;
                 double ang = 0, cs = 0, sn = 0;
                 PSTAMP(p_gather);
                 if (cand) {
@@ -591,11 +601,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     reg_angle = rlane_d(th, t - 1);
                 }
                 PSTAMP(p_chain);
+                // vmcnt(0) while only loads can be outstanding (they have long returned): behind this point the stores below are the only vector
+                // memory operations in flight, so the next iteration's ring read and address arithmetic need not wait for their acknowledgement
+                // (without it the compiler waits at the loop head -- a table load of a lane that was no candidate may still target a live register)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
                     const bool mine = (acc >> lane) & 1ull;
                     const int slot = a & (PEND - 1);
-                    if (wave_vote(mine && s_pend[slot] != -1)) PEND_FLUSH();
+                    if (wave_vote(mine && pendv != -1)) PEND_FLUSH();      // (nothing has written the table since the gather read the lane's slot)
                     if (mine) {
                         const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
                         grad[a] = pw | kUsed;
@@ -604,13 +618,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         s_pend[slot] = a;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    // two accepted pixels of this batch hashing to one slot: only one survived in the table -> make both visible
-                    if (wave_vote(mine && s_pend[slot] != a)) PEND_FLUSH();
+                    // two accepted pixels of this batch hashing to one slot: only one survived in the table -> make both visible (PEND_VERIFY)
+                    chkA = mine ? a : -1;
+                    chkV = mine ? s_pend[slot] : -1;
+                    chkOn = true;
                 }
                 i += nb;
                 __builtin_amdgcn_wave_barrier();
                 PSTAMP(p_commit);
             }
+            PEND_VERIFY();
+#undef PEND_VERIFY
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; it_big += iters; } else { t_small += t1 - t0; ++n_small; it_small += iters; } t0 = t1; }
 #endif
