@@ -197,7 +197,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
             const int li = wv * SPAN + k * 64 + lane;
             const bool def = c0 + li < Ps && s_deg[c0 + li - lo] != kDegUndef;
             const unsigned long long m = wave_vote(def);
-            if (def) s_list[wv * SPAN + wc + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+            if (def) s_list[wv * SPAN + wc + wave_rank_below(m)] = (uint16_t)li;
             wc += __popcll(m);
         }
         if (lane == 0) s_wcnt[wv] = wc;
@@ -363,6 +363,9 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
 }
 
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 24 agents share a CU with other kernels)
+// lanes 9 e + k of the agent's 7 x 9 gather grid that look at a neighbour (k != 4: not the FIFO entry's own pixel; lane 63 is unused)
+constexpr unsigned long long neighbour_lanes() { unsigned long long m = 0; for (int l = 0; l < 63; ++l) if (l % 9 != 4) m |= 1ull << l; return m; }
+constexpr unsigned long long kNeighbourLanes = neighbour_lanes();
 constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be visible to a load yet (512 entries: 122.1 ms per 6144 images, 1024: 121.4 --
                              // fewer collisions, fewer flushes, fewer seed windows gathered twice; 5 KB of LDS per agent)
 
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         // are per-(gx, gy) table entries
         double seedAng = 0;
         float2 seedSum = make_float2(0.f, 0.f);
-        if (((mask >> lane) & 1ull) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
+        if (wave_bit(mask) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
             {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const unsigned long long grow = mask & ~isoM;
                 const unsigned long long lead = isoM & (grow ? ((1ull << __builtin_ctzll(grow)) - 1ull) : ~0ull);
                 if (lead) {
-                    const bool mine = (lead >> lane) & 1ull;
+                    const bool mine = wave_bit(lead);
                     const int slot = addr & (PEND - 1);
                     if (wave_vote(mine && s_pend[slot] != -1)) PEND_FLUSH();
                     if (mine) { grad[addr] = wseed | kUsed; s_pend[slot] = addr; }
@@ -501,24 +504,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_TIMING2
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
 #endif
-                bool cand = lane < 63 && e < nb && k != 4;
+                // candidates as lane masks (scalar registers) from here on: the 7 x 9 grid minus the centres, the first nb FIFO entries
+                const unsigned long long geo = kNeighbourLanes & ((1ull << (9 * nb)) - 1ull);
                 // (the ring read is unconditional and the memory read a rare wave-uniform branch: as one conditional expression the two became a
                 // generic-pointer flat load, in front of which the compiler waits for the previous iteration's stores to be acknowledged)
                 uint32_t rp = s_ring[(i + e) & (RING - 1)];
                 asm volatile("" : "+v"(rp));        // (keeps the two loads from being merged again)
                 PEND_VERIFY();
-                if (n - i > RING) { __threadfence_block(); rp = reg[rbase + i + (cand ? e : 0)].x; __builtin_amdgcn_s_waitcnt(0x0F70); }   // window left the ring: read the FIFO from memory
+                if (n - i > RING) { __threadfence_block(); rp = reg[rbase + i + (wave_bit(geo) ? e : 0)].x; __builtin_amdgcn_s_waitcnt(0x0F70); }   // window left the ring: read the FIFO from memory
                 const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
-                cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
-                const int a = cand ? yy * Ws + xx : 0;
+                const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
+                const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
                 PSTAMP(p_ring);
                 const uint32_t pw = grad[a];
                 const int pendv = s_pend[a & (PEND - 1)];      // (unconditional: issued beside the gradient load instead of behind it; the commit reuses it)
                 const int xy = xx | (yy << 16);
-                cand = cand && !(pw & (kUsed | kNotDef)) && pendv != a;
+                unsigned long long cm = inImg & wave_vote(!(pw & (kUsed | kNotDef))) & wave_vote(pendv != a);
                 double ang = 0, cs = 0, sn = 0;
                 PSTAMP(p_gather);
-                if (cand) {
+                if (wave_bit(cm)) {
                     const AngEnt* t = ent + (pw & 0x3fffffu);      // one 32-byte sector per candidate
                     cs = t->cs; sn = t->sn; ang = t->ang;
                 }
@@ -526,7 +530,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
                 // that same angle, as in the reference), the angle is updated and the rest is re-tested.
                 PSTAMP(p_table);
-                unsigned long long cm = wave_vote(cand);
                 unsigned long long acc = 0;
 #ifdef OLF_STATS
                 st_cand += __popcll(cm);
@@ -536,9 +539,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // isaligned(): n = |theta - a|; if (n > 3pi/2) n = |n - 2pi|; n <= prec.  For n in (3pi/2, 2pi + prec] the subtraction is exact
                     // (Sterbenz), so the wrapped test is n >= 2pi - prec, with that bound rounded up to a double on the host (precWrap);
                     // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
+                    // (votes per comparison, combined as lane masks: a vote on the combined predicate costs a v_cndmask + v_cmp pair on top)
                     const double nth = fabs(d_sub(reg_angle, ang));
-                    const bool was = nth <= prec || nth >= precWrap;
-                    const unsigned long long al = wave_vote(was) & cm;      // cm only ever holds live candidates
+                    const unsigned long long wasM = wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+                    const unsigned long long al = wasM & cm;      // cm only ever holds live candidates
                     if (!al) break;
                     if ((al & (al - 1ull)) == 0) {
                         // a single aligned candidate: the plain sequential step
@@ -584,8 +588,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     double thg = shfl_d(th, max(g - 1, 0));
                     if (g == 0) thg = reg_angle;
                     const double n2 = fabs(d_sub(thg, ang));
-                    const bool re = n2 <= prec || n2 >= precWrap;
-                    const unsigned long long mis = wave_vote(re != was && !(dupStep < g)) & cm;
+                    const unsigned long long reM = wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+                    const unsigned long long mis = (reM ^ wasM) & ~wave_vote(dupStep < g) & cm;
                     const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
                     const unsigned long long okAcc = spec & bm;
                     const int t = __popcll(okAcc);
@@ -607,11 +611,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
-                    const bool mine = (acc >> lane) & 1ull;
+                    const bool mine = wave_bit(acc);
                     const int slot = a & (PEND - 1);
-                    if (wave_vote(mine && pendv != -1)) PEND_FLUSH();      // (nothing has written the table since the gather read the lane's slot)
+                    if (wave_vote(pendv != -1) & acc) PEND_FLUSH();        // (nothing has written the table since the gather read the lane's slot)
                     if (mine) {
-                        const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
+                        const int idx = n0 + wave_rank_below(acc);
                         grad[a] = pw | kUsed;
                         s_ring[idx & (RING - 1)] = (uint32_t)xy;
                         reg[rbase + idx] = make_uint2((uint32_t)xy, pw);
@@ -861,7 +865,7 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
         const unsigned long long km = wave_vote(c.keep != 0);
         if (lane == 0) s_wave[wave] = __popcll(km);
         __syncthreads();
-        int pos = s_base + __popcll(km & ((1ull << lane) - 1ull));
+        int pos = s_base + wave_rank_below(km);
         for (int w = 0; w < wave; ++w) pos += s_wave[w];
         if (c.keep) {
             if (pos < g.maxDetect) {

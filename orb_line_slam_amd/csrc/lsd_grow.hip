@@ -487,9 +487,9 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
                     if (new2 >= 0 && curOrd + 2 < MW_DIR) dir[curOrd + 2] = new2;
                 }
             }
-            const bool mine = (acc >> lane) & 1ull;
+            const bool mine = wave_bit(acc);
             if (mine) {
-                const int idx = n0 + __popcll(acc & ((1ull << lane) - 1ull));
+                const int idx = n0 + wave_rank_below(acc);
                 pOld = __hip_atomic_fetch_min(c.owner + a, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 pMine = true;
                 ring[idx & (MW_RING - 1)] = (uint32_t)xy;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
             const bool valid = i0 + u * 256 < n;
             const uint32_t d = (k[u] >> SHIFT) & (RB - 1);
             const unsigned long long m = match_digit(d, valid);
-            if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[d], (uint32_t)__popcll(m));      // one atomic per digit value and wave step (plain per-key LDS atomics: 0.95 vs 0.88 ms)
+            if (valid && wave_rank_below(m) == 0) atomicAdd(&h[d], (uint32_t)__popcll(m));      // one atomic per digit value and wave step (plain per-key LDS atomics: 0.95 vs 0.88 ms)
         }
     }
     __syncthreads();
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_radix_scatter(const uint32_
             const bool valid = i0 + u * 64 < hiw;
             const uint32_t d = (k[u] >> SHIFT) & (RB - 1);
             const unsigned long long m = match_digit(d, valid);
-            if (valid && (m & ((1ull << lane) - 1ull)) == 0) pos[wv][d] += (uint32_t)__popcll(m);      // this wave owns pos[wv] (per-key LDS atomics: 3.5 vs 2.9 ms)
+            if (valid && wave_rank_below(m) == 0) pos[wv][d] += (uint32_t)__popcll(m);      // this wave owns pos[wv] (per-key LDS atomics: 3.5 vs 2.9 ms)
         }
     }
     __syncthreads();
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(SCATTER_THREADS) void k_radix_scatter(const uint32_
         const uint32_t d = (key >> SHIFT) & (RB - 1);
         const unsigned long long m = match_digit(d, valid);      // equal digits of this step, in lane order = input order: stable
         if (valid) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull)), cnt = __popcll(m);
+            const int rank = wave_rank_below(m), cnt = __popcll(m);
             const uint32_t p = pos[wv][d] + (uint32_t)rank;
             stage[p] = key;
             if (rank == cnt - 1) pos[wv][d] = p + 1;

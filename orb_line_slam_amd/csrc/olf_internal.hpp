@@ -36,6 +36,10 @@ void set_error(const std::string& s);
 // Wave-wide vote.  hip's __ballot() converts the predicate to an int first and compares that with 0 (a v_cndmask + v_cmp_ne pair per vote);
 // the wave64 builtin takes the compare's lane mask as it is.
 __device__ __forceinline__ unsigned long long wave_vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// set bits of a lane mask below this lane (v_mbcnt pair; "__popcll(m & ((1ull << lane) - 1))" compiles to a 64-bit shift, two bit-field inserts and two counts)
+__device__ __forceinline__ int wave_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+// this lane's bit of a (wave-uniform) lane mask as a predicate: the mask becomes the EXEC / select operand as it is, no per-lane shift and compare
+__device__ __forceinline__ bool wave_bit(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 #endif
 
 constexpr int kEdge = 19;          // EDGE_THRESHOLD   src/ORBextractor.cc:76

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_nc, __popcll(pm));
                 base = __shfl(base, 0);
-                if (pass) s_cand[base + __popcll(pm & ((1ull << lane) - 1ull))] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
+                if (pass) s_cand[base + wave_rank_below(pm)] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
             }
         }
     }
