@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
             const uintptr_t addr = reinterpret_cast<uintptr_t>(row + xw);
             const int sh = (int)(addr & 3) * 8;
             if (xw >= 0 && (sh ? xw + 7 < W : xw + 3 < W)) {          // the second aligned word must stay inside the row
-                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
+                const uint32_t* p4 = reinterpret_cast<const uint32_t*>(row + xw - (int)(addr & 3));      // (pointer arithmetic, not an integer cast: stays a global load)
                 v = sh ? __funnelshift_r(p4[0], p4[1], sh) : p4[0];
             } else {
                 v = 0;

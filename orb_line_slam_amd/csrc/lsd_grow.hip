@@ -48,8 +48,11 @@ typedef int mw_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ MwCtl mw_ctl(int* ctl)
 {
     // (the four words change independently; every use tolerates a stale or torn snapshot -- see the callers)
-    const mw_v4i v = *reinterpret_cast<volatile mw_v4i*>(ctl);
-    MwCtl r; r.head = uni(v.x); r.tail = uni(v.y); r.dispNext = uni(v.z); r.wm = (uint32_t)uni(v.w);
+    // (two 8-byte relaxed atomic loads: a volatile vector read through the generic pointer became a flat load with system-scope cache bits and a
+    // vmcnt(0) either side of it -- several hundred cycles for 16 bytes of LDS, at every pick and dispatch)
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<unsigned long long*>(ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<unsigned long long*>(ctl) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    MwCtl r; r.head = uni((int)(unsigned)lo); r.tail = uni((int)(unsigned)(lo >> 32)); r.dispNext = uni((int)(unsigned)hi); r.wm = (uint32_t)uni((int)(unsigned)(hi >> 32));
     return r;
 }
 

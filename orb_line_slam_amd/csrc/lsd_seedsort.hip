@@ -539,7 +539,9 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
             const int mid = first + m / 2;
             const int pidx = lane == 0 ? first : lane == 1 ? first + 1 : lane == 2 ? mid : last - 1;
             uint32_t pv = 0;
-            if (lane < 4) pv = inLDS ? s_buf[pidx - c.ldsFirst] : c.A[pidx];
+            // (two branches, not one conditional expression: that becomes a generic-pointer flat load, slower than ds_read for the many LDS-resident ranges)
+            if (inLDS) { if (lane < 4) pv = s_buf[pidx - c.ldsFirst]; asm volatile("" : "+v"(pv)); }
+            else if (lane < 4) pv = c.A[pidx];
             const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)pv, 0), ea = (uint32_t)__builtin_amdgcn_readlane((int)pv, 1);
             const uint32_t eb = (uint32_t)__builtin_amdgcn_readlane((int)pv, 2), ec = (uint32_t)__builtin_amdgcn_readlane((int)pv, 3);
             const uint32_t Ka = ssK(ea), Kb = ssK(eb), Kc = ssK(ec);
@@ -549,8 +551,8 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
             const uint32_t es = sel == 0 ? ea : sel == 1 ? eb : ec;
             const int sidx = sel == 0 ? first + 1 : sel == 1 ? mid : last - 1;
             if (lane == 0) {
-                if (inLDS) { s_buf[first - c.ldsFirst] = es; s_buf[sidx - c.ldsFirst] = e0; }
-                else { c.A[first] = es; c.A[sidx] = e0; }
+                if (inLDS) { s_buf[first - c.ldsFirst] = es; s_buf[sidx - c.ldsFirst] = e0; asm volatile("" ::: "memory"); }      // (no tail merging into a flat store)
+                else { c.A[first] = es; c.A[sidx] = e0; asm volatile("" ::: "memory"); }
             }
             __builtin_amdgcn_wave_barrier();
             const uint32_t Kp = ssK(es);
