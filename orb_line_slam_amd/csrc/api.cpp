@@ -49,7 +49,7 @@ struct olf_ctx {
     hipStream_t stream2 = nullptr;
     bool has_tables = false;       // holds a reference on the device's shared LSD angle tables
     bool mark_front = false;
-    bool wait_front_after_pyramid = false;      // fused entry: the ORB stream waits for the LSD front after its own pyramid (below)
+    int orb_wait_after = 0;        // fused entry: the ORB stream waits for the LSD front behind this many of its own dense stages (pyramid, blur, FAST)
     hipEvent_t ev_front = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
@@ -389,11 +389,16 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const OrbGeom& g = c->orb.geom;
     c->last_n_images = n_images;
+    // (the blur only needs the pyramid: with orb_wait_after >= 2 it runs ahead of FAST, beside the dense half of the LSD front)
+    const int wa = c->orb_wait_after;
     { StageScope t(c, s, ST_ORB_PYRAMID); OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s)); }
-    if (c->wait_front_after_pyramid) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    if (wa == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    if (wa >= 2) { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
+    if (wa == 2) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_FAST); OLF_TRY(launch_orb_fast(g, c->ob, n_images, s)); }
+    if (wa == 3) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_OCTREE); OLF_TRY(launch_orb_octree(g, c->ob, n_images, s)); }
-    { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
+    if (wa < 2) { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
     { StageScope t(c, s, ST_ORB_DESCRIBE); OLF_TRY(launch_orb_describe(g, c->ob, n_images, d_kps, d_desc, d_counts, g.outCap, s)); }
     return OLF_OK;
 }
@@ -855,10 +860,10 @@ int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_
     if (n_images < 0 || n_images > c->max_images) return OLF_ERR_CAPACITY;
     if (n_images == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    // mark_front: the ORB stream waits for ev_front, recorded behind the whole front including the seed ordering.  OLF_SCHED bit 2 (4) records it in
+    // mark_front: the ORB stream waits for ev_front, recorded behind the whole front including the seed ordering.  OLF_SCHED + 16 records it in
     // front of the std::sort replay instead -- measured worse (297.7 against 282.7 ms per 3072-pair step: the ORB kernels then slow the sort down and
     // still meet the growth agents afterwards), kept as a switch for experiments.
-    static const bool front_before_sort = getenv("OLF_SCHED") && (atoi(getenv("OLF_SCHED")) & 4);
+    static const bool front_before_sort = getenv("OLF_SCHED") && (atoi(getenv("OLF_SCHED")) & 16);
     const bool early = c->mark_front && c->line.geom.seedOrder == 1 && front_before_sort;
     c->lb.sortEvent = early ? c->ev_front : nullptr;
     { StageScope t(c, s, ST_LSD_FRONT); const int rc = launch_lsd_front(c->line.geom, c->lb, d_images, c->W, n_images, s); c->lb.sortEvent = nullptr; OLF_TRY(rc); }
@@ -969,9 +974,10 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
     // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  The ORB
-    // path starts when the dense front half of LSD is through: two dense pipelines at once only slow each other down, whereas the ORB
-    // kernels running beside the latency-bound growth agents leave those at their stand-alone speed (measured: 265 against 278 ms per
-    // 3072-pair step; OLF_SCHED=0 starts both paths together).  OLF_ONE_STREAM serialises the two paths (clean per-stage timings).
+    // stream builds its pyramid beside the dense half of the LSD front and then waits for the front's end: two dense pipelines at once only
+    // slow each other down (OLF_SCHED=0: 290 ms per 3072-pair step), whereas FAST beside the latency-bound growth agents is hidden almost
+    // completely (105 ms beside them, 24 alone, and the agents keep their stand-alone speed).  Round 3, ms per step: wait before the pyramid
+    // 266.3, behind it 260.3 (default), behind pyramid + blur 262.5, behind FAST 279.  OLF_ONE_STREAM serialises the two paths.
     static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
     if (one_stream) {
         OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
@@ -980,19 +986,21 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
         OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
         return OLF_OK;
     }
-    static const int sched = getenv("OLF_SCHED") ? atoi(getenv("OLF_SCHED")) : 1;
+    // OLF_SCHED: 0 both paths at once; 1 .. 4: the ORB stream waits for the LSD front before its pyramid / behind the pyramid / behind pyramid + blur /
+    // behind pyramid + blur + FAST (+ 16: the front ends before the seed sort)
+    static const int sched = (getenv("OLF_SCHED") ? atoi(getenv("OLF_SCHED")) : 2) & 15;
     OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    c->mark_front = (sched & 1) != 0;
+    c->mark_front = sched != 0;
     const int rcl = olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2);
     c->mark_front = false;
     OLF_TRY(rcl);
     OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
     OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
-    if ((sched & 3) == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
-    c->wait_front_after_pyramid = sched == 3;
+    if (sched == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    c->orb_wait_after = sched >= 2 ? sched - 1 : 0;
     const int rco = olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s);
-    c->wait_front_after_pyramid = false;
+    c->orb_wait_after = 0;
     OLF_TRY(rco);
     OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
