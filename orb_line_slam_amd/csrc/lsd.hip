@@ -363,9 +363,6 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
 }
 
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 24 agents share a CU with other kernels)
-// lanes 9 e + k of the agent's 7 x 9 gather grid that look at a neighbour (k != 4: not the FIFO entry's own pixel; lane 63 is unused)
-constexpr unsigned long long neighbour_lanes() { unsigned long long m = 0; for (int l = 0; l < 63; ++l) if (l % 9 != 4) m |= 1ull << l; return m; }
-constexpr unsigned long long kNeighbourLanes = neighbour_lanes();
 constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be visible to a load yet (512 entries: 122.1 ms per 6144 images, 1024: 121.4 --
                              // fewer collisions, fewer flushes, fewer seed windows gathered twice; 5 KB of LDS per agent)
 
@@ -494,8 +491,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_TIMING
                 ++iters;
 #endif
-                const int nb = min(7, n - i);
-                const int e = lane / 9, k = lane - 9 * e;
+                const int nb = min(8, n - i);
+                const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);      // 8 FIFO entries x 8 neighbours (k = 4 is the entry's own pixel)
 #ifdef OLF_STATS
                 ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2; if (n - i > RING) ++st_mem;
 #endif
@@ -504,8 +501,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_TIMING2
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
 #endif
-                // candidates as lane masks (scalar registers) from here on: the 7 x 9 grid minus the centres, the first nb FIFO entries
-                const unsigned long long geo = kNeighbourLanes & ((1ull << (9 * nb)) - 1ull);
+                // candidates as lane masks (scalar registers) from here on: lane 8 e + j looks at neighbour j of FIFO entry e, the first nb entries count
+                const unsigned long long geo = nb == 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
                 // (the ring read is unconditional and the memory read a rare wave-uniform branch: as one conditional expression the two became a
                 // generic-pointer flat load, in front of which the compiler waits for the previous iteration's stores to be acknowledged)
                 uint32_t rp = s_ring[(i + e) & (RING - 1)];
