@@ -8,7 +8,7 @@
 // Pseudo-ordering: every defined pixel becomes a key ((n_bins-1-bin) << 22 | address), emitted in raster order; a stable segmented
 // radix sort (rocPRIM) over the 10 bin bits yields "bins high to low, raster order inside a bin".
 // Region growing is order-dependent by construction (seed order, running region angle, shared `used` map), so one wave per image
-// (k_lsd_grow, "the agent") replays it sequentially: the 3x3 neighbourhoods of up to 7 FIFO entries are examined in parallel lanes and
+// (k_lsd_grow, "the agent") replays it sequentially: the 3x3 neighbourhoods of up to 8 FIFO entries are examined in parallel lanes and
 // only the accept chain is serial -- run as speculative rounds that need one fastAtan2 per round instead of one per accepted pixel.
 // Regions that are large enough are logged and fitted afterwards, in parallel, by k_lsd_rect / k_lsd_emit (region2rect + KeyLine).
 // Parallelism comes from the batch: thousands of images in flight, up to 8 agents per SIMD.

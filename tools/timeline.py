@@ -15,5 +15,5 @@ sel = rows[first:]
 qs = sorted({r[3] for r in sel})
 print("queues:", qs, "kernels:", len(sel), "span ms: %.2f" % ((max(r[1] for r in sel) - t0) / 1e6))
 for s, e, k, q in sel:
-    if (e - s) > 300_000:
+    if (e - s) > int(__import__("os").environ.get("TL_MIN_NS", "300000")):
         print("%8.2f %8.2f %8.2f  q%s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, qs.index(q), k))
