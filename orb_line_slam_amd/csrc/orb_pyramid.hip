@@ -109,11 +109,15 @@ constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
 // interior (the sub-image minus its 3-pixel frame; everything outside counts as 0).  Tiles overlap by the 1-pixel NMS halo, so a tile
 // scores its corners into an LDS score tile, suppresses non-maxima there (neighbours in another cell do not count) and appends the
 // survivors to their cell's list.  No dense score map exists in memory; k_cells_sort orders each list and applies the dual threshold.
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, int minTh,
-                                                    uint32_t* __restrict__ cells, int* __restrict__ cellCount, int totalCells, int cellCap)
+// Footprint: 17.4 KB of LDS and <= 64 VGPRs, so that TWO blocks per CU fit beside the 24 resident growth agents (they leave 37 KB of LDS, two wave
+// slots and 128 VGPRs per SIMD): in the fused entry this kernel runs in the agents' shadow (api.cpp, OLF_SCHED).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, int minTh,
+                  uint32_t* __restrict__ cells, int* __restrict__ cellCount, int totalCells, int cellCap)
 {
     __shared__ uint32_t tile[FT_INH * FT_INW];
-    __shared__ unsigned short s_cand[FT_W * FT_H], s_list[FT_W * FT_H];
+    __shared__ unsigned short s_cand[FT_W * FT_H];      // A1's survivors, compacted in place to the corners by A2 (s_list)
+    unsigned short* const s_list = s_cand;
     __shared__ uint8_t s_score[FT_H * FT_W];
     __shared__ int s_nc, s_n;
     const int img = blockIdx.z;
@@ -168,23 +172,32 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t* __restrict__ 
     constexpr int P = FT_INW * 4;
     // ---- phase A2: the full segment test of the survivors, one per lane (dense): 16 ring bytes from the LDS tile, brighter / darker
     // masks, >= 9 contiguous.  Corners are queued for scoring.
+    // (in place: a round's 256 entries are all read before any corner is appended, and the append position never passes the round's end)
     const int nCand = s_nc;
-    for (int i = threadIdx.x; i < nCand; i += 256) {
-        const int id = s_cand[i], ty = id / FT_W, tx = id - ty * FT_W;
-        const uint8_t* c = tb + (ty + 3) * P + tx + 4;
-        const int v = c[0], hiT = v + minTh, loT = v - minTh;
-        int ring[16];
-        ring[0] = c[3 * P];   ring[1] = c[3 * P + 1];   ring[2] = c[2 * P + 2];   ring[3] = c[P + 3];
-        ring[4] = c[3];       ring[5] = c[-P + 3];      ring[6] = c[-2 * P + 2];  ring[7] = c[-3 * P + 1];
-        ring[8] = c[-3 * P];  ring[9] = c[-3 * P - 1];  ring[10] = c[-2 * P - 2]; ring[11] = c[-P - 3];
-        ring[12] = c[-3];     ring[13] = c[P - 3];      ring[14] = c[2 * P - 2];  ring[15] = c[3 * P - 1];
-        uint32_t dark = 0, bright = 0;
+    for (int i0 = 0; i0 < nCand; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool corner = false;
+        int id = 0;
+        if (i < nCand) {
+            id = s_cand[i];
+            const int ty = id / FT_W, tx = id - ty * FT_W;
+            const uint8_t* c = tb + (ty + 3) * P + tx + 4;
+            const int v = c[0], hiT = v + minTh, loT = v - minTh;
+            int ring[16];
+            ring[0] = c[3 * P];   ring[1] = c[3 * P + 1];   ring[2] = c[2 * P + 2];   ring[3] = c[P + 3];
+            ring[4] = c[3];       ring[5] = c[-P + 3];      ring[6] = c[-2 * P + 2];  ring[7] = c[-3 * P + 1];
+            ring[8] = c[-3 * P];  ring[9] = c[-3 * P - 1];  ring[10] = c[-2 * P - 2]; ring[11] = c[-P - 3];
+            ring[12] = c[-3];     ring[13] = c[P - 3];      ring[14] = c[2 * P - 2];  ring[15] = c[3 * P - 1];
+            uint32_t dark = 0, bright = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            dark |= (uint32_t)(ring[k] < loT) << k;
-            bright |= (uint32_t)(ring[k] > hiT) << k;
+            for (int k = 0; k < 16; ++k) {
+                dark |= (uint32_t)(ring[k] < loT) << k;
+                bright |= (uint32_t)(ring[k] > hiT) << k;
+            }
+            corner = run9(dark) || run9(bright);
         }
-        if (run9(dark) || run9(bright)) s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
+        __syncthreads();
+        if (corner) s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
     }
     __syncthreads();
     // ---- phase B: scores of the queued corners into the LDS score tile, one corner per thread (dense lanes)
