@@ -55,7 +55,308 @@ static inline double angle_diff(double a, double b)
     return std::fabs(diff);
 }
 
-// cv::LineSegmentDetector::detect with refine = LSD_REFINE_NONE.  scaled_out (optional) receives the
+static inline double angle_diff_signed(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -kPI) diff += M_2__PI;
+    while (diff > kPI) diff -= M_2__PI;
+    return diff;
+}
+static inline double distSq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+static inline double dist(double x1, double y1, double x2, double y2) { return std::sqrt(distSq(x1, y1, x2, y2)); }
+
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+// cv LineSegmentDetectorImpl::region_grow (lsd.cpp): 8-neighbourhood growth from `addr0`, running region angle from float sums
+static void region_grow(LsdState& S, int addr0, std::vector<RegionPoint>& reg, double& reg_angle, double prec)
+{
+    const int W = S.w, H = S.h;
+    reg.clear();
+    reg_angle = S.angles[addr0];
+    reg.push_back({addr0 % W, addr0 / W, reg_angle, S.modgrad[addr0]});
+    float sumdx = float(std::cos(reg_angle));
+    float sumdy = float(std::sin(reg_angle));
+    S.used[addr0] = 1;
+    for (size_t i = 0; i < reg.size(); ++i) {
+        const int rx = reg[i].x, ry = reg[i].y;
+        const int xx_min = std::max(rx - 1, 0), xx_max = std::min(rx + 1, W - 1);
+        const int yy_min = std::max(ry - 1, 0), yy_max = std::min(ry + 1, H - 1);
+        for (int yy = yy_min; yy <= yy_max; ++yy) {
+            int c_addr = xx_min + yy * W;
+            for (int xx = xx_min; xx <= xx_max; ++xx, ++c_addr) {
+                if (!S.used[c_addr] && is_aligned(S, c_addr, reg_angle, prec)) {
+                    S.used[c_addr] = 1;
+                    const double angle = S.angles[c_addr];
+                    reg.push_back({xx, yy, angle, S.modgrad[c_addr]});
+                    sumdx += std::cos((double)float(angle));   // convention C.6: double libm, rounded by the float +=
+                    sumdy += std::sin((double)float(angle));
+                    reg_angle = fastAtan2(sumdy, sumdx) * DEG_TO_RADS;
+                }
+            }
+        }
+    }
+}
+
+// cv LineSegmentDetectorImpl::region2rect + get_theta
+static void region2rect(const std::vector<RegionPoint>& reg, double reg_angle, double prec, double p, Rect& rec)
+{
+    double x = 0, y = 0, sum = 0;
+    for (const RegionPoint& q : reg) {
+        const double weight = q.modgrad;
+        x += double(q.x) * weight;
+        y += double(q.y) * weight;
+        sum += weight;
+    }
+    x /= sum; y /= sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (const RegionPoint& q : reg) {
+        const double dx = double(q.x) - x, dy = double(q.y) - y, weight = q.modgrad;
+        Ixx += dy * dy * weight;
+        Iyy += dx * dx * weight;
+        Ixy -= dx * dy * weight;
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fastAtan2(float(lambda - Ixx), float(Ixy)))
+                                                     : double(fastAtan2(float(Ixy), float(lambda - Iyy)));
+    theta *= DEG_TO_RADS;
+    if (angle_diff(theta, reg_angle) > prec) theta += kPI;
+    const double dx = std::cos(theta), dy = std::sin(theta);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (const RegionPoint& q : reg) {
+        const double regdx = double(q.x) - x, regdy = double(q.y) - y;
+        const double l = regdx * dx + regdy * dy;
+        const double w = -regdx * dy + regdy * dx;
+        if (l > l_max) l_max = l;
+        else if (l < l_min) l_min = l;
+        if (w > w_max) w_max = w;
+        else if (w < w_min) w_min = w;
+    }
+    rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+// ---- LSD_REFINE_STD / LSD_REFINE_ADV (convention C.14: restated from OpenCV 3.4's modules/imgproc/src/lsd.cpp as recalled -- the file is not in
+// /root/reference, like the rest of OpenCV; unpinned).  reduce_region_radius, refine, rect_nfa (with its integer edge steps and the
+// tailp->p.x comparisons the original has), nfa, log_gamma, rect_improve.
+static bool reduce_region_radius(LsdState& S, std::vector<RegionPoint>& reg, double reg_angle, double prec, double p, Rect& rec, double density, double density_th)
+{
+    const double xc = double(reg[0].x), yc = double(reg[0].y);
+    const double radSq1 = distSq(xc, yc, rec.x1, rec.y1), radSq2 = distSq(xc, yc, rec.x2, rec.y2);
+    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        for (size_t i = 0; i < reg.size(); ++i) {
+            if (distSq(xc, yc, double(reg[i].x), double(reg[i].y)) > radSq) {
+                S.used[(size_t)reg[i].y * S.w + reg[i].x] = 0;
+                std::swap(reg[i], reg[reg.size() - 1]);
+                reg.pop_back();
+                --i;
+            }
+        }
+        if (reg.size() < 2) return false;
+        region2rect(reg, reg_angle, prec, p, rec);
+        density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    }
+    return true;
+}
+
+static bool refine(LsdState& S, std::vector<RegionPoint>& reg, double& reg_angle, double prec, double p, Rect& rec, double density_th)
+{
+    double density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density >= density_th) return true;
+    const double xc = double(reg[0].x), yc = double(reg[0].y);
+    const double ang_c = reg[0].angle;
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (size_t i = 0; i < reg.size(); ++i) {
+        S.used[(size_t)reg[i].y * S.w + reg[i].x] = 0;
+        if (dist(xc, yc, reg[i].x, reg[i].y) < rec.width) {
+            const double ang_d = angle_diff_signed(reg[i].angle, ang_c);
+            sum += ang_d;
+            s_sum += ang_d * ang_d;
+            ++n;
+        }
+    }
+    const double mean_angle = sum / double(n);
+    const double tau = 2.0 * std::sqrt((s_sum - 2.0 * mean_angle * sum) / double(n) + mean_angle * mean_angle);
+    region_grow(S, reg[0].y * S.w + reg[0].x, reg, reg_angle, tau);
+    if (reg.size() < 2) return false;
+    region2rect(reg, reg_angle, prec, p, rec);
+    density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density < density_th) return reduce_region_radius(S, reg, reg_angle, prec, p, rec, density, density_th);
+    return true;
+}
+
+static inline bool double_equal(double a, double b)
+{
+    if (a == b) return true;
+    const double abs_diff = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b);
+    double abs_max = (aa > bb) ? aa : bb;
+    if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+    return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);
+}
+static double log_gamma_lanczos(double x)
+{
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) {
+        a -= std::log(x + double(n));
+        b += q[n] * std::pow(x, double(n));
+    }
+    return a + std::log(b);
+}
+static double log_gamma_windschitl(double x)
+{
+    return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+}
+static inline double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+
+static double nfa(int n, int k, double p, double LOG_NT)
+{
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - double(n) * std::log10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = log_gamma(double(n) + 1) - log_gamma(double(k) + 1) - log_gamma(double(n - k) + 1) + double(k) * std::log(p) +
+                            double(n - k) * std::log(1.0 - p);
+    double term = std::exp(log1term);
+    if (double_equal(term, 0)) {
+        if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;      // M_LN10
+        return -LOG_NT;
+    }
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        const double bin_term = double(n - i + 1) / double(i);
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - std::pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * std::fabs(-std::log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -std::log10(bin_tail) - LOG_NT;
+}
+
+static bool is_aligned_xy(const LsdState& S, int x, int y, double theta, double prec) { return is_aligned(S, y * S.w + x, theta, prec); }
+
+static double rect_nfa(const LsdState& S, const Rect& rec, double LOG_NT)
+{
+    struct Edge { int x, y; bool taken; };
+    int total_pts = 0, alg_pts = 0;
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    Edge ordered_x[4];
+    Edge* min_y = &ordered_x[0];
+    Edge* max_y = &ordered_x[0];
+    ordered_x[0] = {int(rec.x1 - dyhw), int(rec.y1 + dxhw), false};
+    ordered_x[1] = {int(rec.x2 - dyhw), int(rec.y2 + dxhw), false};
+    ordered_x[2] = {int(rec.x2 + dyhw), int(rec.y2 - dxhw), false};
+    ordered_x[3] = {int(rec.x1 + dyhw), int(rec.y1 - dxhw), false};
+    std::sort(ordered_x, ordered_x + 4, [](const Edge& a, const Edge& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
+    for (unsigned i = 1; i < 4; ++i) {
+        if (min_y->y > ordered_x[i].y) min_y = &ordered_x[i];
+        if (max_y->y < ordered_x[i].y) max_y = &ordered_x[i];
+    }
+    min_y->taken = true;
+    Edge* leftmost = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+        if (!ordered_x[i].taken) {
+            if (!leftmost) leftmost = &ordered_x[i];
+            else if (leftmost->x > ordered_x[i].x) leftmost = &ordered_x[i];
+        }
+    leftmost->taken = true;
+    Edge* rightmost = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+        if (!ordered_x[i].taken) {
+            if (!rightmost) rightmost = &ordered_x[i];
+            else if (rightmost->x < ordered_x[i].x) rightmost = &ordered_x[i];
+        }
+    rightmost->taken = true;
+    Edge* tailp = nullptr;
+    for (unsigned i = 0; i < 4; ++i)
+        if (!ordered_x[i].taken) {
+            if (!tailp) tailp = &ordered_x[i];
+            else if (tailp->x > ordered_x[i].x) tailp = &ordered_x[i];
+        }
+    tailp->taken = true;
+    // (integer divisions and the tailp->x comparisons: as in the original)
+    const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
+    const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
+    const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
+    const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = min_y->x, right_x = min_y->x;
+    const int min_iter = min_y->y, max_iter = max_y->y;
+    for (int y = min_iter; y <= max_iter; ++y) {
+        if (y < 0 || y >= S.h) continue;
+        for (int x = int(left_x); x <= int(right_x); ++x) {
+            if (x < 0 || x >= S.w) continue;
+            ++total_pts;
+            if (is_aligned_xy(S, x, y, rec.theta, rec.prec)) ++alg_pts;
+        }
+        if (y >= leftmost->y) lstep = slstep;
+        if (y >= rightmost->y) rstep = srstep;
+        left_x += lstep;
+        right_x += rstep;
+    }
+    return nfa(total_pts, alg_pts, rec.p, LOG_NT);
+}
+
+static double rect_improve(const LsdState& S, Rect& rec, double LOG_NT, double LOG_EPS)
+{
+    const double delta = 0.5, delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(S, rec, LOG_NT);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    Rect r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * kPI;
+        const double log_nfa_new = rect_nfa(S, r, LOG_NT);
+        if (log_nfa_new > log_nfa) { log_nfa = log_nfa_new; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (unsigned n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            const double log_nfa_new = rect_nfa(S, r, LOG_NT);
+            if (log_nfa_new > log_nfa) { rec = r; log_nfa = log_nfa_new; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (unsigned n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            const double log_nfa_new = rect_nfa(S, r, LOG_NT);
+            if (log_nfa_new > log_nfa) { rec = r; log_nfa = log_nfa_new; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (unsigned n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            const double log_nfa_new = rect_nfa(S, r, LOG_NT);
+            if (log_nfa_new > log_nfa) { rec = r; log_nfa = log_nfa_new; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (unsigned n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * kPI;
+            const double log_nfa_new = rect_nfa(S, r, LOG_NT);
+            if (log_nfa_new > log_nfa) { rec = r; log_nfa = log_nfa_new; }
+        }
+    return log_nfa;
+}
+
+// cv::LineSegmentDetector::detect (refine = P.lsd_refine: 0 NONE, 1 STD, 2 ADV).  scaled_out (optional) receives the
 // blurred + upsampled image, for stage-wise comparison.
 void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>& lines, Image* scaled_out, std::vector<int>* region_sizes)
 {
@@ -138,63 +439,20 @@ void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>
     for (size_t oi = 0; oi < S.order.size(); ++oi) {
         const int addr0 = S.order[oi];
         if (S.used[addr0] || S.angles[addr0] == NOTDEF) continue;
-        // ---- region_grow
-        reg.clear();
-        double reg_angle = S.angles[addr0];
-        reg.push_back({addr0 % W, addr0 / W, reg_angle, S.modgrad[addr0]});
-        float sumdx = float(std::cos(reg_angle));
-        float sumdy = float(std::sin(reg_angle));
-        S.used[addr0] = 1;
-        for (size_t i = 0; i < reg.size(); ++i) {
-            const int rx = reg[i].x, ry = reg[i].y;
-            const int xx_min = std::max(rx - 1, 0), xx_max = std::min(rx + 1, W - 1);
-            const int yy_min = std::max(ry - 1, 0), yy_max = std::min(ry + 1, H - 1);
-            for (int yy = yy_min; yy <= yy_max; ++yy) {
-                int c_addr = xx_min + yy * W;
-                for (int xx = xx_min; xx <= xx_max; ++xx, ++c_addr) {
-                    if (!S.used[c_addr] && is_aligned(S, c_addr, reg_angle, prec)) {
-                        S.used[c_addr] = 1;
-                        const double angle = S.angles[c_addr];
-                        reg.push_back({xx, yy, angle, S.modgrad[c_addr]});
-                        sumdx += std::cos((double)float(angle));   // convention C.6: double libm, rounded by the float +=
-                        sumdy += std::sin((double)float(angle));
-                        reg_angle = fastAtan2(sumdy, sumdx) * DEG_TO_RADS;
-                    }
-                }
-            }
-        }
+        double reg_angle;
+        region_grow(S, addr0, reg, reg_angle, prec);
         if (region_sizes) region_sizes->push_back((int)reg.size());
         if ((int)reg.size() < min_reg_size) continue;
-        // ---- region2rect
-        double x = 0, y = 0, sum = 0;
-        for (const RegionPoint& q : reg) {
-            const double weight = q.modgrad;
-            x += double(q.x) * weight;
-            y += double(q.y) * weight;
-            sum += weight;
+        Rect rec;
+        region2rect(reg, reg_angle, prec, p, rec);
+        if (P.lsd_refine > 0) {
+            if (!refine(S, reg, reg_angle, prec, p, rec, P.lsd_density_th)) continue;
+            if (P.lsd_refine >= 2) {
+                const double log_nfa = rect_improve(S, rec, LOG_NT, P.lsd_log_eps);
+                if (log_nfa <= P.lsd_log_eps) continue;
+            }
         }
-        x /= sum; y /= sum;
-        double Ixx = 0, Iyy = 0, Ixy = 0;
-        for (const RegionPoint& q : reg) {
-            const double dx = double(q.x) - x, dy = double(q.y) - y, weight = q.modgrad;
-            Ixx += dy * dy * weight;
-            Iyy += dx * dx * weight;
-            Ixy -= dx * dy * weight;
-        }
-        const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fastAtan2(float(lambda - Ixx), float(Ixy)))
-                                                         : double(fastAtan2(float(Ixy), float(lambda - Iyy)));
-        theta *= DEG_TO_RADS;
-        if (angle_diff(theta, reg_angle) > prec) theta += kPI;
-        const double dx = std::cos(theta), dy = std::sin(theta);
-        double l_min = 0, l_max = 0;
-        for (const RegionPoint& q : reg) {
-            const double regdx = double(q.x) - x, regdy = double(q.y) - y;
-            const double l = regdx * dx + regdy * dy;
-            if (l > l_max) l_max = l;
-            else if (l < l_min) l_min = l;
-        }
-        double x1 = x + l_min * dx, y1 = y + l_min * dy, x2 = x + l_max * dx, y2 = y + l_max * dy;
+        double x1 = rec.x1, y1 = rec.y1, x2 = rec.x2, y2 = rec.y2;
         x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
         if (SCALE != 1) { x1 /= SCALE; y1 /= SCALE; x2 /= SCALE; y2 /= SCALE; }
         lines.push_back({{float(x1), float(y1), float(x2), float(y2)}});

@@ -203,7 +203,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
 {
     LineGeom& g = geom;
     g = LineGeom();
-    if (p.lsd_refine != 0) return OLF_ERR_INVALID;            // only LSD_REFINE_NONE is on the path
+    if (p.lsd_refine != 0 && p.lsd_refine != 1) return OLF_ERR_INVALID;      // LSD_REFINE_NONE and LSD_REFINE_STD are on the path; ADV (NFA) is not
     if (p.conv_seed_order != 0 && p.conv_seed_order != 1) return OLF_ERR_INVALID;
     if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
@@ -266,6 +266,8 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE, INTER_LINEAR): scale_x = 1/SCALE
     g.resizeExact = p.conv_resize_exact ? 1 : 0;
     g.seedOrder = p.conv_seed_order;
+    g.refine = p.lsd_refine;
+    g.densityTh = p.lsd_density_th;
     if (g.resizeExact) {
         resize_axis_coefs_exact(W, g.Ws, 1. / p.lsd_scale, rx.data());
         resize_axis_coefs_exact(H, g.Hs, 1. / p.lsd_scale, ry.data());

@@ -362,6 +362,93 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
     return OLF_OK;
 }
 
+struct SegCand { float e0, e1, e2, e3, length; int keep; };
+
+// LSDDetectorC::detectImpl's clamping of the Vec4f end points and the length filter (LSDDetector_custom.cpp:270-289), from the rectangle's end points
+__device__ __forceinline__ SegCand rect_to_cand(const LineGeom& g, double x1, double y1, double x2, double y2)
+{
+    x1 = d_add(x1, 0.5); y1 = d_add(y1, 0.5); x2 = d_add(x2, 0.5); y2 = d_add(y2, 0.5);
+    if (g.scale != 1) { x1 = x1 / g.scale; y1 = y1 / g.scale; x2 = x2 / g.scale; y2 = y2 / g.scale; }
+    float e0 = (float)x1, e1 = (float)y1, e2 = (float)x2, e3 = (float)y2;
+    const int cols = g.W, rows = g.H;
+    if (e0 < 0) e0 = 0;
+    if (e0 >= cols) e0 = (float)cols - 1.0f;
+    if (e2 < 0) e2 = 0;
+    if (e2 >= cols) e2 = (float)cols - 1.0f;
+    if (e1 < 0) e1 = 0;
+    if (e1 >= rows) e1 = (float)rows - 1.0f;
+    if (e3 < 0) e3 = 0;
+    if (e3 >= rows) e3 = (float)rows - 1.0f;
+    const double dxe = (double)f_sub(e0, e2), dye = (double)f_sub(e1, e3);
+    const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
+    SegCand c; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.length = (float)length; c.keep = length > g.minLength;
+    return c;
+}
+
+// ---- LSD_REFINE_STD inside the agent (cv LineSegmentDetectorImpl::refine / reduce_region_radius, convention C.14; oracle/line_oracle.cpp).
+// The region's pixel log is (x | y << 16, gradient word) pairs in growth order; every lane runs the same scalar loops over it (uniform addresses:
+// one request per load), so the sums are formed in exactly the reference's order.
+struct AgentRect { double x1, y1, x2, y2, width; };
+
+__device__ __forceinline__ double log_modgrad(uint32_t w) { const int gx = unpack_gx(w), gy = unpack_gy(w); return sqrt((double)(gx * gx + gy * gy) / 4.0); }
+
+__device__ __forceinline__ AgentRect agent_region2rect(const uint2* lg, int n, double reg_angle, double prec)
+{
+    AgentRect rec;
+    double x = 0, y = 0, sum = 0;
+    for (int q = 0; q < n; ++q) {
+        const uint2 e = lg[q];
+        const double wt = log_modgrad(e.y);
+        x = d_add(x, d_mul((double)(int)(e.x & 0xffffu), wt));
+        y = d_add(y, d_mul((double)(int)(e.x >> 16), wt));
+        sum = d_add(sum, wt);
+    }
+    x = x / sum; y = y / sum;
+    double Ixx = 0, Iyy = 0, Ixy = 0;
+    for (int q = 0; q < n; ++q) {
+        const uint2 e = lg[q];
+        const double wt = log_modgrad(e.y);
+        const double ex = d_sub((double)(int)(e.x & 0xffffu), x), ey = d_sub((double)(int)(e.x >> 16), y);
+        Ixx = d_add(Ixx, d_mul(d_mul(ey, ey), wt));
+        Iyy = d_add(Iyy, d_mul(d_mul(ex, ex), wt));
+        Ixy = d_sub(Ixy, d_mul(d_mul(ex, ey), wt));
+    }
+    const double dI = d_sub(Ixx, Iyy);
+    const double lambda = d_mul(0.5, d_sub(d_add(Ixx, Iyy), sqrt(d_add(d_mul(dI, dI), d_mul(d_mul(4.0, Ixy), Ixy)))));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)dev_fastAtan2((float)d_sub(lambda, Ixx), (float)Ixy)
+                                           : (double)dev_fastAtan2((float)Ixy, (float)d_sub(lambda, Iyy));
+    theta = d_mul(theta, kDegToRads);
+    {
+        double diff = d_sub(theta, reg_angle);
+        while (diff <= -kPI) diff = d_add(diff, kM2PI);
+        while (diff > kPI) diff = d_sub(diff, kM2PI);
+        if (fabs(diff) > prec) theta = d_add(theta, kPI);
+    }
+    double ddx, ddy;
+    sincos(theta, &ddy, &ddx);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int q = 0; q < n; ++q) {
+        const uint32_t pk = lg[q].x;
+        const double rdx = d_sub((double)(int)(pk & 0xffffu), x), rdy = d_sub((double)(int)(pk >> 16), y);
+        const double lq = d_add(d_mul(rdx, ddx), d_mul(rdy, ddy));
+        const double wq = d_add(d_mul(-rdx, ddy), d_mul(rdy, ddx));
+        l_max = fmax(l_max, lq); l_min = fmin(l_min, lq);      // ("if (l > l_max) .. else if (l < l_min) .." from (0, 0))
+        w_max = fmax(w_max, wq); w_min = fmin(w_min, wq);
+    }
+    rec.x1 = d_add(x, d_mul(l_min, ddx)); rec.y1 = d_add(y, d_mul(l_min, ddy));
+    rec.x2 = d_add(x, d_mul(l_max, ddx)); rec.y2 = d_add(y, d_mul(l_max, ddy));
+    rec.width = d_sub(w_max, w_min);
+    if (rec.width < 1.0) rec.width = 1.0;
+    return rec;
+}
+
+__device__ __forceinline__ double agent_dist(double x1, double y1, double x2, double y2)
+{
+    const double ax = d_sub(x2, x1), ay = d_sub(y2, y1);
+    return sqrt(d_add(d_mul(ax, ax), d_mul(ay, ay)));
+}
+__device__ __forceinline__ double agent_density(int n, const AgentRect& r) { return (double)n / d_mul(agent_dist(r.x1, r.y1, r.x2, r.y2), r.width); }
+
 constexpr int RING = 256;    // FIFO window of the growing region kept in LDS (LDS is kept small: 24 agents share a CU with other kernels)
 constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be visible to a load yet (512 entries: 122.1 ms per 6144 images, 1024: 121.4 --
                              // fewer collisions, fewer flushes, fewer seed windows gathered twice; 5 KB of LDS per agent)
@@ -376,10 +463,15 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // The agent is a long dependent chain (LDS ring -> gradient word -> angle table -> accept chain): a single wave spends ~3/4 of its time
 // waiting, so throughput comes from interleaving waves.  With region2rect moved to k_lsd_rect the agent needs 64 VGPRs, i.e. up to
 // 8 agents per SIMD (8192 per GPU) and room for other kernels beside them.
+// REFINE (lsd_refine = LSD_REFINE_STD): every region of minRegSize pixels is fitted and, if its density is below the threshold, un-used, grown again
+// under the tolerance tau derived from its angles, and shrunk (reduce_region_radius) -- all inside the seed loop, because the pixels it gives back are
+// seeds and neighbours of later regions.  The agent then writes the segment candidates itself (candAll) and k_lsd_rect is not launched.
+template <bool REFINE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
-                                                 int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt)
+                                                 int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt,
+                                                 SegCand* __restrict__ candAll)
 {
     __shared__ uint32_t s_ring[RING];
     __shared__ int s_pend[PEND];
@@ -433,7 +525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         const bool valid = base + lane < nkeys;
         const int addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
         keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
-        const uint32_t wseed = valid ? grad[addr] : kUsed;
+        uint32_t wseed = valid ? grad[addr] : kUsed;
         int maskEpoch = flushEpoch;      // the window's USED bits as loaded here are complete up to this flush count
         const bool isoSeed = (wseed & kIso) != 0;
 #ifdef OLF_STATS
@@ -446,6 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         double seedAng = 0;
         float2 seedSum = make_float2(0.f, 0.f);
         if (wave_bit(mask) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
+        unsigned long long tabM = mask;      // lanes whose table entries are loaded (REFINE: the mask can gain lanes)
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
             {
@@ -469,17 +562,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
             ++st_regions;
 #endif
-            int n = 1;
             // the seed's word as loaded with the window: only its USED bit can have changed since, and the mask says it has not
             const uint32_t pseed = (uint32_t)rlane((int)wseed, l);
-            double reg_angle = rlane_d(seedAng, l);
+            // REFINE: the growth below runs a second time from the same seed under the tolerance tau (cv refine())
+            double precC = prec;
+            bool regrown = false, accept = false;
+            AgentRect rec = {0, 0, 0, 0, 0};
+            int n;
+            double reg_angle;
+          for (;;) {
+            n = 1;
+            reg_angle = rlane_d(seedAng, l);
             float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
             MARK_USED(seed, pseed);
             if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = make_uint2(pk, pseed); }
             __builtin_amdgcn_wave_barrier();
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); t_seed += t1 - t0; t0 = t1; }
-            int iters = 0;
 #endif
             int i = 0;
             // the check that two pixels accepted in one iteration did not hash to one table slot is read back after the commit's writes but only
@@ -489,7 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #define PEND_VERIFY() do { if (chkOn) { if (wave_vote(chkV != chkA)) PEND_FLUSH(); chkOn = false; } } while (0)
             while (i < n) {
 #ifdef OLF_TIMING
-                ++iters;
+                if (n >= g.minRegSize) ++it_big; else ++it_small;
 #endif
                 const int nb = min(8, n - i);
                 const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);      // 8 FIFO entries x 8 neighbours (k = 4 is the entry's own pixel)
@@ -538,7 +637,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
                     // (votes per comparison, combined as lane masks: a vote on the combined predicate costs a v_cndmask + v_cmp pair on top)
                     const double nth = fabs(d_sub(reg_angle, ang));
-                    const unsigned long long wasM = wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+                    // (REFINE: the tolerance of a second growth is computed on the device, so the wrapped test keeps its original form)
+                    const unsigned long long wasM = REFINE ? wave_vote((nth > kM32PI ? fabs(d_sub(nth, kM2PI)) : nth) <= precC)
+                                                           : wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
                     const unsigned long long al = wasM & cm;      // cm only ever holds live candidates
                     if (!al) break;
                     if ((al & (al - 1ull)) == 0) {
@@ -585,7 +686,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     double thg = shfl_d(th, max(g - 1, 0));
                     if (g == 0) thg = reg_angle;
                     const double n2 = fabs(d_sub(thg, ang));
-                    const unsigned long long reM = wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+                    const unsigned long long reM = REFINE ? wave_vote((n2 > kM32PI ? fabs(d_sub(n2, kM2PI)) : n2) <= precC)
+                                                          : wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
                     const unsigned long long mis = (reM ^ wasM) & ~wave_vote(dupStep < g) & cm;
                     const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
                     const unsigned long long okAcc = spec & bm;
@@ -630,10 +732,88 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             }
             PEND_VERIFY();
 #undef PEND_VERIFY
+            if (!REFINE) break;
+            const uint2* lg = reg + rbase;
+            if (!regrown) {
+                if (n < g.minRegSize) break;
+                __threadfence_block();                       // the log of this region is read back from memory
+                rec = agent_region2rect(lg, n, reg_angle, prec);
+                if (agent_density(n, rec) >= g.densityTh) { accept = true; break; }
+                // refine(): statistics of the angles within rec.width of the seed; every pixel of the region becomes NOTUSED again
+                const uint2 e0 = lg[0];
+                const double xc = (double)(int)(e0.x & 0xffffu), yc = (double)(int)(e0.x >> 16);
+                const double ang_c = ent[e0.y & 0x3fffffu].ang;
+                double sum = 0, s_sum = 0;
+                int cnt = 0;
+                for (int q = 0; q < n; ++q) {
+                    const uint2 e = lg[q];
+                    if (agent_dist(xc, yc, (double)(int)(e.x & 0xffffu), (double)(int)(e.x >> 16)) < rec.width) {
+                        double ad = d_sub(ent[e.y & 0x3fffffu].ang, ang_c);
+                        while (ad <= -kPI) ad = d_add(ad, kM2PI);
+                        while (ad > kPI) ad = d_sub(ad, kM2PI);
+                        sum = d_add(sum, ad);
+                        s_sum = d_add(s_sum, d_mul(ad, ad));
+                        ++cnt;
+                    }
+                }
+                for (int q = lane; q < n; q += 64) { const uint2 e = lg[q]; grad[(int)(e.x >> 16) * Ws + (int)(e.x & 0xffffu)] = e.y; }      // (the logged word has no USED bit)
+                PEND_FLUSH();
+                const double mean = sum / (double)cnt;
+                precC = d_mul(2.0, sqrt(d_add(d_sub(s_sum, d_mul(d_mul(2.0, mean), sum)) / (double)cnt, d_mul(mean, mean))));
+                regrown = true;
+                continue;
+            }
+            // the second growth is through
+            if (n < 2) break;
+            __threadfence_block();
+            rec = agent_region2rect(lg, n, reg_angle, prec);
+            double density = agent_density(n, rec);
+            if (density >= g.densityTh) { accept = true; break; }
+            {   // reduce_region_radius(): shrink the radius by 25 % until the density is reached; a removed pixel is NOTUSED again and its place in the
+                // list is taken by the last pixel (std::swap + pop_back), which the next rectangle's sums then meet in that order
+                uint2* lw = reg + rbase;
+                const uint2 e0 = lw[0];
+                const double xc = (double)(int)(e0.x & 0xffffu), yc = (double)(int)(e0.x >> 16);
+                const double ra1 = d_sub(rec.x1, xc), rb1 = d_sub(rec.y1, yc), ra2 = d_sub(rec.x2, xc), rb2 = d_sub(rec.y2, yc);
+                const double radSq1 = d_add(d_mul(ra1, ra1), d_mul(rb1, rb1)), radSq2 = d_add(d_mul(ra2, ra2), d_mul(rb2, rb2));
+                double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+                bool ok = true;
+                while (density < g.densityTh) {
+                    radSq = d_mul(radSq, 0.5625);
+                    for (int q = 0; q < n; ++q) {
+                        const uint2 e = lw[q];
+                        const double ax = d_sub((double)(int)(e.x & 0xffffu), xc), ay = d_sub((double)(int)(e.x >> 16), yc);
+                        if (d_add(d_mul(ax, ax), d_mul(ay, ay)) > radSq) {
+                            const uint2 last = lw[n - 1];
+                            if (lane == 0) { grad[(int)(e.x >> 16) * Ws + (int)(e.x & 0xffffu)] = e.y; lw[q] = last; }
+                            __threadfence_block();
+                            --n; --q;
+                        }
+                    }
+                    if (n < 2) { ok = false; break; }
+                    rec = agent_region2rect(lw, n, reg_angle, prec);
+                    density = agent_density(n, rec);
+                }
+                PEND_FLUSH();
+                accept = ok;
+            }
+            break;
+          }
+            if (REFINE) {
+                if (accept) {
+                    if (nreg < g.maxRegions) {
+                        const SegCand cnd = rect_to_cand(g, rec.x1, rec.y1, rec.x2, rec.y2);
+                        if (lane == 0) {
+                            candAll[(size_t)img * g.maxRegions + nreg] = cnd;
+                        }
+                        ++nreg;
+                    } else if (lane == 0) atomicOr(status, 8);
+                }
+            }
 #ifdef OLF_TIMING
-            { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; it_big += iters; } else { t_small += t1 - t0; ++n_small; it_small += iters; } t0 = t1; }
+            { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; } else { t_small += t1 - t0; ++n_small; } t0 = t1; }
 #endif
-            if (n >= g.minRegSize) {
+            if (!REFINE && n >= g.minRegSize) {
                 // a region large enough to become a segment: keep its pixel list (the log only moves forward for these) and record
                 // (start, size, final region angle); k_lsd_rect fits all rectangles of the batch in parallel afterwards
                 if (nreg < g.maxRegions) {
@@ -652,7 +832,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
             st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(wave_vote(valid && lane > l));
 #endif
-            if (n == 1) mask &= mask - 1;
+            if (REFINE && maskEpoch != flushEpoch) {
+                // pixels may have been given back since the window was loaded (refine un-uses whole regions): seeds of this window that were USED
+                // then can be seeds now -- look at every later seed's word again, and fetch the table entries of the ones that are new
+                const uint32_t wnow = valid ? grad[addr] : kUsed;
+                mask = wave_vote(valid && lane > l && !(wnow & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
+                if (wave_bit(mask)) wseed = wnow;
+                if (wave_bit(mask & ~tabM) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
+                tabM |= mask;
+                maskEpoch = flushEpoch;
+            }
+            else if (n == 1) mask &= mask - 1;
             else if (maskEpoch == flushEpoch) {
                 // no flush since the window's words were loaded: whatever has been marked since is still in the pending table -- no need to
                 // gather the 64 (spatially random) seed words again
@@ -684,7 +874,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // LSDDetector_custom.cpp:270-289).  Regions are independent once grown: one thread per region, its sums run over the region's pixels in
 // growth order (exactly the reference's order).  The segment candidate (clamped end points, length, keep flag) goes to a 24-byte record;
 // k_lsd_emit then walks each image's candidates in detection order and writes the KeyLines that pass the length filter.
-struct SegCand { float e0, e1, e2, e3, length; int keep; };
 
 // CHAINED: the pixel lists are chains of 32-pixel chunks (lsd_grow.hip; rr.start = first chunk id) instead of one contiguous log per image.
 template <bool CHAINED>
@@ -798,21 +987,7 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
     }
     double x1 = d_add(x, d_mul(l_min, ddx)), y1 = d_add(y, d_mul(l_min, ddy));
     double x2 = d_add(x, d_mul(l_max, ddx)), y2 = d_add(y, d_mul(l_max, ddy));
-    x1 = d_add(x1, 0.5); y1 = d_add(y1, 0.5); x2 = d_add(x2, 0.5); y2 = d_add(y2, 0.5);
-    if (g.scale != 1) { x1 = x1 / g.scale; y1 = y1 / g.scale; x2 = x2 / g.scale; y2 = y2 / g.scale; }
-    float e0 = (float)x1, e1 = (float)y1, e2 = (float)x2, e3 = (float)y2;
-    const int cols = g.W, rows = g.H;
-    if (e0 < 0) e0 = 0;
-    if (e0 >= cols) e0 = (float)cols - 1.0f;
-    if (e2 < 0) e2 = 0;
-    if (e2 >= cols) e2 = (float)cols - 1.0f;
-    if (e1 < 0) e1 = 0;
-    if (e1 >= rows) e1 = (float)rows - 1.0f;
-    if (e3 < 0) e3 = 0;
-    if (e3 >= rows) e3 = (float)rows - 1.0f;
-    const double dxe = (double)f_sub(e0, e2), dye = (double)f_sub(e1, e3);
-    const double length = (double)(float)sqrt(d_add(d_mul(dxe, dxe), d_mul(dye, dye)));
-    SegCand c; c.e0 = e0; c.e1 = e1; c.e2 = e2; c.e3 = e3; c.length = (float)length; c.keep = length > g.minLength;
+    const SegCand c = rect_to_cand(g, x1, y1, x2, y2);
     candAll[(size_t)img * g.maxRegions + r] = c;
 #undef RECT_BLOCK
 #undef RECT_STEP
@@ -894,7 +1069,8 @@ int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipS
 
 int lsd_grow_waves(int n_images);
 // the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
-static int lsd_grow_path(const LineDeviceBufs& b, int n_images) { return b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
+// (lsd_refine = STD runs in the one-wave agent only)
+static int lsd_grow_path(const LineGeom& g, const LineDeviceBufs& b, int n_images) { return g.refine ? 0 : b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
@@ -915,7 +1091,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const int nChunks = (g.Ps + LG_CHUNK - 1) / LG_CHUNK, total = nChunks * n_images;
         const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
-        const bool ow = lsd_grow_path(b, n_images) != 0;
+        const bool ow = lsd_grow_path(g, b, n_images) != 0;
         if (g.seedOrder == 1) {
             if (ow) hipLaunchKernelGGL((k_lsd_keys<true, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
             else hipLaunchKernelGGL((k_lsd_keys<false, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
@@ -948,7 +1124,7 @@ int lsd_grow_waves(int n_images)
 
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
-    const int nw = lsd_grow_path(b, n_images);
+    const int nw = lsd_grow_path(g, b, n_images);
     b.chained = nw != 0;
     if (nw > 0) {
         // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
@@ -958,19 +1134,30 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
         // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once
-        hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt);
+        hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt, (SegCand*)nullptr);
         OLF_HIP_CHECK(hipGetLastError());
         return OLF_OK;
     }
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr);
+    if (g.refine)
+        // (the candidates go to keysA: keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
+        hipLaunchKernelGGL(k_lsd_grow<true>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
+    else
+        hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
 
 int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
+    if (g.refine) {      // the agent has fitted the rectangles itself (candidates in keysA)
+        hipLaunchKernelGGL(k_lsd_emit, dim3(n_images), dim3(256), 0, s, b.geom, reinterpret_cast<const SegCand*>(b.keysA), b.regCount, b.rawLines,
+                           b.rawCount, b.status);
+        OLF_HIP_CHECK(hipGetLastError());
+        return OLF_OK;
+    }
     // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
     if (b.chained)
         hipLaunchKernelGGL(k_lsd_rect_mixed, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,

@@ -55,13 +55,15 @@ for it in range(N):
     p.line.lsd_ang_th = float(rng.choice([15.0, 22.5, 30.0]))
     p.line.lsd_n_bins = int(rng.choice([256, 512, 1024]))
     p.line.conv_seed_order = int(rng.random() < 0.7)       # convention C.9: mostly the std::sort order (the default), sometimes the raster order
+    p.line.lsd_refine = int(rng.random() < 0.3)            # LSD_REFINE_STD on a third of the draws
+    p.line.lsd_density_th = float(rng.choice([0.6, 0.6, 0.7, 0.85]))
     p.stereo.fx, p.stereo.bf = float(rng.uniform(300, 900)), float(rng.uniform(30, 400))
     p.stereo.best_lr_matches = int(rng.integers(0, 2))
     kind = int(rng.integers(0, 6))
     if kind == 5 and w * h > 300 * 1000:
         kind = 1                                     # full-size pure noise exceeds the 65535 corners a level can hold
     desc = (f"#{it} {w}x{h} kind {kind} orb({p.orb.nfeatures},{p.orb.scale_factor:.2f},{p.orb.nlevels},{p.orb.ini_th_fast},{p.orb.min_th_fast}) "
-            f"lsd(n={p.line.lsd_nfeatures},len={p.line.min_line_length},s={p.line.lsd_scale},sig={p.line.lsd_sigma_scale},q={p.line.lsd_quant},"
+            f"lsd(n={p.line.lsd_nfeatures},len={p.line.min_line_length},refine={p.line.lsd_refine},dens={p.line.lsd_density_th},s={p.line.lsd_scale},sig={p.line.lsd_sigma_scale},q={p.line.lsd_quant},"
             f"a={p.line.lsd_ang_th},bins={p.line.lsd_n_bins})")
     try:
         fe = ola.StereoFrontEnd(p, w, h, max_pairs=1)
