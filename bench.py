@@ -42,7 +42,7 @@ CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD 
     "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=640),
 }
 STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_fast_cells": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
-                "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow",
+                "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow<false>",
                 "lsd_rect": "olf::k_lsd_rect", "line_select_lbd": "olf::k_lbd_rows", "stereo_lines": "olf::k_lines_dist", "match_bf": "olf::k_knn2"}
 
 
@@ -419,8 +419,10 @@ def main():
         try:
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
                 pm = json.load(open(f))
-                if pm.get("source_hash") == sh and STAGE_KERNEL[dom] in pm["kernels"]:
-                    traffic = int(pm["kernels"][STAGE_KERNEL[dom]]["bytes_per_image"] * 2 * B)
+                # (rocprofv3 prints a template kernel as "void olf::name<args>(...)": the summary's keys are that text up to the parenthesis)
+                key = next((k for k in pm["kernels"] if k.replace("void ", "") == STAGE_KERNEL[dom]), None)
+                if pm.get("source_hash") == sh and key:
+                    traffic = int(pm["kernels"][key]["bytes_per_image"] * 2 * B)
                     break
         except Exception:
             traffic = None
