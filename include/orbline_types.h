@@ -65,7 +65,7 @@ typedef struct olf_orb_params {
 typedef struct olf_line_params {
     int32_t lsd_nfeatures;      /* 0 = keep all                                        */
     double  min_line_length;    /* relative to min(w,h); src/LineExtractor.cc:53       */
-    int32_t lsd_refine;         /* 0 LSD_REFINE_NONE, 1 LSD_REFINE_STD; 2 (ADV) refused */
+    int32_t lsd_refine;         /* 0 LSD_REFINE_NONE, 1 LSD_REFINE_STD, 2 LSD_REFINE_ADV */
     double  lsd_scale;
     double  lsd_sigma_scale;
     double  lsd_quant;

@@ -203,7 +203,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
 {
     LineGeom& g = geom;
     g = LineGeom();
-    if (p.lsd_refine != 0 && p.lsd_refine != 1) return OLF_ERR_INVALID;      // LSD_REFINE_NONE and LSD_REFINE_STD are on the path; ADV (NFA) is not
+    if (p.lsd_refine < 0 || p.lsd_refine > 2) return OLF_ERR_INVALID;        // LSD_REFINE_NONE / STD / ADV
     if (p.conv_seed_order != 0 && p.conv_seed_order != 1) return OLF_ERR_INVALID;
     if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
@@ -228,6 +228,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.nBins = p.lsd_n_bins;
     const double LOG_NT = 5 * (std::log10(double(g.Ws)) + std::log10(double(g.Hs))) / 2 + std::log10(11.0);
     g.minRegSize = int(-LOG_NT / std::log10(pp));
+    g.logNT = LOG_NT; g.logEps = p.lsd_log_eps; g.pProb = pp;
     g.minLength = p.min_line_length * std::min(W, H);
     g.maxDetect = std::min(8192, std::max(4096, g.Ps / 256));       // raw segments kept per image before the top-N (k_line_select sorts them in LDS)
     // 16-byte region records alias the unsorted key buffer, 24-byte segment candidates the sorted one (4 bytes per pixel each)

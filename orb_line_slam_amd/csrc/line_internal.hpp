@@ -45,6 +45,7 @@ struct LineGeom {
     int seedOrder;             // convention C.9: 0 raster order inside a gradient bin (stable radix sort), 1 libstdc++'s std::sort order (lsd_seedsort.hip)
     int refine;                // lsd_refine: 0 LSD_REFINE_NONE, 1 LSD_REFINE_STD (density check, second growth, reduce_region_radius inside the agent)
     double densityTh;          // lsd_density_th
+    double logNT, logEps, pProb;   // LSD_REFINE_ADV: 5 (log10 Ws + log10 Hs) / 2 + log10 11 (host libm), lsd_log_eps, ang_th / 180
     int resizeExact;           // convention C.10: the upsampling is cv::resize INTER_LINEAR_EXACT (8-bit coefficients in rx / ry)
 };
 

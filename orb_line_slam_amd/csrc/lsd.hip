@@ -388,7 +388,7 @@ __device__ __forceinline__ SegCand rect_to_cand(const LineGeom& g, double x1, do
 // ---- LSD_REFINE_STD inside the agent (cv LineSegmentDetectorImpl::refine / reduce_region_radius, convention C.14; oracle/line_oracle.cpp).
 // The region's pixel log is (x | y << 16, gradient word) pairs in growth order; every lane runs the same scalar loops over it (uniform addresses:
 // one request per load), so the sums are formed in exactly the reference's order.
-struct AgentRect { double x1, y1, x2, y2, width; };
+struct AgentRect { double x1, y1, x2, y2, width, theta, dx, dy, prec, p; };
 
 __device__ __forceinline__ double log_modgrad(uint32_t w) { const int gx = unpack_gx(w), gy = unpack_gy(w); return sqrt((double)(gx * gx + gy * gy) / 4.0); }
 
@@ -439,7 +439,173 @@ __device__ __forceinline__ AgentRect agent_region2rect(const uint2* lg, int n, d
     rec.x2 = d_add(x, d_mul(l_max, ddx)); rec.y2 = d_add(y, d_mul(l_max, ddy));
     rec.width = d_sub(w_max, w_min);
     if (rec.width < 1.0) rec.width = 1.0;
+    rec.theta = theta; rec.dx = ddx; rec.dy = ddy; rec.prec = prec; rec.p = 0;      // (p: set by the caller, only the NFA stage reads it)
     return rec;
+}
+
+// ---- LSD_REFINE_ADV: rect_improve / rect_nfa / nfa / log_gamma (convention C.14; oracle/line_oracle.cpp).  The numbers of false alarms are
+// compared with each other and with log_eps only; their libm calls (log, exp, pow, sinh, log10) are the device library's, so a decision can differ
+// from the host's where two of these doubles are closer than the libraries' last-bit differences.
+__device__ __noinline__ double agent_log_gamma(double x)
+{
+    if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+    const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+    double b = 0;
+    for (int n = 0; n < 7; ++n) {
+        a -= log(x + (double)n);
+        b += q[n] * pow(x, (double)n);
+    }
+    return a + log(b);
+}
+
+__device__ __noinline__ double agent_nfa(int n, int k, double p, double LOG_NT)
+{
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - (double)n * log10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = agent_log_gamma((double)n + 1) - agent_log_gamma((double)k + 1) - agent_log_gamma((double)(n - k) + 1) + (double)k * log(p) +
+                            (double)(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    {   // double_equal(term, 0)
+        bool eq = term == 0.0;
+        if (!eq) { double am = fabs(term); if (am < 2.2250738585072014e-308) am = 2.2250738585072014e-308; eq = (fabs(term) / am) <= (100.0 * 2.2204460492503131e-16); }
+        if (eq) {
+            if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
+            return -LOG_NT;
+        }
+    }
+    double bin_tail = term;
+    for (int i = k + 1; i <= n; ++i) {
+        const double bin_term = (double)(n - i + 1) / (double)i;
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - pow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < 0.1 * fabs(-log10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - LOG_NT;
+}
+
+// rect_nfa: the rectangle's corners (truncated to int), ordered by x then y; rows from the lowest to the highest corner, the left and right ends of a
+// row advance by the edge steps (integer divisions, and tailp's x where its y is meant: as in the original).  The pixels of a row are counted across the
+// lanes (the counts do not depend on the order).
+__device__ __noinline__ double agent_rect_nfa(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, const AgentRect& rec, int lane)
+{
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+    int ex[4], ey[4];
+    ex[0] = (int)(rec.x1 - dyhw); ey[0] = (int)(rec.y1 + dxhw);
+    ex[1] = (int)(rec.x2 - dyhw); ey[1] = (int)(rec.y2 + dxhw);
+    ex[2] = (int)(rec.x2 + dyhw); ey[2] = (int)(rec.y2 - dxhw);
+    ex[3] = (int)(rec.x1 + dyhw); ey[3] = (int)(rec.y1 - dxhw);
+    // std::sort of four (x, y) pairs, x ascending then y ascending (equal pairs are indistinguishable): insertion sort
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0 && (ex[j] == ex[j - 1] ? ey[j] < ey[j - 1] : ex[j] < ex[j - 1]); --j) {
+            const int tx = ex[j], ty = ey[j]; ex[j] = ex[j - 1]; ey[j] = ey[j - 1]; ex[j - 1] = tx; ey[j - 1] = ty;
+        }
+    int imin = 0, imax = 0;
+    for (int i = 1; i < 4; ++i) {
+        if (ey[imin] > ey[i]) imin = i;
+        if (ey[imax] < ey[i]) imax = i;
+    }
+    unsigned taken = 1u << imin;
+    int il = -1;
+    for (int i = 0; i < 4; ++i)
+        if (!((taken >> i) & 1u)) { if (il < 0) il = i; else if (ex[il] > ex[i]) il = i; }
+    taken |= 1u << il;
+    int ir = -1;
+    for (int i = 0; i < 4; ++i)
+        if (!((taken >> i) & 1u)) { if (ir < 0) ir = i; else if (ex[ir] < ex[i]) ir = i; }
+    taken |= 1u << ir;
+    int it = -1;
+    for (int i = 0; i < 4; ++i)
+        if (!((taken >> i) & 1u)) { if (it < 0) it = i; else if (ex[it] > ex[i]) it = i; }
+    const int myx = ex[imin], myy = ey[imin], lx = ex[il], ly = ey[il], rx = ex[ir], ry = ey[ir], tx = ex[it];
+    const double flstep = (myy != ly) ? (double)((myx - lx) / (myy - ly)) : 0;
+    const double slstep = (ly != tx) ? (double)((lx - tx) / (ly - tx)) : 0;
+    const double frstep = (myy != ry) ? (double)((myx - rx) / (myy - ry)) : 0;
+    const double srstep = (ry != tx) ? (double)((rx - tx) / (ry - tx)) : 0;
+    double lstep = flstep, rstep = frstep;
+    double left_x = myx, right_x = myx;
+    int total_pts = 0, alg_pts = 0;
+    const int Ws = g.Ws, Hs = g.Hs;
+    for (int y = myy; y <= ey[imax]; ++y) {
+        if (y < 0 || y >= Hs) continue;
+        const int xa = (int)left_x, xb = (int)right_x;
+        for (int x0 = xa; x0 <= xb; x0 += 64) {
+            const int x = x0 + lane;
+            const bool in = x <= xb && x >= 0 && x < Ws;
+            bool al = false;
+            if (in) {
+                const uint32_t w = grad[y * Ws + x];
+                if (!(w & kNotDef)) {
+                    double nt = fabs(d_sub(rec.theta, ent[w & 0x3fffffu].ang));
+                    if (nt > kM32PI) nt = fabs(d_sub(nt, kM2PI));
+                    al = nt <= rec.prec;
+                }
+            }
+            total_pts += __popcll(wave_vote(in));
+            alg_pts += __popcll(wave_vote(al));
+        }
+        if (y >= ly) lstep = slstep;
+        if (y >= ry) rstep = srstep;
+        left_x += lstep;
+        right_x += rstep;
+    }
+    return agent_nfa(total_pts, alg_pts, rec.p, g.logNT);
+}
+
+__device__ __noinline__ double agent_rect_improve(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, AgentRect& rec, int lane)
+{
+    const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = g.logEps;
+    double log_nfa = agent_rect_nfa(g, grad, ent, rec, lane);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    AgentRect r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * kPI;
+        const double v = agent_rect_nfa(g, grad, ent, r, lane);
+        if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            const double v = agent_rect_nfa(g, grad, ent, r, lane);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            const double v = agent_rect_nfa(g, grad, ent, r, lane);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            const double v = agent_rect_nfa(g, grad, ent, r, lane);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n)
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * kPI;
+            const double v = agent_rect_nfa(g, grad, ent, r, lane);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    return log_nfa;
 }
 
 __device__ __forceinline__ double agent_dist(double x1, double y1, double x2, double y2)
@@ -466,7 +632,7 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // REFINE (lsd_refine = LSD_REFINE_STD): every region of minRegSize pixels is fitted and, if its density is below the threshold, un-used, grown again
 // under the tolerance tau derived from its angles, and shrunk (reduce_region_radius) -- all inside the seed loop, because the pixels it gives back are
 // seeds and neighbours of later regions.  The agent then writes the segment candidates itself (candAll) and k_lsd_rect is not launched.
-template <bool REFINE>
+template <int REFINE>      // 0: LSD_REFINE_NONE, 1: STD, 2: ADV
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
@@ -800,6 +966,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             break;
           }
             if (REFINE) {
+                if (REFINE >= 2 && accept) {        // LSD_REFINE_ADV: keep the rectangle only if its (improved) number of false alarms is meaningful
+                    rec.p = g.pProb;
+                    __threadfence_block();
+                    if (agent_rect_improve(g, grad, ent, rec, lane) <= g.logEps) accept = false;
+                }
                 if (accept) {
                     if (nreg < g.maxRegions) {
                         const SegCand cnd = rect_to_cand(g, rec.x1, rec.y1, rec.x2, rec.y2);
@@ -1134,17 +1305,20 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
         // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once
-        hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+        hipLaunchKernelGGL(k_lsd_grow<0>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt, (SegCand*)nullptr);
         OLF_HIP_CHECK(hipGetLastError());
         return OLF_OK;
     }
-    if (g.refine)
-        // (the candidates go to keysA: keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
-        hipLaunchKernelGGL(k_lsd_grow<true>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+    // (lsd_refine: the candidates go to keysA -- keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
+    if (g.refine >= 2)
+        hipLaunchKernelGGL(k_lsd_grow<2>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
+    else if (g.refine)
+        hipLaunchKernelGGL(k_lsd_grow<1>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
     else
-        hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+        hipLaunchKernelGGL(k_lsd_grow<0>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;

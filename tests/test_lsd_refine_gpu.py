@@ -1,6 +1,6 @@
 """GPU parity for lsd_refine = 1 (cv::LSD_REFINE_STD, src/LineExtractor.cc:45 passes Config's lsd_refine through): the density check, the second
 growth under the tolerance tau and reduce_region_radius run inside the growth agent; key lines and LBD descriptors must equal the oracle's
-(oracle/line_oracle.cpp, convention C.14).  lsd_refine = 2 (LSD_REFINE_ADV, the NFA stage) is refused at context creation."""
+(oracle/line_oracle.cpp, convention C.14).  lsd_refine = 2 (LSD_REFINE_ADV) adds the NFA stage."""
 import ctypes as C
 import numpy as np
 import pytest
@@ -89,9 +89,45 @@ def test_refine_std_through_the_fused_stereo_entry(oracle):
         assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
 
 
-def test_refine_adv_is_refused():
+@pytest.mark.parametrize("w,h,seed_order", [(640, 480, 1), (1242, 375, 1), (752, 480, 0), (320, 240, 1)])
+def test_line_extract_refine_adv(oracle, w, h, seed_order):
+    """lsd_refine = 2 (LSD_REFINE_ADV): rect_improve / rect_nfa / nfa on top of STD.  The numbers of false alarms go through the device's libm
+    (log, exp, pow, sinh, log10), the oracle's through glibc's; they are only compared with each other and with log_eps, so the key lines agree
+    unless such a comparison is closer than the libraries' last-bit differences -- none is on these images."""
+    p = oracle.full_params(2000, 0)
+    p.line.lsd_refine = 2; p.line.conv_seed_order = seed_order
+    p1 = oracle.full_params(2000, 0)
+    p1.line.lsd_refine = 1; p1.line.conv_seed_order = seed_order
+    ex = ola.Lineextractor(0, 0.025, lsd_refine=2, conv_seed_order=seed_order)
+    rng = np.random.default_rng(w)
+    dropped = 0
+    for seed in (3, 4):
+        left, right = synth.stereo_pair(seed, w, h)
+        noisy = np.clip(left.astype(np.int32) + rng.integers(-12, 13, left.shape), 0, 255).astype(np.uint8)
+        for img in (left, right, noisy):
+            gk, gd = ex(img)
+            o = oracle.line_extract(img, p.line)
+            _cmp_keylines(gk, o["kls"])
+            assert np.array_equal(gd, o["desc"])
+            dropped += len(oracle.line_extract(img, p1.line)["kls"]) - len(o["kls"])
+    assert dropped > 0, "the NFA stage must reject something on these images"
+
+
+def test_refine_adv_other_thresholds_and_patterns(oracle):
+    w, h = 640, 360
+    for name, eps in (("rings", 0.0), ("soft_edges", 1.0), ("tri_diag", -2.0), ("checker", 0.0)):
+        img = _pattern(name, w, h)
+        p = oracle.full_params(1000, 0)
+        p.line.lsd_refine = 2; p.line.lsd_log_eps = eps
+        ex = ola.Lineextractor(0, 0.025, lsd_refine=2, lsd_log_eps=eps)
+        k, d = ex(img)
+        o = oracle.line_extract(img, p.line)
+        _cmp_keylines(k, o["kls"])
+        assert np.array_equal(d, o["desc"]), name
+
+
+def test_refine_out_of_range_is_refused():
     p = _lib.default_params()
-    p.line.lsd_refine = 2
+    p.line.lsd_refine = 3
     h = C.c_void_p()
     assert _lib.lib().olf_ctx_create(C.byref(p), 640, 480, 1, C.byref(h)) == _lib.OLF_ERR_INVALID
-    assert b"LSD" in _lib.lib().olf_last_error() or _lib.lib().olf_last_error()

@@ -55,7 +55,8 @@ for it in range(N):
     p.line.lsd_ang_th = float(rng.choice([15.0, 22.5, 30.0]))
     p.line.lsd_n_bins = int(rng.choice([256, 512, 1024]))
     p.line.conv_seed_order = int(rng.random() < 0.7)       # convention C.9: mostly the std::sort order (the default), sometimes the raster order
-    p.line.lsd_refine = int(rng.random() < 0.3)            # LSD_REFINE_STD on a third of the draws
+    p.line.lsd_refine = int(rng.choice([0, 0, 0, 0, 1, 1, 2]))   # LSD_REFINE_STD / ADV on some of the draws
+    p.line.lsd_log_eps = float(rng.choice([0.0, 0.0, 1.0, -1.0]))
     p.line.lsd_density_th = float(rng.choice([0.6, 0.6, 0.7, 0.85]))
     p.stereo.fx, p.stereo.bf = float(rng.uniform(300, 900)), float(rng.uniform(30, 400))
     p.stereo.best_lr_matches = int(rng.integers(0, 2))
