@@ -373,14 +373,15 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         const uint32_t iv_v = WG_LOAD(c.eInval + slot), wm_v = (uint32_t)WG_LOAD(c.ctl + C_WM);
         const uint32_t iv = (uint32_t)uni((int)iv_v), wm = (uint32_t)uni((int)wm_v);
         if (iv != MW_FREE) { blocker = iv; fail = true; PROF_CNT(PF_F_INVAL); break; }
-        const int nb = min(7, n - i);
-        const int e = lane / 9, k = lane - 9 * e;
-        bool cand = lane < 63 && e < nb && k != 4;
+        // 8 FIFO entries x 8 neighbours per iteration, candidates as lane masks in scalar registers (as in the one-wave agent, lsd.hip)
+        const int nb = min(8, n - i);
+        const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);
+        const unsigned long long geo = nb == 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
         uint32_t rp;
         if (n - i > MW_RING) {
             // the window left the ring: read the FIFO from the chunk chain
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const int q = i + (cand ? e : 0);
+            const int q = i + (wave_bit(geo) ? e : 0);
             const int ord = q >> 5;
             int cid;
             if (ord < MW_DIR) cid = dir[ord];
@@ -388,33 +389,32 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             rp = AG_LOAD(c.chunks + (size_t)cid * 32 + (q & 31));
         } else rp = ring[(i + e) & (MW_RING - 1)];
         const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
-        cand = cand && xx >= 0 && yy >= 0 && xx < Ws && yy < Hs;
-        const int a = cand ? yy * Ws + xx : 0;
+        const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
+        const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
         const uint32_t pw = c.grad[a];
         const uint32_t o = AG_LOAD(c.owner + a);
         const int xy = xx | (yy << 16);
         // not mine, not used by a final region; an older, unfinished claim stays a candidate ("contested")
-        cand = cand && !(pw & kNotDef) && o != T && !(o < T && (o >> MW_SLOT_BITS) < wm);
-        const bool con = cand && o < T;
+        const unsigned long long olderM = wave_vote(o < T);
+        unsigned long long cm = inImg & wave_vote(!(pw & kNotDef)) & wave_vote(o != T) & ~(olderM & wave_vote((o >> MW_SLOT_BITS) < wm));
+        const unsigned long long conM = cm & olderM;
         MW_PENDING();
         if (fail) break;
         double ang = 0, cs = 0, sn = 0;
-        if (cand) {
+        if (wave_bit(cm)) {
             const uint32_t ti = pw & 0x3fffffu;
             const AngEnt* t = ent + ti;
             ang = t->ang;
             cs = t->cs; sn = t->sn;
         }
-        unsigned long long cm = wave_vote(cand);
-        const unsigned long long conM = wave_vote(con);
         PROF(PF_GATHER);
         unsigned long long acc = 0;
         const int n0 = n;
         while (cm) {
             // isaligned(): see k_lsd_grow (lsd.hip) -- wrapped test against precWrap, candidates in lane order = the reference's visiting order
             const double nth = fabs(d_sub(reg_angle, ang));
-            const bool was = nth <= prec || nth >= precWrap;
-            const unsigned long long al = wave_vote(was) & cm;
+            const unsigned long long wasM = wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+            const unsigned long long al = wasM & cm;
             if (!al) break;
             if ((al & (al - 1ull)) == 0) {
                 const int cc = __builtin_ctzll(al);
@@ -452,8 +452,8 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             double thg = shfl_d(th, max(gq - 1, 0));
             if (gq == 0) thg = reg_angle;
             const double n2 = fabs(d_sub(thg, ang));
-            const bool re = n2 <= prec || n2 >= precWrap;
-            const unsigned long long mis = wave_vote(re != was && !(dupStep < gq)) & cm;
+            const unsigned long long reM = wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+            const unsigned long long mis = (reM ^ wasM) & ~wave_vote(dupStep < gq) & cm;
             const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
             const unsigned long long okAcc = spec & bm;
             const int tt = __popcll(okAcc);
@@ -472,7 +472,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             n = n0; fail = true; PROF_CNT(PF_F_CONTEST); break;
         }
         if (acc) {
-            // chunks for list positions n0 .. n-1 (at most two new ones: an iteration adds <= 56 pixels)
+            // chunks for list positions n0 .. n-1 (at most two new ones: an iteration adds <= 64 pixels)
             const int curOrd = (n0 - 1) >> 5, lastOrd = (n - 1) >> 5;
             int new1 = -1, new2 = -1;
             if (lastOrd > curOrd) {
