@@ -426,6 +426,20 @@ def main():
                     break
         except Exception:
             traffic = None
+        # the same kernel against the part's vector-instruction issue rate: SQ_INSTS_VALU per image (profiles/*_valu_budget.json, same source-hash rule)
+        # x images per launch / launch duration, over 256 CUs x 4 SIMDs x one wave64 vector instruction per 4 cycles at 2.4 GHz = 614.4 G/s
+        valu = None
+        try:
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_budget.json")), reverse=True):
+                vb = json.load(open(f))
+                key = next((k for k in vb["kernels"] if k.replace("void ", "") == STAGE_KERNEL[dom]), None)
+                if vb.get("source_hash") == sh and key:
+                    rate = vb["kernels"][key]["valu_per_image"] * 2 * B / (dom_ms * 1e-3) / 1e9
+                    valu = {"achieved": round(rate, 1), "peak": 614.4, "unit": "G wave-instructions/s", "frac": round(rate / 614.4, 4),
+                            "valu_per_image": int(vb["kernels"][key]["valu_per_image"]), "salu_per_image": int(vb["kernels"][key]["salu_per_image"])}
+                    break
+        except Exception:
+            valu = None
         out = {
             "metric": f"stereo frames/s extract+match (ORB+LBD), {'KITTI ' if args.config == 'C3' else ''}{W}x{H}", "value": round(fps, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -437,7 +451,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                          "avg_launch_ms": round(dom_ms, 4), "path_bytes_per_pair": int(ab["pair"]),
-                         "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6)},
+                         "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6), "valu_issue": valu},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
         }
         if alone:

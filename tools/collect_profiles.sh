@@ -10,6 +10,9 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tm
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d /tmp/pw -o run -- python $R/tools/prof_lines.py 4096 > /tmp/pw.log 2>&1
 python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw 4096 $O/${T}_pmc_hbm_traffic > $O/${T}_pmc_hbm_traffic_lines4096.txt 2>&1
 cp $O/${T}_pmc_hbm_traffic.json $R/profiles/      # bench.py reads roofline.traffic from the summary whose source hash matches the sources it runs
+rm -rf /tmp/pb
+OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
+python $R/tools/pmc_budget.py /tmp/pb 1024 $O/${T}_valu_budget.json > $O/${T}_valu_budget_per_kernel.txt 2>&1; cp $O/${T}_valu_budget.json $R/profiles/
 timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_C3.json; cut -c1-160 $O/${T}_bench_C3.json
 OLF_ONE_STREAM=1 timeout 600 python $R/bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_one_stream.json
 for c in C2 C4 C5; do timeout 600 python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_$c.json; done
@@ -19,9 +22,6 @@ cp $(ls /tmp/ks/*kernel_stats.csv | head -1) $O/${T}_bench_C3_kernel_stats.csv
 python $R/tools/timeline.py /tmp/ks > $O/${T}_timeline_two_streams.txt 2>&1
 rm -rf /tmp/ks1; OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /tmp/ks1.log 2>&1
 cp $(ls /tmp/ks1/*kernel_stats.csv | head -1) $O/${T}_bench_C3_one_stream_kernel_stats.csv
-rm -rf /tmp/pb
-OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
-python $R/tools/pmc_budget.py /tmp/pb 1024 > $O/${T}_valu_budget_per_kernel.txt 2>&1
 OLF_ONE_STREAM=1 timeout 600 python $R/tools/grow_sweep.py 1 8 128 512 1024 2048 3072 > $O/${T}_grow_sweep.txt 2>&1
 timeout 900 python $R/tools/soak.py $SOAK > $O/${T}_soak.txt 2>&1; tail -2 $O/${T}_soak.txt
 timeout 900 python $R/tools/fuzz.py 500 11 2>/dev/null | tail -8 > $O/${T}_fuzz_500configs.txt; tail -1 $O/${T}_fuzz_500configs.txt
