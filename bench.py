@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--scene", choices=("default", "long", "bars"), default="default", help="long: fewer, larger shapes; bars: long thin bars -> key lines of about 0.08*W pixels (SURVEY App. D model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bow", action="store_true", help="frame-to-frame ORB matching by the dense kNN stand-in of rounds 1-2 instead of SearchByBoW")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the pass that runs every stage alone (counter collections that must see exactly the timed steps)")
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
@@ -364,7 +365,7 @@ def main():
     # every stage on its own: the four extraction / matching entries back to back on one stream (what OLF_ONE_STREAM=1 makes of a step), outside the
     # timed region -- in the two-stream step the stages slow each other down, so only these times can be set against a stage's own bytes
     alone = None
-    if rank == 0:
+    if rank == 0 and not args.no_isolated:
         ctx.profile(True)
         s0 = torch.cuda.current_stream().cuda_stream
         for _ in range(2):

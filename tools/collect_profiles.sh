@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d /tm
 python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw 4096 $O/${T}_pmc_hbm_traffic > $O/${T}_pmc_hbm_traffic_lines4096.txt 2>&1
 cp $O/${T}_pmc_hbm_traffic.json $R/profiles/      # bench.py reads roofline.traffic from the summary whose source hash matches the sources it runs
 rm -rf /tmp/pb
-OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
+OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --no-isolated --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
 python $R/tools/pmc_budget.py /tmp/pb 1024 $O/${T}_valu_budget.json > $O/${T}_valu_budget_per_kernel.txt 2>&1; cp $O/${T}_valu_budget.json $R/profiles/
 timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_C3.json; cut -c1-160 $O/${T}_bench_C3.json
 OLF_ONE_STREAM=1 timeout 600 python $R/bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_one_stream.json
