@@ -352,3 +352,56 @@ def test_line_extract_long_line_scene(oracle):
         _cmp_keylines(gk, o["kls"])
         assert np.array_equal(gd, o["desc"])
         assert gk["numOfPixels"].mean() > 90
+
+
+def test_line_extract_full_occupancy_batch(oracle):
+    """6144 KITTI-sized images in one call -- the bench's batch: 24 one-wave seed sorts / growth agents per CU, i.e. workgroups whose LDS
+    allocations start far above 64 KB (the seed sort stages blocks through global_load_lds, whose M0 base has 16 bits), every resident wave
+    slot taken.  Every image's key lines and descriptors must equal the oracle's for the distinct image it is a copy of."""
+    w, h, distinct, n = 1242, 375, 24, 6144
+    base = synth.stereo_batch(7100, distinct // 2, w, h)
+    p = oracle.full_params(2000, 500)
+    want = [oracle.line_extract(im, p.line) for im in base]
+    imgs = np.tile(base, (n // distinct, 1, 1))
+    assert len(imgs) == n
+    ex = ola.Lineextractor(500, 0.025, max_images=n)
+    kls, desc, counts = ex.extract_batch(imgs)
+    bad = []
+    for i in range(n):
+        o = want[i % distinct]
+        c = int(counts[i])
+        if c != len(o["kls"]) or not np.array_equal(kls[i, :c], o["kls"]) or not np.array_equal(desc[i, :c], o["desc"]):
+            bad.append(i)
+    assert not bad, (len(bad), bad[:8])
+
+
+def test_stereo_frames_full_batch(oracle):
+    """the headline batch -- 3072 pairs through the fused entry (two streams, the ORB kernels in the growth agents' shadow, every wave slot and
+    most of the LDS taken): every pair's key points, descriptors, stereo matches, key lines and line matches equal the oracle's for the
+    distinct pair it is a copy of"""
+    w, h, distinct, n = 1242, 375, 8, 3072
+    p = oracle.full_params(2000, 500, 718.856, 386.1448)
+    base = synth.stereo_batch(7300, distinct, w, h)
+    want = []
+    for i in range(distinct):
+        o = oracle.stereo_points(base[2 * i], base[2 * i + 1], p)
+        ol, orr = oracle.line_extract(base[2 * i], p.line), oracle.line_extract(base[2 * i + 1], p.line)
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        want.append((o, ol, orr, m, disp, le))
+    imgs = np.tile(base, (n // distinct, 1, 1))
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=n)
+    f = fe.frames(imgs)
+    bad = []
+    for i in range(n):
+        g = f.pair(i)
+        o, ol, orr, m, disp, le = want[i % distinct]
+        ok = (np.array_equal(g["mvKeys"], o["kpsL"]) and np.array_equal(g["mDescriptors"], o["descL"]) and np.array_equal(g["mvKeysRight"], o["kpsR"])
+              and np.array_equal(g["mDescriptorsRight"], o["descR"]) and np.array_equal(g["mvuRight"].view(np.uint32), o["uRight"].view(np.uint32))
+              and np.array_equal(g["mvDepth"].view(np.uint32), o["depth"].view(np.uint32))
+              and np.array_equal(g["mvKeys_Line"], ol["kls"]) and np.array_equal(g["mvKeysRight_Line"], orr["kls"])
+              and np.array_equal(g["mDescriptors_Line"], ol["desc"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"])
+              and np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+              and np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64)))
+        if not ok:
+            bad.append(i)
+    assert not bad, (len(bad), bad[:8])
