@@ -172,7 +172,7 @@ int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
  * its heap-sort branch. */
 int olf_debug_seed_sort(olf_ctx* ctx, const uint32_t* keys, int n, int kthr, int depth_limit, uint32_t* out, int32_t* out_n);
 /* debug / tests: the kernel variant of that replay -- 0: one wave per image (batches), 1 / 2: 4 / 8 cooperating waves per image (few images: the
- * drop-in's one-pair-per-call shape), 3 / 4: groups of 4 / 8 images per workgroup whose waves take over each other's ranges (large batches),
+ * drop-in's one-pair-per-call shape), 3 / 4: groups of 4 / 8 images per workgroup whose waves take over each other's ranges (large batches), 5: 2 waves per image,
  * -1: chosen from the batch size.  Results do not depend on it. */
 int olf_debug_seed_sort_mode(olf_ctx* ctx, int mode);
 /* debug / tests: cap the 32-pixel chunk pool the multi-wave growth may use per image (0: all of it).  An image that exhausts the pool is grown

@@ -533,7 +533,7 @@ int olf_debug_seed_sort(olf_ctx* c, const uint32_t* keys, int n, int kthr, int d
 // debug / tests: which seed-sort kernel runs (-1: chosen from the batch size; 0: one wave per image; 1 / 2: 4 / 8 waves per image)
 int olf_debug_seed_sort_mode(olf_ctx* c, int mode)
 {
-    if (!c || mode < -1 || mode > 4) { set_error("olf_debug_seed_sort_mode: bad argument"); return OLF_ERR_INVALID; }
+    if (!c || mode < -1 || mode > 5) { set_error("olf_debug_seed_sort_mode: bad argument"); return OLF_ERR_INVALID; }
     c->lb.forceSortMode = mode;
     return OLF_OK;
 }

@@ -670,15 +670,18 @@ int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipS
 {
     // OLF_SS_MW: 0 forces the one-wave kernel, 1 / 2 the 4- / 8-wave variant, 3 / 4 groups of 4 / 8 images (A/B measurements); default: by batch size
     static const int forced = [] { const char* e = getenv("OLF_SS_MW"); return e ? atoi(e) : -1; }();
-    // up to 256 images: 8 waves per image (101 KB of LDS, one workgroup per CU); up to 768: 4 waves (53 KB, three per CU); beyond: one wave per image --
+    // up to 256 images: 8 waves per image (101 KB of LDS, one workgroup per CU); up to 640: 4 waves (53 KB, three per CU); up to 1536: 2 waves (30 KB, five per
+    // CU: the 1280 images of a 1080p batch go 144 -> 103 ms; KITTI size, ms: 512 images 9.3 / 12.2 with 4 / 2 waves, 768: 17.3 / 13.0, 1024: 18.3 / 13.7 and
+    // 23.2 with one, 1536: 27.1 / 24.2 / 24.7); beyond: one wave per image --
     // alone (mode 0).  Modes 3 / 4 (groups of 4 / 8 images whose waves take over each other's streamed ranges) are opt-in: on 6144 copies of 32 images
     // the kernel goes 43.5 -> 37.9 ms (groups of 8; 40.2 with 4; equal at 1536 images), on the bench's 512 distinct pairs the front does not move
     // (71.3 against 71.7 ms) and the step is 278.9 against 276.8 ms -- the launch is bound by issue slots, not by its slowest image.
     // One stereo pair through olf_stereo_frames, host to host: 25.6 ms with the one-wave kernel, 16.5 ms with 4 waves, 15.1 ms with 8
-    const int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 768 ? 1 : 0);
+    const int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 640 ? 1 : n_images <= 1536 ? 5 : 0);
     int rc = OLF_OK;
     if (mode == 1) rc = launch_seedsort_mw<4, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 2) rc = launch_seedsort_mw<8, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
+    else if (mode == 5) rc = launch_seedsort_mw<2, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 3) rc = launch_seedsort_grp<4>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 4) rc = launch_seedsort_grp<8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else

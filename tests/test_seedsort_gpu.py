@@ -67,7 +67,7 @@ def test_sort_kernel_variants_agree(oracle):
     imgs = imgs[[0, 1, 6, 2, 3, 4, 5]]
     want_lines = [oracle.line_extract(im, p.line) for im in imgs]
     assert len(want_lines[2]["kls"]) == 0 and len(want_lines[0]["kls"]) > 100
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5):
         _lib.check(_lib.lib().olf_debug_seed_sort_mode(ctx.handle, mode), "olf_debug_seed_sort_mode")
         for keys in cases:
             out = np.zeros(len(keys), np.uint32); n = C.c_int32()
