@@ -36,9 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD lines, fx, bf, default pairs per GPU per step
-    "C2": dict(w=640, h=480, nf=1000, nl=200, fx=435.2047, bf=47.9064, pairs=4096),
+    "C2": dict(w=640, h=480, nf=1000, nl=200, fx=435.2047, bf=47.9064, pairs=3072),
     "C3": dict(w=1242, h=375, nf=2000, nl=500, fx=718.856, bf=386.1448, pairs=3072),
-    "C4": dict(w=752, h=480, nf=1200, nl=500, fx=435.2047, bf=47.9064, pairs=3584),
+    "C4": dict(w=752, h=480, nf=1200, nl=500, fx=435.2047, bf=47.9064, pairs=3072),
     "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=640),
 }
 STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_fast_cells": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
