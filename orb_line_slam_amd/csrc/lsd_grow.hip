@@ -377,7 +377,10 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         const int nb = min(8, n - i);
         const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);
         const unsigned long long geo = nb == 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
-        uint32_t rp;
+        // (as in the one-wave agent, lsd.hip: the ring read unconditional, the memory read a rare branch that waits for itself -- merged into one
+        // load the two make the compiler drain the vector-memory counter, i.e. wait for the previous iteration's claims, before every gather)
+        uint32_t rp = ring[(i + e) & (MW_RING - 1)];
+        asm volatile("" : "+v"(rp));
         if (n - i > MW_RING) {
             // the window left the ring: read the FIFO from the chunk chain
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -387,7 +390,8 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             if (ord < MW_DIR) cid = dir[ord];
             else { cid = dir[MW_DIR - 1]; for (int o2 = MW_DIR - 1; o2 < ord; ++o2) cid = AG_LOAD(c.links + cid); }
             rp = AG_LOAD(c.chunks + (size_t)cid * 32 + (q & 31));
-        } else rp = ring[(i + e) & (MW_RING - 1)];
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
         const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
         const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
         const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
@@ -466,6 +470,9 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             reg_angle = rlane_d(th, tt - 1);
         }
         PROF(PF_CHAIN);
+        // vmcnt(0) while only loads can be in flight (they have returned): what crosses the back edge is then exactly this iteration's claims and
+        // list stores, and the next gather is issued in front of their results
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (acc & conM) {
             // the reference would add a pixel that an older, unfinished region holds right now: yield to that region
             blocker = (uint32_t)rlane((int)(o >> MW_SLOT_BITS), __builtin_ctzll(acc & conM));
