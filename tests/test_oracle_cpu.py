@@ -263,6 +263,30 @@ def test_introsort_restatement_equals_std_sort(oracle):
     assert not np.array_equal(oracle.std_sort_keys(keys), keys[np.argsort(k, kind="stable")])
 
 
+def test_lsd_refine_restatement_consistency(oracle):
+    """lsd_refine (convention C.14, restated from memory): properties that hold whatever the details -- a density threshold of 0 never
+    refines (STD = NONE), a log_eps below every number of false alarms never rejects and never improves (ADV = STD), STD changes segments on
+    real content, ADV with the default log_eps only ever drops or alters segments of STD"""
+    from orb_line_slam_amd import synth
+    left, _ = synth.stereo_pair(3, 640, 480)
+    p = oracle.full_params(1000, 0)
+    base, _ = oracle.lsd_detect(left, p.line)
+    p.line.lsd_refine = 1
+    std, _ = oracle.lsd_detect(left, p.line)
+    p.line.lsd_density_th = 0.0
+    assert np.array_equal(oracle.lsd_detect(left, p.line)[0], base)
+    p = oracle.full_params(1000, 0)
+    p.line.lsd_refine = 2
+    p.line.lsd_log_eps = -1e300
+    assert np.array_equal(oracle.lsd_detect(left, p.line)[0], std)
+    p.line.lsd_log_eps = 0.0
+    adv, _ = oracle.lsd_detect(left, p.line)
+    assert not np.array_equal(std, base) and len(adv) < len(std) and len(adv) > 0
+    # flat and tiny inputs
+    p.line.lsd_refine = 2
+    assert len(oracle.lsd_detect(np.full((64, 64), 7, np.uint8), p.line)[0]) == 0
+
+
 def test_lsd_resize_convention_changes_only_the_working_image(oracle):
     """Convention C.10: INTER_LINEAR_EXACT differs from INTER_LINEAR by at most one grey level per pixel of LSD's working image."""
     left, _ = synth.stereo_pair(5, 320, 240)
