@@ -273,7 +273,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     LineDeviceBufs& l = c->lb;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
-    A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
+    A(l.topBuf, n * (size_t)lsd_seedsort_top_words()); A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
     // chunk pool of the multi-wave growth: every pixel in a list once (Ps / 32) plus one partly filled chunk per logged region and ROB slot;
     // Ps / 16 chunks fill exactly the 2 * Ps words the one-wave agent's log needs anyway.  An image that still runs out is grown again by
     // the one-wave agent (launch_lsd_grow)

@@ -79,6 +79,7 @@ struct LineDeviceBufs {
     hipEvent_t sortEvent = nullptr;  // when set, launch_lsd_front records it in front of the seed ordering (the dense, bandwidth-bound part of the front is through)
     int* growFmt = nullptr;        // [n] after the multi-wave growth: 0 chunk chains, -1 given up (pool exhausted), 1 grown again by the one-wave agent (contiguous log)
     int poolChunks = 0;            // olf_debug_lsd_pool: > 0 caps the chunk pool the multi-wave kernel may use (tests of the fall-back)
+    int* topBuf = nullptr;         // [n][SS_TOP_WORDS] job lists / counters / final ranges of the seed sort's grid-wide top levels (lsd_seedsort.hip)
     int forceSortMode = -1;        // olf_debug_seed_sort_mode: 0 one wave per image, 1 / 2 the 4- / 8-wave kernel of lsd_seedsort.hip; -1: by batch size
     int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
@@ -102,6 +103,7 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
+int lsd_seedsort_top_words();      // ints per image of LineDeviceBufs::topBuf
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);

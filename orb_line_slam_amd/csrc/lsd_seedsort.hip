@@ -29,6 +29,10 @@
 
 namespace olf {
 
+// the grid-wide top levels (launch_seedsort_top, below)
+constexpr int SS_TOP_MIN = 32768, SS_TOP_JOBS = 64, SS_TOP_LEVELS = 6, SS_TOP_FINAL = 224;
+constexpr int SS_JW = 12;      // words of a job: first, last, depth of its children, lb, ub, pivot key, first tile, tiles, s, cut
+constexpr int SS_TOP_WORDS = 8 + 2 * SS_TOP_JOBS * SS_JW + SS_TOP_FINAL * 5;      // per image: counters [nJobs, nNext, nFinal, tiles, Kthr, n], two job lists, final entries
 constexpr int SS_CAP = 1024;      // elements of a range held in LDS (4 KB + 2 KB of exchange arrays: 24 waves = 24 images per CU)
 constexpr int SS_NE_MEM = 4;      // tiles per block while a range streams from memory (stopper queues: 2 x 256 pairs = the idle range buffer; the staged blocks behind it)
 constexpr int SS_NE_LDS = 2;      // ... while it is LDS resident (stopper queues: 2 x 128 pairs behind the range buffer)
@@ -394,7 +398,7 @@ enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OT
 template <int NW, int NEM, int NI = 1>
 __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_images, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                               const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                              uint32_t* s_buf, uint32_t* s_x, int* ctl)
+                                              uint32_t* s_buf, uint32_t* s_x, int* ctl, const int* topImg = nullptr)
 {
     static_assert(NI == 1 || NI == NW, "one wave per image of the group");
 #ifdef OLF_SS_PROF
@@ -442,7 +446,16 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
     int curSlot = NI > 1 ? ssU((int)(threadIdx.x >> 6)) : 0;
     if (NW == 1) SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
     else if (NI == 1) {
-        if (threadIdx.x == 0) { ctl[0] = 0; ctl[1] = 1; ctl[2] = 0; ctl[3] = 0; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
+        if (threadIdx.x == 0) {
+            ctl[0] = 0; ctl[2] = 0; ctl[3] = 0;
+            if (topImg) {
+                // the top levels have been partitioned by the grid-wide kernels (launch_seedsort_top): start from the ranges they left
+                const int nf = min(topImg[2], SHCAP);
+                const int* f = topImg + 8 + 2 * SS_TOP_JOBS * SS_JW;
+                for (int q = 0; q < nf; ++q) { shF[q] = f[5 * q]; shL[q] = f[5 * q + 1]; shD[q] = f[5 * q + 2]; shLb[q] = f[5 * q + 3]; shUb[q] = f[5 * q + 4]; }
+                ctl[1] = nf;
+            } else { ctl[1] = 1; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
+        }
         __syncthreads();
     } else {
         if (lane == 0) { cntS[curSlot] = 0; kthS[curSlot] = (int)Kthr; okS[curSlot] = empty ? 0 : 1; }
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
 template <int NW, int NEM, int NI>
 __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                                             const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                                            int n_images)
+                                                            int n_images, const int* __restrict__ topAll)
 {
     extern __shared__ __align__(8) uint32_t s_dyn[];
     constexpr int BUFW = 4 * 64 * NEM, XW = 2 * 64 * NEM;
@@ -627,7 +640,8 @@ __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __r
     uint32_t* s_buf = s_dyn + (size_t)NW * XW + (size_t)wv * BUFW;
     int* ctl = reinterpret_cast<int*>(s_dyn + (size_t)NW * (BUFW + XW));
     static_assert((size_t)NW * XW * 4 <= 65536, "staged blocks within reach of M0");
-    ss_sort_image<NW, NEM, NI>(*gp, blockIdx.x * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl);
+    ss_sort_image<NW, NEM, NI>(*gp, blockIdx.x * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl,
+                               NI == 1 && topAll ? topAll + (size_t)blockIdx.x * SS_TOP_WORDS : nullptr);
 }
 
 // the batch in image groups: NI waves, NI images, the one-wave kernel's block size and LDS per wave -- and its six waves per SIMD
@@ -654,6 +668,285 @@ static int launch_seedsort_grp(const LineGeom& g, LineDeviceBufs& b, int n_image
     return OLF_OK;
 }
 
+// ---- the top of the recursion on the whole GPU (few images) -------------------------------------------------------------------------------------
+// With a handful of images the first partitions are what a stereo pair waits for: 668 k, 475 k, 270 k ... elements streamed by ONE wave while the
+// rest of the chip idles (a workgroup's waves together are no faster: a single CU keeps ~16 KB in flight).  The ranges of at least SS_TOP_MIN elements
+// are therefore partitioned level by level by grid-wide kernels -- one launch per phase, the launch boundary being the barrier -- from the same rank
+// formulation as ss_partition: with L(j) the position of the j-th element >= pivot from the left and R(j) that of the j-th element <= pivot from the
+// right, the pairs j < s swap, s = #{j : L(j) < R(j)}; f(x) = #{L-stoppers left of x} rises, g(x) = #{R-stoppers at or right of x} falls, and
+// s = max_x min(f(x), g(x)) sits where they cross.  Per level: k_top_pivot (median of three, tile tables), k_top_count (stoppers per 64-key tile),
+// k_top_scan (f, g at the tile boundaries, crossing tile, s, the cut), k_top_gather (values of the swapping stoppers by rank -- into the seed list's
+// memory, which nothing has been emitted to yet), k_top_apply (stored at their partners' positions), k_top_next (children: next level's jobs, or
+// entries of the stack the per-image kernel starts from).  Job lists / counters / final entries: b.topBuf; f and g: the image's growth log.
+struct SsTop {
+    int* cnt; int* jobs; int* next; int* fin;
+};
+__device__ __forceinline__ SsTop ss_top(int* topAll, int img, int level)
+{
+    int* b = topAll + (size_t)img * SS_TOP_WORDS;
+    SsTop t; t.cnt = b; t.jobs = b + 8 + ((level & 1) ? SS_TOP_JOBS * SS_JW : 0); t.next = b + 8 + ((level & 1) ? 0 : SS_TOP_JOBS * SS_JW); t.fin = b + 8 + 2 * SS_TOP_JOBS * SS_JW;
+    return t;
+}
+__device__ __forceinline__ void ss_top_child(const SsTop& t, int* s_next, int* s_fin, int first, int last, int depth, uint32_t lb, uint32_t ub, uint32_t Kthr, bool lastLevel,
+                                             int* status)
+{
+    if (lb > Kthr) return;                                    // only undefined pixels: never seeds, never leave the range
+    if (!lastLevel && last - first >= SS_TOP_MIN && lb != ub && depth > 0) {
+        const int j = atomicAdd(s_next, 1);
+        int* q = t.next + j * SS_JW;
+        q[0] = first; q[1] = last; q[2] = depth - 1; q[3] = (int)lb; q[4] = (int)ub;
+    } else {
+        const int e = atomicAdd(s_fin, 1);
+        if (e < SS_TOP_FINAL) { int* q = t.fin + e * 5; q[0] = first; q[1] = last; q[2] = depth; q[3] = (int)lb; q[4] = (int)ub; }
+        else atomicOr(status, 32);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_top_init(const LineGeom* __restrict__ gp, int* __restrict__ topAll, const int* __restrict__ maxN, int nOverride, int kthrOverride,
+                                                 int depthOverride, int* __restrict__ status)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x;
+    if (threadIdx.x) return;
+    const SsTop t = ss_top(topAll, img, 0);
+    const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
+    uint32_t Kthr = 0;
+    bool empty = n <= 0;
+    if (empty) {}
+    else if (kthrOverride >= 0) Kthr = (uint32_t)kthrOverride;
+    else {
+        const int mN = maxN[img * 32];
+        if (mN <= 0) empty = true;
+        else {      // (as in ss_sort_image)
+            const double max_grad = sqrt((double)mN / 4.0);
+            const double bin_coef = (double)(g.nBins - 1) / max_grad;
+            const double normT = sqrt((double)g.nThr / 4.0);
+            Kthr = (uint32_t)(g.nBins - 1 - (int)(normT * bin_coef));
+        }
+    }
+    t.cnt[0] = 0; t.cnt[1] = 0; t.cnt[2] = 0; t.cnt[3] = 0; t.cnt[4] = (int)Kthr; t.cnt[5] = empty ? 0 : n;
+    if (empty) return;
+    const int depth0 = depthOverride >= 0 ? depthOverride : 2 * (31 - __builtin_clz((unsigned)n));
+    __shared__ int s_nj, s_nf;
+    s_nj = 0; s_nf = 0;
+    // (the root through the same rule as every child; the list level 0 reads is the `next` list of a view of "level -1")
+    const SsTop tm = ss_top(topAll, img, 1);
+    ss_top_child(tm, &s_nj, &s_nf, 0, n, depth0, 0u, (uint32_t)(g.nBins - 1), Kthr, false, status);
+    t.cnt[0] = s_nj; t.cnt[2] = s_nf;
+}
+
+// one thread per job: __move_median_to_first(first, first + 1, mid, last - 1); thread 0 then numbers the jobs' tiles
+__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_pivot(int* __restrict__ topAll, uint32_t* keysAll, size_t Ps, int level)
+{
+    const int img = blockIdx.x, j = threadIdx.x;
+    const SsTop t = ss_top(topAll, img, level);
+    const int nj = t.cnt[0];
+    uint32_t* A = keysAll + (size_t)img * Ps;
+    if (j < nj) {
+        int* q = t.jobs + j * SS_JW;
+        const int first = q[0], last = q[1], mid = first + (last - first) / 2;
+        const uint32_t e0 = A[first], ea = A[first + 1], eb = A[mid], ec = A[last - 1];
+        const uint32_t Ka = ssK(ea), Kb = ssK(eb), Kc = ssK(ec);
+        int sel;
+        if (Ka < Kb) sel = Kb < Kc ? 1 : (Ka < Kc ? 2 : 0);
+        else sel = Ka < Kc ? 0 : (Kb < Kc ? 2 : 1);
+        const uint32_t es = sel == 0 ? ea : sel == 1 ? eb : ec;
+        const int sidx = sel == 0 ? first + 1 : sel == 1 ? mid : last - 1;
+        A[first] = es; A[sidx] = e0;
+        q[5] = (int)ssK(es);
+        q[7] = (last - first - 1 + 63) >> 6;
+    }
+    __syncthreads();
+    if (j == 0) {
+        int acc = 0;
+        for (int k = 0; k < nj; ++k) { int* q = t.jobs + k * SS_JW; q[6] = acc; acc += q[7]; }
+        t.cnt[3] = acc;
+    }
+}
+
+// the tile `gt` of the level's flat tile numbering -> its job; PL / GR of job j start at (first tile + j) and leave one spare word per job (T + 1 entries)
+__device__ __forceinline__ int ss_top_job_of(const SsTop& t, int nj, int gt)
+{
+    int j = 0;
+    for (int k = 1; k < nj; ++k) if (t.jobs[k * SS_JW + 6] <= gt) j = k;      // (first tiles ascend with the job index)
+    return j;
+}
+
+template <int PASS>      // 0: count, 1: gather the swapping stoppers' values by rank, 2: store them at their partners' positions
+__global__ __launch_bounds__(256) void k_top_tiles(int* __restrict__ topAll, uint32_t* keysAll, uint32_t* outAll, uint32_t* __restrict__ scrAll, size_t Ps, size_t scrStride,
+                                                   int half, int level)
+{
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const SsTop t = ss_top(topAll, img, level);
+    const int nj = t.cnt[0], gt = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (gt >= t.cnt[3]) return;
+    const int j = ss_top_job_of(t, nj, gt);
+    const int* q = t.jobs + j * SS_JW;
+    const int lo = q[0] + 1, hi = q[1], tt = gt - q[6], s = q[8];
+    const uint32_t Kp = (uint32_t)q[5];
+    uint32_t* A = keysAll + (size_t)img * Ps;
+    uint32_t* PL = scrAll + (size_t)img * scrStride + q[6] + j;
+    uint32_t* GR = PL + half;
+    const int pos = lo + 64 * tt + lane;
+    const bool v = pos < hi;
+    if (PASS == 0) {
+        const uint32_t e = v ? A[pos] : 0xffffffffu;
+        const unsigned long long mL = wave_vote(v && ssK(e) >= Kp), mR = wave_vote(v && ssK(e) <= Kp);
+        if (lane == 0) { PL[tt + 1] = (uint32_t)__popcll(mL); GR[tt] = (uint32_t)__popcll(mR); }
+        return;
+    }
+    const int nl0 = (int)PL[tt], nr0 = (int)GR[tt + 1];
+    if (nl0 >= s && nr0 >= s) return;
+    const uint32_t e = v ? A[pos] : 0xffffffffu;
+    const bool isL = v && ssK(e) >= Kp, isR = v && ssK(e) <= Kp;
+    const unsigned long long mL = wave_vote(isL), mR = wave_vote(isR);
+    const int rl = nl0 + wave_rank_below(mL), rr = nr0 + __popcll((mR >> lane) >> 1);
+    // values by rank in the seed list's memory under the range: VL upwards from its start, VR downwards from its end (2 s <= length)
+    uint32_t* V = outAll + (size_t)img * Ps;
+    if (PASS == 1) {
+        if (isL && rl < s) V[lo + rl] = e;
+        if (isR && rr < s) V[hi - 1 - rr] = e;
+    } else {
+        if (isL && rl < s) A[pos] = V[hi - 1 - rl];
+        else if (isR && rr < s) A[pos] = V[lo + rr];
+    }
+}
+
+// one workgroup per job: the counts become f (PL[t] = L-stoppers in tiles < t) and g (GR[t] = R-stoppers in tiles >= t); then s and the cut
+__global__ __launch_bounds__(256) void k_top_scan(int* __restrict__ topAll, const uint32_t* __restrict__ keysAll, uint32_t* __restrict__ scrAll, size_t Ps, size_t scrStride,
+                                                  int half, int level)
+{
+    constexpr int NT = 256;
+    __shared__ int s_red[2 * NT];
+    const int img = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SsTop t = ss_top(topAll, img, level);
+    if (j >= t.cnt[0]) return;
+    int* q = t.jobs + j * SS_JW;
+    const int lo = q[0] + 1, hi = q[1], T = q[7];
+    const uint32_t Kp = (uint32_t)q[5];
+    const uint32_t* A = keysAll + (size_t)img * Ps;
+    uint32_t* PL = scrAll + (size_t)img * scrStride + q[6] + j;
+    uint32_t* GR = PL + half;
+    const int C = (T + NT - 1) / NT, c0 = min(tid * C, T), c1 = min(c0 + C, T);
+    {
+        int sl = 0, sr = 0;
+        for (int x = c0; x < c1; ++x) { sl += (int)PL[x + 1]; sr += (int)GR[x]; }
+        s_red[tid] = sl; s_red[NT + tid] = sr;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        int accL = 0, accR = 0;
+        for (int b = 0; b < NT / 64; ++b) {                   // prefix over the threads' chunk sums (left to right) and suffix (right to left)
+            const int i = b * 64 + lane, k = (NT / 64 - 1 - b) * 64 + (63 - lane);
+            const int vl = s_red[i], vr = s_red[NT + k];
+            int pl = vl, pr = vr;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int xl = __shfl_up(pl, o), xr = __shfl_up(pr, o); if (lane >= o) { pl += xl; pr += xr; } }
+            const int totL = __shfl(pl, 63), totR = __shfl(pr, 63);
+            s_red[i] = accL + pl - vl;
+            s_red[NT + k] = accR + pr - vr;
+            accL += totL; accR += totR;
+        }
+    }
+    __syncthreads();
+    {
+        int run = s_red[tid];
+        if (tid == 0) PL[0] = 0;
+        for (int x = c0; x < c1; ++x) { run += (int)PL[x + 1]; PL[x + 1] = (uint32_t)run; }
+        run = s_red[NT + tid];
+        for (int x = c1 - 1; x >= c0; --x) { run += (int)GR[x]; GR[x] = (uint32_t)run; }
+        if (tid == 0) GR[T] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wv != 0) return;
+    // the crossing: the first boundary tb with f(tb) >= g(tb); s = max min(f, g) over the positions of tile tb - 1 and its two boundaries
+    int a = 0, b = T;                                         // f(0) = 0 <= g(0); f(T) = NL >= 0 = g(T)
+    while (a < b) { const int m = (a + b) >> 1; if (PL[m] >= GR[m]) b = m; else a = m + 1; }
+    const int tb = a;
+    int s = (int)min(PL[tb], GR[tb]);
+    if (tb > 0) {
+        const int u = tb - 1, pos = lo + 64 * u + lane;
+        const bool v = pos < hi;
+        const uint32_t e = v ? A[pos] : 0xffffffffu;
+        const unsigned long long mL = wave_vote(v && ssK(e) >= Kp), mR = wave_vote(v && ssK(e) <= Kp);
+        const int f = (int)PL[u] + wave_rank_below(mL);                                     // L-stoppers left of this position
+        const int gq = (int)GR[u + 1] + __popcll(mR >> lane);                               // R-stoppers at or right of it
+        int best = min(f, gq);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+        s = max(s, best);
+    }
+    // cut = min(L(s), R(s - 1)) over the ones that exist, else hi
+    const int NL = (int)PL[T], NR = (int)GR[0];
+    int cut = hi;
+    if (s < NL) {                                             // L(s): tile x with PL[x] <= s < PL[x + 1]
+        int x = 0, y = T - 1;
+        while (x < y) { const int m = (x + y + 1) >> 1; if ((int)PL[m] <= s) x = m; else y = m - 1; }
+        const int pos = lo + 64 * x + lane;
+        const bool v = pos < hi;
+        const uint32_t e = v ? A[pos] : 0xffffffffu;
+        const unsigned long long mL = wave_vote(v && ssK(e) >= Kp);
+        const unsigned long long hit = wave_vote(v && ssK(e) >= Kp && (int)PL[x] + wave_rank_below(mL) == s);
+        if (hit) cut = min(cut, lo + 64 * x + (int)__builtin_ctzll(hit));
+    }
+    if (s >= 1 && s - 1 < NR) {                               // R(s - 1): tile x with GR[x + 1] <= s - 1 < GR[x]
+        int x = 0, y = T - 1;
+        while (x < y) { const int m = (x + y) >> 1; if ((int)GR[m + 1] <= s - 1) y = m; else x = m + 1; }
+        const int pos = lo + 64 * x + lane;
+        const bool v = pos < hi;
+        const uint32_t e = v ? A[pos] : 0xffffffffu;
+        const unsigned long long mR = wave_vote(v && ssK(e) <= Kp);
+        const unsigned long long hit = wave_vote(v && ssK(e) <= Kp && (int)GR[x + 1] + __popcll((mR >> lane) >> 1) == s - 1);
+        if (hit) cut = min(cut, lo + 64 * x + (int)__builtin_ctzll(hit));
+    }
+    if (lane == 0) { q[8] = s; q[9] = cut; }
+}
+
+// children of every job: [cut, last) with K >= Kp, [first, cut) with K <= Kp (the pivot sits at first)
+__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topAll, int level, int* __restrict__ status)
+{
+    __shared__ int s_next, s_fin;
+    const int img = blockIdx.x, j = threadIdx.x;
+    const SsTop t = ss_top(topAll, img, level);
+    const int nj = t.cnt[0];
+    if (j == 0) { s_next = 0; s_fin = t.cnt[2]; }
+    __syncthreads();
+    if (j < nj) {
+        const int* q = t.jobs + j * SS_JW;
+        const int first = q[0], last = q[1], depth = q[2], cut = q[9];
+        const uint32_t lb = (uint32_t)q[3], ub = (uint32_t)q[4], Kp = (uint32_t)q[5], Kthr = (uint32_t)t.cnt[4];
+        const bool lastLevel = level == SS_TOP_LEVELS - 1;
+        ss_top_child(t, &s_next, &s_fin, cut, last, depth, max(lb, Kp), ub, Kthr, lastLevel, status);
+        ss_top_child(t, &s_next, &s_fin, first, cut, depth, lb, min(ub, Kp), Kthr, lastLevel, status);
+    }
+    __syncthreads();
+    if (j == 0) { t.cnt[0] = s_next; t.cnt[2] = min(s_fin, SS_TOP_FINAL); t.cnt[3] = 0; }
+}
+
+int lsd_seedsort_top_words() { return SS_TOP_WORDS; }
+
+static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
+{
+    const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
+    const int maxTiles = n / 64 + SS_TOP_JOBS + 2, half = maxTiles + SS_TOP_JOBS + 2;
+    const size_t stride = std::max((size_t)b.nChunks * 32, (size_t)2 * g.Ps);
+    if ((size_t)2 * half > stride) return OLF_ERR_CAPACITY;
+    hipLaunchKernelGGL(k_top_init, dim3(n_images), dim3(64), 0, s, b.geom, b.topBuf, b.maxN, nOverride, kthrOverride, depthOverride, b.status);
+    if (n < SS_TOP_MIN) return OLF_OK;       // (the root is a final entry)
+    const dim3 tg((maxTiles + 3) / 4, n_images);
+    for (int level = 0; level < SS_TOP_LEVELS; ++level) {
+        hipLaunchKernelGGL(k_top_pivot, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, b.keysA, (size_t)g.Ps, level);
+        hipLaunchKernelGGL(k_top_tiles<0>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
+        hipLaunchKernelGGL(k_top_scan, dim3(SS_TOP_JOBS, n_images), dim3(256), 0, s, b.topBuf, b.keysA, b.region, (size_t)g.Ps, stride, half, level);
+        hipLaunchKernelGGL(k_top_tiles<1>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
+        hipLaunchKernelGGL(k_top_tiles<2>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
+        hipLaunchKernelGGL(k_top_next, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, level, b.status);
+    }
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 template <int NW, int NEM, int NI>
 static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
@@ -661,8 +954,14 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
     const size_t lds = ((size_t)NW * (4 * 64 * NEM + 2 * 64 * NEM) + 4 + 5 * (NI > 1 ? 64 : 256) + 24) * 4;
     if (lds > 64 * 1024)       // per launch: the attribute belongs to the device the launch goes to
         OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // OLF_SS_TOP=0: the whole recursion inside the per-image workgroup (A/B measurements)
+    static const bool top = [] { const char* e = getenv("OLF_SS_TOP"); return !e || atoi(e) != 0; }();
+    // (few images only: the grids cover every possible tile of every image at every level -- at 128 images the two forms are level, at 1024 the
+    // grid-wide one loses 104 against 73 ms, on a 1080p batch 330 against 102)
+    const bool useTop = top && NI == 1 && b.topBuf && n_images <= 64;
+    if (useTop) { const int rc = launch_seedsort_top(g, b, n_images, s, nOverride, kthrOverride, depthOverride); if (rc != OLF_OK) return rc; }
     hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3((n_images + NI - 1) / NI), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
-                       nOverride, kthrOverride, depthOverride, n_images);
+                       nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (const int*)nullptr);
     return OLF_OK;
 }
 

@@ -133,3 +133,20 @@ def test_std_sort_seed_order_structured_and_noise(oracle):
         gk, gd = ex(images["rings"])
         o = oracle.line_extract(images["rings"], p.line)
         assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), waves
+
+
+def test_sort_paths_by_batch_size(oracle):
+    """the first partitions run as grid-wide kernels for up to 64 images per call and inside the per-image workgroup beyond: 6, 64, 65 and 130
+    images of one size through the line path, every image against the oracle"""
+    w, h, distinct = 480, 320, 13
+    base = synth.stereo_batch(900, 7, w, h)[:distinct]
+    p = oracle.full_params(1000, 300)
+    want = [oracle.line_extract(im, p.line) for im in base]
+    for n in (6, 64, 65, 130):
+        imgs = np.tile(base, (n // distinct + 1, 1, 1))[:n]
+        ex = ola.Lineextractor(300, 0.025, max_images=n)
+        kls, desc, counts = ex.extract_batch(imgs)
+        for i in range(n):
+            o = want[i % distinct]
+            c = int(counts[i])
+            assert c == len(o["kls"]) and np.array_equal(kls[i, :c], o["kls"]) and np.array_equal(desc[i, :c], o["desc"]), (n, i)
