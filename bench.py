@@ -4,7 +4,8 @@
 One "step" = one pass of the whole hot path over one batch of B stereo pairs per GPU, inputs already resident in HBM:
 olf_stereo_frames_dev (ExtractORB x2, ExtractLine x2, ComputeStereoMatches, ComputeStereoMatches_Lines; reference src/Frame.cc:136-221)
 + the frame-to-frame LBD match (match(), src/LineMatcher.cpp:104-132) and the frame-to-frame ORB match against the previous
-frame of the batch.  Workloads (--config): C2 640x480 1000+200, C3 KITTI 1242x375 2000+500 (default: the configuration
+frame of the batch: ORBmatcher::SearchByBoW (src/ORBmatcher.cc:161-290) batched on the device, ComputeBoW included (BASELINE.json config 3;
+--no-bow: a dense kNN stand-in).  Workloads (--config): C2 640x480 1000+200, C3 KITTI 1242x375 2000+500 (default: the configuration
 the metric is quoted on), C4 EuRoC 752x480 1200+500, C5 1920x1080 4000+1000.
 
 Multi-GPU: frames are independent -> every rank processes its own B pairs (weak scaling, no data-path collective).
@@ -13,10 +14,13 @@ batch (csrc/records.hip) and sends it to rank 0 (orb_line_slam_amd/distributed.p
 sends, on a side stream, overlapped with the next step's kernels).  --verify: rank 0 re-runs every other rank's input (same seeds) and
 byte-compares the records it received with its own.
 
-The JSON line also carries: the dominant stage's roofline (algorithmic bytes / HIP-event duration, all stages considered), a measured
-copy-kernel ceiling next to the 8 TB/s specification, host-to-host latency of small batches (1, 8, 128 pairs per call), the PCIe-inclusive
-rate of the double-buffered offline pipeline, and the CPU oracle timed on this box's host cores in two shapes (A: 4 threads per frame, one
-frame at a time, like the reference; B: one frame per core on all cores).
+The JSON line also carries: the roofline of the dominant stage (the one with the largest stand-alone time; algorithmic bytes / HIP-event
+duration of its launch inside the timed region; `traffic` = 2 x FETCH_SIZE + WRITE_SIZE and `valu_issue` = its vector instructions against the
+part's issue rate, both from PMC summaries under profiles/ that carry the hash of the sources they were collected on), `roofline.stages`:
+every stage run alone, a measured copy-kernel ceiling next to the 8 TB/s specification, host-to-host latency of small batches (1, 8, 128
+pairs per call), the PCIe-inclusive rate of the double-buffered offline pipeline, and the CPU oracle timed on this box's host cores in two
+shapes (A: 4 threads per frame, one frame at a time, like the reference, 20 warm-up + 200 timed frames with a per-stage breakdown; B: one
+frame per thread as a thread-count sweep against the box's CPU quota).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29501 bench.py --gpus 8 --steps 5 --warmup 2
