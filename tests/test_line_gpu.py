@@ -372,6 +372,7 @@ def test_line_extract_full_occupancy_batch(oracle):
         c = int(counts[i])
         if c != len(o["kls"]) or not np.array_equal(kls[i, :c], o["kls"]) or not np.array_equal(desc[i, :c], o["desc"]):
             bad.append(i)
+    ex._ctx.close()      # (a context of this size holds > 100 GB: released here, not whenever the collector gets to it)
     assert not bad, (len(bad), bad[:8])
 
 
@@ -404,4 +405,5 @@ def test_stereo_frames_full_batch(oracle):
               and np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64)))
         if not ok:
             bad.append(i)
+    fe.ctx.close()
     assert not bad, (len(bad), bad[:8])
