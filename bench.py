@@ -46,7 +46,7 @@ CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD 
     "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=640),
 }
 STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_fast_cells": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
-                "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow<0>",
+                "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow<0",
                 "lsd_rect": "olf::k_lsd_rect", "line_select_lbd": "olf::k_lbd_rows", "stereo_lines": "olf::k_lines_dist", "match_bf": "olf::k_knn2"}
 
 
@@ -200,6 +200,11 @@ def main():
     ap.add_argument("--seed-order", type=int, choices=(0, 1), default=None, help="convention C.9: order of the LSD seeds inside a gradient bin (default: the library's)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="N>1: nccl = RCCL over xGMI (device buffers); gloo = the same gather staged through host memory (lets 2 ranks share one GPU: the N>1 code path on a 1-GPU box)")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
+    ap.add_argument("--images", default=None, help="recorded stereo sequence instead of synthetic input: a KITTI sequence directory (times.txt, image_0, image_1 -- "
+                    "Examples/PL/PL_stereo_kitti.cc LoadImages), a EuRoC mav0 directory or any directory with left / right image folders (orb_line_slam_amd/sequence.py); "
+                    "the image size comes from the files, the feature counts from --config; fewer pairs than the batch are tiled")
+    ap.add_argument("--sequence", type=int, default=0, metavar="RUN", help="synthetic input as runs of RUN consecutive frames of one scene (frame k of a run = the scene "
+                    "shifted by 2k pixels), so that the frame-to-frame matchers see related frames; 0: independent scenes (SURVEY 8(d)'s generator)")
     args = ap.parse_args()
 
     import torch
@@ -231,6 +236,11 @@ def main():
 
     cfg = CONFIGS[args.config]
     W, H = cfg["w"], cfg["h"]
+    seq = None
+    if args.images:
+        from orb_line_slam_amd.sequence import StereoSequence
+        seq = StereoSequence(args.images, limit=args.pairs or cfg["pairs"])
+        W, H = seq.width, seq.height
     B = args.pairs or cfg["pairs"]
     # the batch lives in HBM (context buffers + outputs, about 62 MB per KITTI pair): shrink it if this GPU has less free memory than the
     # batch needs, and use the same size on every rank
@@ -256,7 +266,24 @@ def main():
     nd = min(args.distinct, B)
 
     def make_input(r):
+        if seq is not None:
+            # every rank reads its own contiguous share of the recording (frame-sharded like SURVEY 8(e)), tiled to B pairs when it is shorter
+            from orb_line_slam_amd.distributed import shard_range
+            lo, hi = shard_range(len(seq), r, world)
+            sub_seq = StereoSequence(left=seq.left[lo:hi] or seq.left[:1], right=seq.right[lo:hi] or seq.right[:1])
+            host = np.concatenate([b for b, _ in sub_seq.batches(B)]).reshape(-1, 2, H, W)
+            reps = (B + len(host) - 1) // len(host)
+            return torch.from_numpy(np.tile(host, (reps, 1, 1, 1))[:B].reshape(2 * B, H, W).copy()).to(dev)
         host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=args.scene)
+        if args.sequence > 1:
+            # runs of consecutive frames: frame k of run j = scene j (both images) shifted by 2k pixels -- related frames for the frame-to-frame matchers
+            R = args.sequence
+            out_h = np.empty((2 * B, H, W), np.uint8)
+            for i in range(B):
+                j, k = (i // R) % nd, i % R
+                out_h[2 * i] = np.roll(host[2 * j], 2 * k, axis=1)
+                out_h[2 * i + 1] = np.roll(host[2 * j + 1], 2 * k, axis=1)
+            return torch.from_numpy(out_h).to(dev)
         # B pairs drawn from the nd distinct ones in a seeded random order (a plain tiling would put identical images at a fixed period,
         # which lines them up with the hardware's round-robin placement of workgroups -- an artefact no real sequence has)
         order = np.random.default_rng(1234 + r).permutation(np.arange(B) % nd) if args.order == "shuffled" else np.arange(B) % nd
@@ -425,7 +452,7 @@ def main():
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
                 pm = json.load(open(f))
                 # (rocprofv3 prints a template kernel as "void olf::name<args>(...)": the summary's keys are that text up to the parenthesis)
-                key = next((k for k in pm["kernels"] if k.replace("void ", "") == STAGE_KERNEL[dom]), None)
+                key = next((k for k in pm["kernels"] if k.replace("void ", "").startswith(STAGE_KERNEL[dom])), None)
                 if pm.get("source_hash") == sh and key:
                     traffic = int(pm["kernels"][key]["bytes_per_image"] * 2 * B)
                     break
@@ -433,30 +460,37 @@ def main():
             traffic = None
         # the same kernel against the part's vector-instruction issue rate: SQ_INSTS_VALU per image (profiles/*_valu_budget.json, same source-hash rule)
         # x images per launch / launch duration, over 256 CUs x 4 SIMDs x one wave64 vector instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-        valu = None
+        valu, valu_step = None, None
         try:
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_budget.json")), reverse=True):
                 vb = json.load(open(f))
-                key = next((k for k in vb["kernels"] if k.replace("void ", "") == STAGE_KERNEL[dom]), None)
+                key = next((k for k in vb["kernels"] if k.replace("void ", "").startswith(STAGE_KERNEL[dom])), None)
                 if vb.get("source_hash") == sh and key:
                     rate = vb["kernels"][key]["valu_per_image"] * 2 * B / (dom_ms * 1e-3) / 1e9
                     valu = {"achieved": round(rate, 1), "peak": 614.4, "unit": "G wave-instructions/s", "frac": round(rate / 614.4, 4),
                             "valu_per_image": int(vb["kernels"][key]["valu_per_image"]), "salu_per_image": int(vb["kernels"][key]["salu_per_image"])}
+                    # the whole step against the same ceiling: every kernel's vector instructions per image x images per step / issue rate = the time the
+                    # step would take if it did nothing but issue them (scalar instructions of the one-wave agents issue in the same slots, DESIGN 3.9:
+                    # the second figure counts them too)
+                    tv = sum(k["valu_per_image"] for k in vb["kernels"].values()); ts = sum(k["salu_per_image"] for k in vb["kernels"].values())
+                    step_ms = dt / args.steps * 1e3
+                    valu_step = {"valu_per_image": int(tv), "salu_per_image": int(ts), "issue_floor_ms": round(tv * 2 * B / 614.4e9 * 1e3, 2),
+                                 "frac": round(tv * 2 * B / 614.4e9 * 1e3 / step_ms, 4), "frac_with_scalar": round((tv + ts) * 2 * B / 614.4e9 * 1e3 / step_ms, 4)}
                     break
         except Exception:
             valu = None
         out = {
             "metric": f"stereo frames/s extract+match (ORB+LBD), {'KITTI ' if args.config == 'C3' else ''}{W}x{H}", "value": round(fps, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": ("recorded: " + os.path.basename(os.path.normpath(args.images))) if seq is not None else "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} stereo, {cfg['nf']} ORB + {cfg['nl']} LBD per image, extract + stereo point/line match + "
                                    f"f2f LBD match + " + ("SearchByBoW vs the previous frame (synthetic k=10 L=6 vocabulary, ComputeBoW included)" if voc is not None else "f2f dense ORB kNN match"), "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
-                       "distinct_pairs": nd, "order": args.order, "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
+                       "distinct_pairs": (len(seq) if seq is not None else nd), "order": ("recorded" if seq is not None else f"runs of {args.sequence}" if args.sequence > 1 else args.order), "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
                        "mean_line_pixels": round(mean_len, 1), "source_hash": sh},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "stage": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                          "avg_launch_ms": round(dom_ms, 4), "path_bytes_per_pair": int(ab["pair"]),
-                         "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6), "valu_issue": valu},
+                         "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6), "valu_issue": valu, "valu_issue_step": valu_step},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
         }
         if alone:
@@ -499,7 +533,11 @@ def main():
                 out["pair_latency_ms"] = {"error": str(e)}
             try:
                 from orb_line_slam_amd.pipeline import pcie_inclusive_rate
-                out["pcie_inclusive"] = pcie_inclusive_rate(params, W, H, pairs=min(B, 1024), batches=4)
+                # the second headline: host images in, host results out, at the full batch, steady state over 10 batches (a reader that decodes into the
+                # pinned staging buffer); and the convenience shape that copies pageable arrays into it first
+                out["pcie_inclusive"] = pcie_inclusive_rate(params, W, H, pairs=B, batches=10, producer="pinned")
+                out["pcie_inclusive"]["frac_of_value"] = round(out["pcie_inclusive"]["value"] / out["value"], 4)
+                out["pcie_inclusive"]["pageable_input"] = pcie_inclusive_rate(params, W, H, pairs=B, batches=4, producer="pageable")["value"]
             except Exception as e:
                 out["pcie_inclusive"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:

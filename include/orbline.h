@@ -181,6 +181,9 @@ int olf_debug_lsd_pool(olf_ctx* ctx, int pool_chunks);
 /* debug/test: the LSD agent's unscaled exact float division against IEEE division on blocks*256*per_thread pseudo-random operand pairs
  * from its operand range; *mismatches = number of quotients that differ in any bit (must be 0). */
 int olf_debug_fdiv_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread, uint64_t* mismatches);
+/* debug/test: the lean sqrt(n / 4.0) of the LSD key kernel (ll_angle's gradient norm; lsd_device.hpp sqrt_quarter) against the compiler's IEEE
+ * sqrt on every integer n in [0, count); *mismatches = number of results that differ in any bit (must be 0). */
+int olf_debug_sqrtq_sweep(olf_ctx* ctx, int count, uint64_t* mismatches);
 
 /* ---- Frame::ComputeStereoMatches (src/Frame.cc:702-876) ------------------------------------- */
 /* Stereo point matching for n_pairs pairs whose ORB features (images 2p = left, 2p+1 = right) came from

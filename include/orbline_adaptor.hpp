@@ -29,6 +29,18 @@ static_assert(sizeof(cv::line_descriptor::KeyLine) == sizeof(olf_keyline), "KeyL
 
 namespace ORB_SLAM2 {
 
+// Parameters the reference reads from its Config singleton inside the functions mirrored here (src/Config.cpp:45,26-160,215-216).  Inside the reference
+// tree define ORBLINE_CONFIG to the reference's class before including this header (it has the same static accessors): #define ORBLINE_CONFIG Config
+struct AdaptorConfig {
+    static bool& hasLines() { static bool v = true; return v; }            // src/LineExtractor.cc:37, src/Frame.cc:203
+    static bool& bestLRMatches() { static bool v = true; return v; }
+    static double& minRatio12P() { static double v = 0.75; return v; }
+    static double& lineSimTh() { static double v = 0.75; return v; }
+};
+#ifndef ORBLINE_CONFIG
+#define ORBLINE_CONFIG AdaptorConfig
+#endif
+
 namespace olf_detail {
 inline void check(int rc, const char* where)
 {
@@ -159,7 +171,7 @@ public:
     void extract(const uint8_t* image, int w, int h, size_t stride, std::vector<olf_keyline>& keylines, std::vector<uint8_t>& descriptors)
     {
         keylines.clear(); descriptors.clear();
-        if (bFLD || !image) return;                // src/LineExtractor.cc:68
+        if (!ORBLINE_CONFIG::hasLines() || bFLD || !image) return;      // src/LineExtractor.cc:37 (Config::hasLines()), :68 (bFLD)
         olf_ctx* x = c.get(w, h);
         const int cap = olf_line_capacity(x);
         keylines.resize(cap); descriptors.resize((size_t)cap * OLF_DESC_BYTES);
@@ -170,6 +182,8 @@ public:
 #ifdef ORBLINE_WITH_OPENCV
     void operator()(const cv::Mat& image, const cv::Mat& /*mask*/, std::vector<cv::line_descriptor::KeyLine>& keylines, cv::Mat& descriptors_line)
     {
+        keylines.clear();
+        if (!ORBLINE_CONFIG::hasLines() || bFLD) return;      // the reference returns with descriptors_line untouched (src/LineExtractor.cc:35-37,68)
         if (image.depth() != 0) throw std::runtime_error("Error, depth image!= 0");   // LSDDetector_custom.cpp:236-237
         std::vector<olf_keyline> k; std::vector<uint8_t> d;
         extract(image.data, image.cols, image.rows, image.step, k, d);

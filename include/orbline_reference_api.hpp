@@ -34,16 +34,7 @@
 
 namespace ORB_SLAM2 {
 
-// Parameters the reference reads from its Config singleton inside these functions (src/Config.cpp:45,26-160).  Inside the reference tree
-// define ORBLINE_CONFIG to the reference's class (it has the same static accessors): #define ORBLINE_CONFIG Config
-struct AdaptorConfig {
-    static bool& bestLRMatches() { static bool v = true; return v; }
-    static double& minRatio12P() { static double v = 0.75; return v; }
-    static double& lineSimTh() { static double v = 0.75; return v; }
-};
-#ifndef ORBLINE_CONFIG
-#define ORBLINE_CONFIG AdaptorConfig
-#endif
+// (AdaptorConfig / ORBLINE_CONFIG -- the Config singleton's accessors read here -- are defined in orbline_adaptor.hpp)
 
 namespace olf_detail {
 
@@ -611,6 +602,9 @@ int matchGrid(const std::vector<line_2d>& lines1, const MatT& desc1, const GridS
 // mvKeysRight, mDescriptors, mDescriptorsRight, mvuRight, mvDepth, mvKeys_Line, mvKeysRight_Line, mDescriptors_Line, mDescriptorsRight_Line,
 // mvDisparity_l, mvle_l, N, N_l of `F`.  The parameters come from the frame's own extractor objects and camera members; the context is
 // the left ORB extractor's (one per image size).  Throws like the reference when the two images differ in size (:145-146).
+// Config::hasLines() == false (:37 of LineExtractor.cc, :203): no line is extracted or matched -- the key line members come back empty, N_l = 0, and the
+// call runs the point half only.  A frame without key points returns like the reference's constructor does (:176-177): N = 0, N_l = the left key lines
+// as extracted, and none of the stereo members (mvuRight, mvDepth, mvDisparity_l, mvle_l) is touched.
 template <class FrameT, class MatT>
 void StereoFrameFeatures(FrameT& F, const MatT& imLeft, const MatT& imRight, const olf_stereo_params* stereo = nullptr)
 {
@@ -635,8 +629,12 @@ void StereoFrameFeatures(FrameT& F, const MatT& imLeft, const MatT& imRight, con
     std::vector<int32_t> lm(lcap);
     std::vector<double> lle((size_t)3 * lcap);
     int32_t n[2] = {0, 0}, nl[2] = {0, 0};
-    olf_frame_buffers o = {k.data(), d.data(), n, ur.data(), dep.data(), kl.data(), ld.data(), nl, lm.data(), ldisp.data(), lle.data()};
-    olf_detail::check(olf_stereo_frames(ctx, pair.data(), 1, &o), "olf_stereo_frames");
+    const bool lines = ORBLINE_CONFIG::hasLines();
+    if (lines) {
+        olf_frame_buffers o = {k.data(), d.data(), n, ur.data(), dep.data(), kl.data(), ld.data(), nl, lm.data(), ldisp.data(), lle.data()};
+        olf_detail::check(olf_stereo_frames(ctx, pair.data(), 1, &o), "olf_stereo_frames");
+    } else
+        olf_detail::check(olf_stereo_points(ctx, pair.data(), 1, k.data(), d.data(), n, ur.data(), dep.data()), "olf_stereo_points");
     typedef typename std::remove_reference<decltype(F.mvKeys[0])>::type KP;
     typedef typename std::remove_reference<decltype(F.mvKeys_Line[0])>::type KL;
     static_assert(sizeof(KP) == sizeof(olf_keypoint) && sizeof(KL) == sizeof(olf_keyline), "cv::KeyPoint / KeyLine layout");
@@ -645,10 +643,12 @@ void StereoFrameFeatures(FrameT& F, const MatT& imLeft, const MatT& imRight, con
     auto fill_mat = [&](MatT& m, const uint8_t* src, int cnt) { m.create(cnt, 32, 0 /* CV_8U */); if (cnt) std::memcpy(m.data, src, (size_t)cnt * 32); };
     fill_kp(F.mvKeys, k.data(), n[0]); fill_kp(F.mvKeysRight, k.data() + cap, n[1]);
     fill_mat(F.mDescriptors, d.data(), n[0]); fill_mat(F.mDescriptorsRight, d.data() + (size_t)cap * 32, n[1]);
-    F.mvuRight.assign(ur.begin(), ur.begin() + n[0]); F.mvDepth.assign(dep.begin(), dep.begin() + n[0]);
     fill_kl(F.mvKeys_Line, kl.data(), nl[0]); fill_kl(F.mvKeysRight_Line, kl.data() + lcap, nl[1]);
-    fill_mat(F.mDescriptors_Line, ld.data(), nl[0]); fill_mat(F.mDescriptorsRight_Line, ld.data() + (size_t)lcap * 32, nl[1]);
+    if (lines) { fill_mat(F.mDescriptors_Line, ld.data(), nl[0]); fill_mat(F.mDescriptorsRight_Line, ld.data() + (size_t)lcap * 32, nl[1]); }
     F.N = n[0]; F.N_l = nl[0];
+    if (n[0] == 0) return;                                                  // "if(mvKeys.empty()) return;" (src/Frame.cc:176-177)
+    F.mvuRight.assign(ur.begin(), ur.begin() + n[0]); F.mvDepth.assign(dep.begin(), dep.begin() + n[0]);
+    if (!lines) return;                                                     // (src/Frame.cc:203)
     F.mvDisparity_l.resize(nl[0]); F.mvle_l.resize(nl[0]);
     for (int i = 0; i < nl[0]; ++i) {
         F.mvDisparity_l[i] = std::make_pair(ldisp[2 * i], ldisp[2 * i + 1]);

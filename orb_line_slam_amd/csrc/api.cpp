@@ -275,11 +275,11 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
     A(l.topBuf, n * (size_t)lsd_seedsort_top_words()); A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
     // chunk pool of the multi-wave growth: every pixel in a list once (Ps / 32) plus one partly filled chunk per logged region and ROB slot;
-    // Ps / 16 chunks fill exactly the 2 * Ps words the one-wave agent's log needs anyway.  An image that still runs out is grown again by
-    // the one-wave agent (launch_lsd_grow)
-    l.nChunks = std::max(1024 + lg.Ps / 32 + 64, lg.Ps / 16);
+    // at least the 2 * Ps words the one-wave agent's log needs (LineGeom::regionStride, one stride for both formats).  An image that still runs out is
+    // grown again by the one-wave agent (launch_lsd_grow)
+    l.nChunks = lg.regionStride / 32;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
-    A(l.region, n * std::max((size_t)l.nChunks * 32, (size_t)2 * lg.Ps)); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    A(l.region, n * (size_t)lg.regionStride); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
@@ -586,6 +586,18 @@ int olf_debug_fdiv_sweep(olf_ctx* c, uint64_t seed, int blocks, int per_thread, 
     OLF_TRY(scratch_get(c, 1, 64, &st));
     OLF_HIP_CHECK(hipMemsetAsync(st, 0, 8, c->stream));
     OLF_TRY(launch_fdiv_sweep((unsigned long long)seed, blocks, per_thread, (unsigned long long*)st, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(mismatches, st, 8, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
+int olf_debug_sqrtq_sweep(olf_ctx* c, int count, uint64_t* mismatches)
+{
+    if (!c || !mismatches || count < 1) { set_error("olf_debug_sqrtq_sweep: bad argument"); return OLF_ERR_INVALID; }
+    void* st = nullptr;
+    OLF_TRY(scratch_get(c, 1, 64, &st));
+    OLF_HIP_CHECK(hipMemsetAsync(st, 0, 8, c->stream));
+    OLF_TRY(launch_sqrtq_sweep(count, (unsigned long long*)st, c->stream));
     OLF_HIP_CHECK(hipMemcpyAsync(mismatches, st, 8, hipMemcpyDeviceToHost, c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return OLF_OK;

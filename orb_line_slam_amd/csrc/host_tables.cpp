@@ -212,6 +212,17 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.Ws = cv_round_d(W * p.lsd_scale); g.Hs = cv_round_d(H * p.lsd_scale);
     g.pitchS = (g.Ws + 63) & ~63;
     g.Ps = g.Ws * g.Hs;
+    // chunk pool of the multi-wave growth: every pixel in a list once (Ps / 32) plus one partly filled chunk per logged region and ROB slot; at least the
+    // 2 * Ps words the one-wave agent's (pixel, gradient word) log needs -- one stride for both formats (see LineGeom::regionStride)
+    {   // division of a pixel index (< 2^22) by Ws as a multiply-high: p = max(32, 22 + ceil(log2 Ws)), M = ceil(2^p / Ws); the error term e = M Ws - 2^p < Ws
+        // satisfies idx * e < 2^22 * 2^ceil(log2 Ws) <= 2^p, which is the condition for floor(idx M / 2^p) == idx / Ws
+        int k = 0; while ((1 << k) < g.Ws) ++k;
+        const int p = std::max(32, 22 + k);
+        const unsigned long long M = ((1ull << p) + (unsigned long long)g.Ws - 1) / (unsigned long long)g.Ws;
+        g.divWsM = (uint32_t)M; g.divWsS = p - 32;
+    }
+    g.alignDeg = p.lsd_ang_th < 90 ? (float)(180.0 - p.lsd_ang_th) : -1.f;      // (tolerances of 90 degrees and more: the folded form does not hold, k_lsd_keys decides in double)
+    g.regionStride = std::max(1024 + g.Ps / 32 + 64, (2 * g.Ps + 31) / 32) * 32;
     if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
     g.prec = kPI * p.lsd_ang_th / 180;
     {   // 2*pi - prec in 64-bit-mantissa arithmetic is exact (two doubles three binades apart), then rounded up to a double

@@ -46,6 +46,10 @@ struct LineGeom {
     int refine;                // lsd_refine: 0 LSD_REFINE_NONE, 1 LSD_REFINE_STD (density check, second growth, reduce_region_radius inside the agent)
     double densityTh;          // lsd_density_th
     double logNT, logEps, pProb;   // LSD_REFINE_ADV: 5 (log10 Ws + log10 Hs) / 2 + log10 11 (host libm), lsd_log_eps, ang_th / 180
+    uint32_t divWsM; int divWsS; // idx / Ws for 0 <= idx < 2^22 without a division: __umulhi(idx, divWsM) >> divWsS (exact: host_tables.cpp)
+    float alignDeg;            // 180 - lsd_ang_th as a float: two level-line angles (degrees) a, b are aligned <=> | |a - b| - 180 | >= alignDeg (decided exactly in double near the boundary)
+    int regionStride;          // 32-bit words per image of LineDeviceBufs::region: ONE stride for both pixel-list formats (chunk chains of the multi-wave growth: regionStride / 32
+                               // chunks; contiguous (pixel, gradient word) log of the one-wave agent: 2 * Ps words), so a fallen-back image never lands in a neighbour's chunks
     int resizeExact;           // convention C.10: the upsampling is cv::resize INTER_LINEAR_EXACT (8-bit coefficients in rx / ry)
 };
 
@@ -102,6 +106,7 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
                       const LineGeom& g, int which, int n_images, hipStream_t s);
 int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
+int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
 int lsd_seedsort_top_words();      // ints per image of LineDeviceBufs::topBuf
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);

@@ -217,11 +217,11 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         uint32_t* kall = keys + (size_t)img * Ps;
         for (int li = threadIdx.x; li < LG_CHUNK && c0 + li < Ps; li += KEYS_THREADS) {
             const int idx = c0 + li;
-            const int y = idx / Ws, x = idx - y * Ws;
+            const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
             if (x < Ws - 1 && y < Hs - 1) {
                 const uint32_t p = grad[idx];
                 const int gx = unpack_gx(p), gy = unpack_gy(p);
-                const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const double norm = sqrt_quarter(gx * gx + gy * gy);
                 const int bin = (int)(norm * bin_coef);
                 kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
             }
@@ -236,22 +236,40 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         const int idx = c0 + li;
         const uint32_t p = grad[idx];
         const int gx = unpack_gx(p), gy = unpack_gy(p);
-        const double norm = sqrt((double)(gx * gx + gy * gy) / 4.0);
+        const double norm = sqrt_quarter(gx * gx + gy * gy);
         const int bin = (int)(norm * bin_coef);
-        const int y = idx / Ws, x = idx - y * Ws;
-        const double a0 = d_mul((double)s_deg[idx - lo], kDegToRads);
+        const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
+        const float deg0 = s_deg[idx - lo];
+        // isaligned() on two angles in degrees a, b: with t = | |a - b| - 180 | it is t >= 180 - ang_th (|a - b| <= ang_th, or >= 360 - ang_th after the
+        // wrap); an undefined neighbour (-1000) gives t > 800.  Decided in float wherever t is farther than 10^-3 degrees from the boundary (the
+        // float differences are good to 10^-4, the reference's double radians to 10^-13); the exact double form only for the rest
         bool iso = true;
+        float margin = 1.0f;
+        const bool xl = x > 0, xr = x < Ws - 1, yu = y > 0, yd = y < Hs - 1;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             if (q == 4) continue;
             const int dx = (q % 3) - 1, dy = (q / 3) - 1;
-            if (x + dx < 0 || x + dx >= Ws || y + dy < 0 || y + dy >= Hs) continue;
+            const bool inb = (dx < 0 ? xl : dx > 0 ? xr : true) && (dy < 0 ? yu : dy > 0 ? yd : true);
             const float dn = s_deg[idx - lo + dy * Ws + dx];
-            if (dn == kDegUndef) continue;
-            double n_theta = d_sub(a0, d_mul((double)dn, kDegToRads));
-            if (n_theta < 0) n_theta = -n_theta;
-            if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
-            if (n_theta <= g.prec) iso = false;
+            const float t = fabsf(f_sub(fabsf(f_sub(deg0, dn)), 180.f));
+            if (inb) { if (t >= g.alignDeg && t <= 181.f) iso = false; margin = fminf(margin, fabsf(f_sub(t, g.alignDeg))); }
+        }
+        if (margin < 1e-3f || g.alignDeg < 0.f) {
+            const double a0 = d_mul((double)deg0, kDegToRads);
+            iso = true;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                if (q == 4) continue;
+                const int dx = (q % 3) - 1, dy = (q / 3) - 1;
+                if (x + dx < 0 || x + dx >= Ws || y + dy < 0 || y + dy >= Hs) continue;
+                const float dn = s_deg[idx - lo + dy * Ws + dx];
+                if (dn == kDegUndef) continue;
+                double n_theta = d_sub(a0, d_mul((double)dn, kDegToRads));
+                if (n_theta < 0) n_theta = -n_theta;
+                if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
+                if (n_theta <= g.prec) iso = false;
+            }
         }
         if (iso) grad[idx] = p | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
@@ -353,6 +371,22 @@ __global__ __launch_bounds__(256) void k_fdiv_sweep(unsigned long long seed, int
         bad += __float_as_uint(q0) != __float_as_uint(q1);
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// debug / test: sqrt_quarter against the compiler's sqrt on every n in [0, count)
+__global__ __launch_bounds__(256) void k_sqrtq_sweep(int count, unsigned long long* __restrict__ mismatches)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= count) return;
+    const double a = sqrt((double)n / 4.0), b = sqrt_quarter(n);
+    if (__double_as_longlong(a) != __double_as_longlong(b)) atomicAdd(mismatches, 1ull);
+}
+
+int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sqrtq_sweep, dim3((count + 255) / 256), dim3(256), 0, s, count, d_mismatches);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
 }
 
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s)
@@ -632,7 +666,11 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // REFINE (lsd_refine = LSD_REFINE_STD): every region of minRegSize pixels is fitted and, if its density is below the threshold, un-used, grown again
 // under the tolerance tau derived from its angles, and shrunk (reduce_region_radius) -- all inside the seed loop, because the pixels it gives back are
 // seeds and neighbours of later regions.  The agent then writes the segment candidates itself (candAll) and k_lsd_rect is not launched.
-template <int REFINE>      // 0: LSD_REFINE_NONE, 1: STD, 2: ADV
+// PF (REFINE = 0 only; bits, A/B through OLF_GROW_PF): 1 = the seed windows as a software pipeline (keys two windows ahead, the windows' gradient words one
+// window ahead; a flush of the pending table first folds the table into the seed masks, so no window is ever gathered twice), 2 = the rows above and
+// below every live seed of a window are requested when the window starts (a region's first 3x3 gather then finds them in the cache instead of in HBM),
+// 4 = the row beyond every candidate of a growth step is requested beside its table entry (the next step's gather).
+template <int REFINE, int PF>      // REFINE 0: LSD_REFINE_NONE, 1: STD, 2: ADV
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
@@ -651,7 +689,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
     // the pixel log: (x | y << 16, gradient word) per pixel -- k_lsd_rect needs the gradient norm of every region pixel and reads it from here
     // instead of gathering the word again
-    uint2* reg = reinterpret_cast<uint2*>(regionAll) + (size_t)img * g.Ps;
+    uint2* reg = reinterpret_cast<uint2*>(regionAll + (size_t)img * g.regionStride);
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec, precWrap = g.precWrap;
@@ -662,7 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
     long long st_mem = 0, st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
-    long long st_win = 0, st_seedl = 0, st_regl = 0, st_acc = 0, st_isos = 0, st_logged = 0;
+    long long st_win = 0, st_seedl = 0, st_regl = 0, st_acc = 0, st_isos = 0, st_logged = 0, st_winLive = 0, st_first = 0, st_cand1 = 0, st_acc1 = 0;
 #endif
 #ifdef OLF_TIMING2
     long long p_ring = 0, p_gather = 0, p_table = 0, p_chain = 0, p_commit = 0, p_n = 0, ps;
@@ -679,26 +717,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #else
 #define ST_FLUSH
 #endif
-#define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
+    constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4);
+// PIPE: what the table holds is folded into the seed masks of the current and of the next window before it is cleared -- the masks then stay complete
+// (a window's words as loaded + every pixel marked since), and a window is never gathered again
+#define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; \
+                          if (PIPE) { mask &= ~wave_vote(s_pend[addr & (PEND - 1)] == addr); deadN |= wave_vote(s_pend[addrN & (PEND - 1)] == addrN); } \
+                          __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
 #define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
                              if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __builtin_amdgcn_wave_barrier(); } while (0)
 
     // The seed windows are a chain of dependent loads (key -> gradient word -> table entries); the key of the next window is fetched one
     // window ahead and the table entries of every growable seed of a window at its start, so a region start waits for neither.
+    // PIPE: keyNext holds the keys of the window after next, (addrN, wN) the addresses and gradient words of the next window (requested one window
+    // ahead: the 64 spatially random words of a window are a full memory round trip), deadN its seeds found in the pending table at a flush since
     uint32_t keyNext = lane < nkeys ? keys[lane] : 0u;
+    int addrN = 0;
+    uint32_t wN = kUsed;
+    unsigned long long deadN = 0;
+    if (PIPE) {
+        addrN = lane < nkeys ? (int)(keyNext & 0x3fffffu) : 0;
+        wN = lane < nkeys ? grad[addrN] : kUsed;
+        keyNext = 64 + lane < nkeys ? keys[64 + lane] : 0u;
+    }
     for (int base = 0; base < nkeys; base += 64) {
         const bool valid = base + lane < nkeys;
-        const int addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
-        keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
-        uint32_t wseed = valid ? grad[addr] : kUsed;
+        int addr;
+        uint32_t wseed;
+        unsigned long long dead = 0;
+        if (PIPE) {
+            addr = addrN; wseed = wN; dead = deadN;
+            const bool validN = base + 64 + lane < nkeys;
+            addrN = validN ? (int)(keyNext & 0x3fffffu) : 0;
+            // (the new requests go out BEHIND the wait for the old ones: tied to the arrival of this window's words, or the compiler hoists the key
+            // load above that wait and every window waits for a request it has just made)
+            int kidx = base + 128 + lane;
+            asm volatile("" : "+v"(kidx), "+v"(addrN) : "v"(wseed));
+            wN = validN ? grad[addrN] : kUsed;
+            keyNext = kidx < nkeys ? keys[kidx] : 0u;
+            deadN = 0;
+        } else {
+            addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
+            keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
+            wseed = valid ? grad[addr] : kUsed;
+        }
         int maskEpoch = flushEpoch;      // the window's USED bits as loaded here are complete up to this flush count
         const bool isoSeed = (wseed & kIso) != 0;
 #ifdef OLF_STATS
         ++st_win; st_seedl += __popcll(wave_vote(valid)); st_isos += __popcll(wave_vote(valid && isoSeed));
 #endif
         // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; ll_angle's seed loop skips them)
-        unsigned long long mask = wave_vote(valid && !(wseed & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr);
+        unsigned long long mask = wave_vote(valid && !(wseed & (kUsed | kNotDef)) && s_pend[addr & (PEND - 1)] != addr) & ~dead;
+        // PFSEED: a region's first step gathers the 3x3 around its seed; the seed's own row came with the window, the rows above and below are
+        // requested here for every live seed, so that (all but the window's first region) find them in the cache
+#ifdef OLF_STATS
+        if (mask) ++st_winLive;
+#endif
+        uint32_t pfA = 0, pfB = 0;
+        if (PFSEED && wave_bit(mask) && !isoSeed) { pfA = grad[max(addr - Ws, 0)]; pfB = grad[min(addr + Ws, g.Ps - 1)]; }
         // region_grow starts at the seed's own angle and at sums (cos, sin) of it (double argument, unlike the added pixels): both
         // are per-(gx, gy) table entries
         double seedAng = 0;
@@ -758,6 +834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #endif
                 const int nb = min(8, n - i);
                 const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);      // 8 FIFO entries x 8 neighbours (k = 4 is the entry's own pixel)
+                const int pfOff = (k / 3 - 1) * Ws;
 #ifdef OLF_STATS
                 ++st_iters; if (n - i >= 14) ++st_deep1; if (n - i >= 21) ++st_deep2; if (n - i > RING) ++st_mem;
 #endif
@@ -784,9 +861,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 unsigned long long cm = inImg & wave_vote(!(pw & (kUsed | kNotDef))) & wave_vote(pendv != a);
                 double ang = 0, cs = 0, sn = 0;
                 PSTAMP(p_gather);
+                uint32_t pfC = 0;
                 if (wave_bit(cm)) {
                     const AngEnt* t = ent + (pw & 0x3fffffu);      // one 32-byte sector per candidate
                     cs = t->cs; sn = t->sn; ang = t->ang;
+                    // PFCAND: an accepted candidate is a FIFO entry of the next step, whose gather reaches one row further out (issued behind the table
+                    // loads: vector memory returns in order)
+                    if (PFCAND) { const int ar = a + pfOff; if ((unsigned)ar < (unsigned)g.Ps && pfOff != 0) pfC = grad[ar]; }
                 }
                 // candidates in lane order = the reference's visiting order.  Under a fixed reg_angle every lane tests
                 // its own candidate at once; the first aligned one is accepted (everything before it is rejected under
@@ -794,7 +875,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 PSTAMP(p_table);
                 unsigned long long acc = 0;
 #ifdef OLF_STATS
-                st_cand += __popcll(cm);
+                st_cand += __popcll(cm); if (i == 0) { ++st_first; st_cand1 += __popcll(cm); }
 #endif
                 const int n0 = n;
                 while (cm) {
@@ -874,6 +955,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 // memory operations in flight, so the next iteration's ring read and address arithmetic need not wait for their acknowledgement
                 // (without it the compiler waits at the loop head -- a table load of a lane that was no candidate may still target a live register)
                 __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (PFCAND) asm volatile("" :: "v"(pfC));
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
                     const bool mine = wave_bit(acc);
@@ -1014,7 +1096,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 maskEpoch = flushEpoch;
             }
             else if (n == 1) mask &= mask - 1;
-            else if (maskEpoch == flushEpoch) {
+            else if (PIPE || maskEpoch == flushEpoch) {
                 // no flush since the window's words were loaded: whatever has been marked since is still in the pending table -- no need to
                 // gather the 64 (spatially random) seed words again
                 mask &= ~((2ull << l) - 1ull) & wave_vote(s_pend[addr & (PEND - 1)] != addr);
@@ -1023,6 +1105,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 maskEpoch = flushEpoch;
             }
         }
+        if (PFSEED) asm volatile("" :: "v"(pfA), "v"(pfB));      // (the requests are only ever waited for here)
     }
 #undef MARK_USED
 #undef PEND_FLUSH
@@ -1035,7 +1118,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #ifdef OLF_STATS
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big;
         o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem;
-        o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; }
+        o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; o[22] = st_winLive; o[23] = st_first; o[24] = st_cand1; }
 #endif
     if (lane == 0) { regCount[img] = nreg; if (growFmt) growFmt[img] = 1; }
 }
@@ -1055,7 +1138,7 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
     const uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
     const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : nullptr;
-    const uint2* log2 = CHAINED ? nullptr : reinterpret_cast<const uint2*>(regionAll) + (size_t)img * g.Ps + rr.start;      // (pixel, gradient word) pairs of the one-wave agent
+    const uint2* log2 = CHAINED ? nullptr : reinterpret_cast<const uint2*>(regionAll + (size_t)img * g.regionStride) + rr.start;      // (pixel, gradient word) pairs of the one-wave agent
     const int* links = CHAINED ? linksAll + (size_t)img * nChunks : nullptr;
     const int n = rr.n, Ws = g.Ws;
     int cid = rr.start, nxt = -1;
@@ -1307,21 +1390,25 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
         // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once
-        hipLaunchKernelGGL(k_lsd_grow<0>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+        hipLaunchKernelGGL((k_lsd_grow<0, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt, (SegCand*)nullptr);
         OLF_HIP_CHECK(hipGetLastError());
         return OLF_OK;
     }
     // (lsd_refine: the candidates go to keysA -- keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
     if (g.refine >= 2)
-        hipLaunchKernelGGL(k_lsd_grow<2>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+        hipLaunchKernelGGL((k_lsd_grow<2, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
     else if (g.refine)
-        hipLaunchKernelGGL(k_lsd_grow<1>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+        hipLaunchKernelGGL((k_lsd_grow<1, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
-    else
-        hipLaunchKernelGGL(k_lsd_grow<0>, dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr);
+    else {
+        static const int pf = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 3; }();
+#define GROW0(PFV) hipLaunchKernelGGL((k_lsd_grow<0, PFV>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr)
+        if (pf == 0) GROW0(0); else if (pf == 1) GROW0(1); else if (pf == 7) GROW0(7); else GROW0(3);
+#undef GROW0
+    }
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

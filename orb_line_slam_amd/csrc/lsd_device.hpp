@@ -49,6 +49,23 @@ __device__ __forceinline__ float fdiv_unscaled(float a, float b)
     return q;
 }
 
+// sqrt(n / 4.0) -- the gradient norm of ll_angle -- for an integer 0 <= n < 2^21, correctly rounded: the compiler's own expansion of sqrt(double)
+// (v_rsq_f64, one Goldschmidt step, two residual corrections) without the range scaling and the special-value selects that these operands never need
+// (22 -> 12 instructions).  tests/test_device_math_gpu.py compares it with sqrt() on every n the gradient can take.
+__device__ __forceinline__ double sqrt_quarter(int n)
+{
+    const double x = (double)n * 0.25;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __fma_rn(-h, g, 0.5);
+    g = __fma_rn(g, r, g); h = __fma_rn(h, r, h);
+    double d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    d = __fma_rn(-g, g, x);
+    g = __fma_rn(d, h, g);
+    return n ? g : 0.0;
+}
+
 // cv::fastAtan2 as dev_fastAtan2 (device_math.hpp), for the agent's region angle: |x| via source modifiers and the unscaled division.
 // Only the sign of a zero result can differ from dev_fastAtan2 (x or y == -0.0f), and the region angle is only ever compared.
 __device__ __forceinline__ float agent_fastAtan2(float y, float x)

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
                                                       const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
-                                                      const AngEnt* __restrict__ ent, int E, int nChunks, int* __restrict__ growFmt)
+                                                      const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -575,7 +575,8 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     c.links = linksAll + (size_t)img * nChunks;
     c.recs = recsAll + (size_t)img * g.maxRegions;
     c.status = status;
-    c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32]; c.nChunks = nChunks; c.Ws = g.Ws; c.Hs = g.Hs;
+    c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32]; c.nChunks = poolLimit;      // (the bound of mw_alloc only: the per-image stride of chunks / links is nChunks)
+    c.Ws = g.Ws; c.Hs = g.Hs;
     c.minRegSize = g.minRegSize; c.maxRegions = g.maxRegions; c.lane = lane;
     for (int q = threadIdx.x; q < E; q += blockDim.x) c.eState[q] = ST_EMPTY;
     if (threadIdx.x < C_N + 1) c.ctl[threadIdx.x] = 0;
@@ -624,7 +625,7 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
     if (lds > 64 * 1024) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
     hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                        reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                       b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks, b.growFmt);
+                       b.nChunks, b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks, b.growFmt);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

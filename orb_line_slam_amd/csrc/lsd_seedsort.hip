@@ -930,7 +930,7 @@ static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_image
 {
     const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
     const int maxTiles = n / 64 + SS_TOP_JOBS + 2, half = maxTiles + SS_TOP_JOBS + 2;
-    const size_t stride = std::max((size_t)b.nChunks * 32, (size_t)2 * g.Ps);
+    const size_t stride = (size_t)g.regionStride;
     if ((size_t)2 * half > stride) return OLF_ERR_CAPACITY;
     hipLaunchKernelGGL(k_top_init, dim3(n_images), dim3(64), 0, s, b.geom, b.topBuf, b.maxN, nOverride, kthrOverride, depthOverride, b.status);
     if (n < SS_TOP_MIN) return OLF_OK;       // (the root is a final entry)

@@ -101,8 +101,6 @@ constexpr int FT_W = 128, FT_H = 32;                 // processed tile; LDS hold
 constexpr int FT_EW = 124, FT_EH = 30;               // emitted part: columns 2 .. 125, rows 1 .. 30 (the rest is the NMS halo of the neighbours)
 constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
 
-// byte `idx` (0..11) of three consecutive little-endian words
-#define FB(w0, w1, w2, idx) ((int)((((idx) < 4 ? (w0) : (idx) < 8 ? (w1) : (w2)) >> (8 * ((idx) & 3))) & 0xffu))
 
 // FAST-9/16 corners of one level, straight into the per-cell candidate lists of ComputeKeyPointsOctTree (src/ORBextractor.cc:791-831):
 // cv::FAST(cell sub-image, threshold, nonmaxSuppression = true) keeps the strict 3x3 local maxima of the corner score inside the cell's
@@ -134,37 +132,59 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     reinterpret_cast<uint4*>(s_score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (threadIdx.x == 0) { s_nc = 0; s_n = 0; }
     __syncthreads();
-    const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4, lane = threadIdx.x & 63;
+    const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4;
     // ---- phase A1: high-speed rejection on the thread's 4x4 pixels (tile rows ry0 .. ry0+9, tile bytes 4q .. 4q+11; pixel p sits at
     // byte 4q+4+p).  A 9-arc of the 16-ring always covers two ADJACENT compass points (N/E/S/W), so a pixel can only be a corner if two
-    // adjacent compass points are both brighter than v+t or both darker than v-t.  Survivors are queued (one LDS atomic per wave and
-    // pixel slot).
+    // adjacent compass points are both brighter than v+t or both darker than v-t.  Survivors are queued (one LDS atomic per thread that has any).
+    // SWAR: the four pixels of a row are the middle dword of (w0, w1, w2); a v_perm_b32 puts two of them (even / odd) into the 16-bit halves of a word, the
+    // compass neighbours likewise ((x, y +- 3): the same bytes of the rows three above / below; (x +- 3, y): bytes cut out of two dwords by the same
+    // instruction).  With the bias K = 512 - (t + 1) per half, n + (K - v) has bit 9 set iff n > v + t and (v + K) - n iff n < v - t; neither can borrow from
+    // or carry into the other half (1 <= field <= 765), so one 32-bit add / sub tests two pixels against one compass point.
     uint32_t w[10][3];
 #pragma unroll
     for (int r = 0; r < 10; ++r)
 #pragma unroll
         for (int k = 0; k < 3; ++k) w[r][k] = tile[(ry0 + r) * FT_INW + q + k];
+    uint32_t hE[10], hO[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        hE[r] = __builtin_amdgcn_perm(w[r][1], w[r][1], 0x0c020c00u);      // pixels 0, 2
+        hO[r] = __builtin_amdgcn_perm(w[r][1], w[r][1], 0x0c030c01u);      // pixels 1, 3
+    }
+    const uint32_t K = 0x02000200u - (uint32_t)(minTh + 1) * 0x00010001u, C9 = 0x02000200u;
+    uint32_t acc = 0;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const int gy = y0 + ry0 + rr;
+        const int c = rr + 3;
+        const uint32_t eE = __builtin_amdgcn_perm(w[c][2], w[c][1], 0x0c050c03u), eO = __builtin_amdgcn_perm(w[c][2], w[c][1], 0x0c060c04u);   // x + 3: bytes 7, 9 / 8, 10
+        const uint32_t wE = __builtin_amdgcn_perm(w[c][1], w[c][0], 0x0c030c01u), wO = __builtin_amdgcn_perm(w[c][1], w[c][0], 0x0c040c02u);   // x - 3: bytes 1, 3 / 2, 4
+        uint32_t ps[2];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int gx = x0 + 4 * q + p;
-            const int c = rr + 3, b = p + 4;                       // centre row in w[], centre byte
-            const int v = FB(w[c][0], w[c][1], w[c][2], b);
-            const int n0 = FB(w[c + 3][0], w[c + 3][1], w[c + 3][2], b), n8 = FB(w[c - 3][0], w[c - 3][1], w[c - 3][2], b);
-            const int n4 = FB(w[c][0], w[c][1], w[c][2], b + 3), n12 = FB(w[c][0], w[c][1], w[c][2], b - 3);
-            const int hiT = v + minTh, loT = v - minTh;
-            const bool b0 = n0 > hiT, b4 = n4 > hiT, b8 = n8 > hiT, b12 = n12 > hiT;
-            const bool d0 = n0 < loT, d4 = n4 < loT, d8 = n8 < loT, d12 = n12 < loT;
-            const bool pass = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) && gx >= xBeg && gx < xEnd && gy >= yBeg && gy < yEnd;
-            const unsigned long long pm = wave_vote(pass);
-            if (pm) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_nc, __popcll(pm));
-                base = __shfl(base, 0);
-                if (pass) s_cand[base + wave_rank_below(pm)] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
-            }
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t V = h ? hO[c] : hE[c], N8 = h ? hO[c - 3] : hE[c - 3], N0 = h ? hO[c + 3] : hE[c + 3], N4 = h ? eO : eE, N12 = h ? wO : wE;
+            const uint32_t Bb = K - V, Bd = V + K;
+            const uint32_t br = ((N0 + Bb) | (N8 + Bb)) & ((N4 + Bb) | (N12 + Bb));
+            const uint32_t dk = ((Bd - N0) | (Bd - N8)) & ((Bd - N4) | (Bd - N12));
+            ps[h] = br | dk;
+        }
+        acc = (acc >> 2) | (ps[0] & C9) | ((ps[1] << 1) & (C9 << 1));
+    }
+    acc >>= 3;      // pixel p of row rr: bit 2 rr + (p & 1) + 16 (p >> 1)
+    {   // scores exist on [xBeg, xEnd) x [yBeg, yEnd) only
+        uint32_t cols = 0, bm = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int gx = x0 + 4 * q + p; if (gx >= xBeg && gx < xEnd) cols |= 1u << ((p & 1) + 16 * (p >> 1)); }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { const int gy = y0 + ry0 + rr; if (gy >= yBeg && gy < yEnd) bm |= cols << (2 * rr); }
+        acc &= bm;
+    }
+    if (acc) {      // survivors are queued (the order inside the queue is immaterial: phase A2 compacts it again and k_cells_sort orders the result)
+        int pos = atomicAdd(&s_nc, __popc(acc));
+        while (acc) {
+            const int b = __builtin_ctz(acc);
+            acc &= acc - 1u;
+            const int rr = (b & 15) >> 1, p = (b & 1) + 2 * (b >> 4);
+            s_cand[pos++] = (unsigned short)((ry0 + rr) * FT_W + 4 * q + p);
         }
     }
     __syncthreads();
@@ -244,7 +264,6 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
         }
     }
 }
-#undef FB
 
 // ---------------------------------------------------------------------------------------------
 // Per-cell dual threshold and ordering (src/ORBextractor.cc:799-831): if any survivor of the cell reaches iniThFAST only those are kept

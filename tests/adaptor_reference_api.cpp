@@ -402,6 +402,26 @@ int main()
             orbR.extract(L.data, 640, 480, 640, k, d);
             if ((int)k.size() != F.N || std::memcmp(k.data(), F.mvKeys.data(), k.size() * sizeof(olf_keypoint)) != 0) return 25;
         }
+        if (gpu) {
+            // Config::hasLines() == false (src/LineExtractor.cc:37, src/Frame.cc:203): the same points, no line member touched by the stereo step
+            ORB_SLAM2::AdaptorConfig::hasLines() = false;
+            Frame G;
+            G.mpORBextractorLeft = &orbL; G.mpORBextractorRight = &orbR; G.mpLineextractorLeft = &lineL; G.mpLineextractorRight = &lineR;
+            ORB_SLAM2::StereoFrameFeatures(G, L, R);
+            std::vector<olf_keyline> kl0; std::vector<uint8_t> ld0;
+            lineL.extract(L.data, 640, 480, 640, kl0, ld0);
+            ORB_SLAM2::AdaptorConfig::hasLines() = true;
+            if (G.N != F.N || std::memcmp(G.mvKeys.data(), F.mvKeys.data(), (size_t)F.N * sizeof(olf_keypoint)) != 0 || G.mvuRight != F.mvuRight) return 27;
+            if (G.N_l != 0 || !G.mvKeys_Line.empty() || !G.mvDisparity_l.empty() || !kl0.empty()) return 28;
+            // a frame without key points: the constructor returns before the stereo step (src/Frame.cc:176-177)
+            Mat flatL(480, 640, 0), flatR(480, 640, 0);
+            for (int y = 0; y < 480; ++y) for (int x = 0; x < 640; ++x) { flatL.at<uint8_t>(y, x) = 90; flatR.at<uint8_t>(y, x) = 90; }
+            Frame Z;
+            Z.mpORBextractorLeft = &orbL; Z.mpORBextractorRight = &orbR; Z.mpLineextractorLeft = &lineL; Z.mpLineextractorRight = &lineR;
+            Z.mvuRight.assign(3, 7.f);
+            ORB_SLAM2::StereoFrameFeatures(Z, flatL, flatR);
+            if (Z.N != 0 || !Z.mvKeys.empty() || Z.mvuRight.size() != 3 || Z.N_l != (int)Z.mvKeys_Line.size()) return 29;
+        }
         Mat small(100, 100, 0);
         try { ORB_SLAM2::StereoFrameFeatures(F, L, small); return 26; } catch (const std::runtime_error&) {}      // size mismatch throws, src/Frame.cc:145-146
     }

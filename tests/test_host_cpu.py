@@ -324,3 +324,42 @@ def test_is_in_frustum_matches_oracle():
         assert np.array_equal(v.mTrackViewCos[oi].view(np.uint32), oc[oi].view(np.uint32))
         for k, arr in enumerate((v.mTrackProjX, v.mTrackProjY, v.mTrackProjXR)):
             assert np.array_equal(arr[oi].view(np.uint32), op[oi, k].view(np.uint32))
+
+
+def test_sequence_loaders_follow_the_reference_layouts(tmp_path):
+    """orb_line_slam_amd/sequence.py: the file lists of Examples/PL/PL_stereo_kitti.cc:130-160 and PL_stereo_euroc.cc:192-216, and the batch reader
+    (left image of pair p at 2p, right at 2p + 1; grey files byte-for-byte).  Host code only."""
+    from PIL import Image
+    from orb_line_slam_amd import sequence
+    rng = np.random.default_rng(3)
+    w, h, n = 40, 24, 5
+    imgs = rng.integers(0, 256, (2 * n, h, w), dtype=np.uint8)
+    # KITTI: times.txt, image_0/%06d.png, image_1/%06d.png
+    k = tmp_path / "kitti" / "00"
+    (k / "image_0").mkdir(parents=True); (k / "image_1").mkdir()
+    (k / "times.txt").write_text("".join("%e\n" % (0.1 * i) for i in range(n)) + "\n")
+    for i in range(n):
+        Image.fromarray(imgs[2 * i]).save(k / "image_0" / ("%06d.png" % i))
+        Image.fromarray(imgs[2 * i + 1]).save(k / "image_1" / ("%06d.png" % i))
+    l, r, t = sequence.load_images_kitti(str(k))
+    assert len(l) == len(r) == len(t) == n and l[3].endswith("image_0/000003.png") and r[3].endswith("image_1/000003.png") and abs(t[3] - 0.3) < 1e-12
+    seq = sequence.StereoSequence(str(k))
+    assert (seq.width, seq.height, len(seq)) == (w, h, n)
+    got = [b.copy() for b, _ in seq.batches(2)]
+    assert [g.shape[0] for g in got] == [4, 4, 2] and np.array_equal(np.concatenate(got), imgs)
+    # EuRoC: one stamp per line, <left>/<stamp>.png, <right>/<stamp>.png, seconds = stamp / 1e9; PGM files through the generic finder
+    e = tmp_path / "mav0"
+    (e / "cam0" / "data").mkdir(parents=True); (e / "cam1" / "data").mkdir(parents=True)
+    stamps = [1403636579763555584 + 50000000 * i for i in range(n)]
+    (tmp_path / "MH01.txt").write_text("\n".join(str(s) for s in stamps) + "\n")
+    for i, s in enumerate(stamps):
+        Image.fromarray(imgs[2 * i]).save(e / "cam0" / "data" / f"{s}.png")
+        Image.fromarray(imgs[2 * i + 1]).save(e / "cam1" / "data" / f"{s}.png")
+    l, r, t = sequence.load_images_euroc(str(e / "cam0" / "data"), str(e / "cam1" / "data"), str(tmp_path / "MH01.txt"))
+    assert len(l) == n and l[1].endswith(f"cam0/data/{stamps[1]}.png") and abs(t[1] - stamps[1] / 1e9) < 1e-6
+    seq = sequence.StereoSequence(left=l, right=r, times=t)
+    assert np.array_equal(np.concatenate([b for b, _ in seq.batches(8)]), imgs)
+    seq = sequence.StereoSequence(str(e), limit=3)
+    assert len(seq) == 3 and np.array_equal(next(seq.batches(3))[0], imgs[:6])
+    with pytest.raises(ValueError):
+        sequence.StereoSequence(left=l, right=r[:-1])

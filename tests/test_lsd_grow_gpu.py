@@ -72,3 +72,33 @@ def test_pool_exhaustion_falls_back_to_the_one_wave_agent(oracle):
             assert n == len(want[i]["kls"]), (waves, pool, i, n, len(want[i]["kls"]))
             assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (waves, pool, i)
     _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, 0), "olf_debug_lsd_pool")
+
+
+def test_pool_fallback_keeps_one_stride_for_both_pixel_list_formats(oracle):
+    """the chunk chains of the multi-wave kernel and the contiguous log of the one-wave fall-back used different per-image strides in the
+    shared pixel-list buffer unless Ps % 16 == 0 and Ps >= 34816.  A small working image (180 x 133, Ps = 23940, Ps % 16 = 4), chained images WITH
+    regions before and behind the fallen-back ones: every image must still equal the oracle."""
+    w, h = 150, 111
+    p = oracle.full_params(2000, 0)
+    rich = synth.stereo_batch(19, 2, w, h)
+    simple = np.full((h, w), 60, np.uint8)
+    simple[30:80, 40:110] = 200                              # one rectangle: four regions, a handful of chunks
+    simple2 = np.full((h, w), 90, np.uint8)
+    simple2[20:95, 20:35] = 10
+    simple2[50:60, 60:140] = 250
+    imgs = np.stack([simple, rich[0], rich[1], simple2, rich[2]])
+    ex = ola.Lineextractor(0, 0.025, max_images=5)
+    ex._params.orb.nlevels = 1                                # (the context also sizes an ORB pyramid: one level accepts a 150 x 111 image)
+    p.orb.nlevels = 1
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    assert len(want[0]["kls"]) >= 4 and len(want[3]["kls"]) >= 4 and len(want[1]["kls"]) > 10
+    for waves, rob, pool in [(8, 256, 300), (4, 128, 160), (16, 512, 560), (8, 256, 0)]:
+        _set(ex, w, h, 5, waves, rob)
+        _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, pool), "olf_debug_lsd_pool")
+        kls, desc, counts = ex.extract_batch(imgs)
+        assert (_status(ex)[0] & (8 | 16)) == 0, (waves, rob, pool)
+        for i in range(5):
+            n = int(counts[i])
+            assert n == len(want[i]["kls"]), (waves, pool, i, n, len(want[i]["kls"]))
+            assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (waves, pool, i)
+    _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, 0), "olf_debug_lsd_pool")
