@@ -410,7 +410,7 @@ static int check_status(olf_ctx* c)
     if (st[0]) {
         (void)hipMemset(c->ob.status, 0, 16);
         set_error("device capacity overflow, flags=" + std::to_string(st[0]) +
-                  " (1/2/4: ORB corner / candidate / key point buffers, 8: LSD regions, segments or pixel-list pool, 16: LSD growth watchdog, 32: frame record buffer)");
+                  " (1/2/4: ORB corner / candidate / key point buffers, 8: LSD regions, segments or pixel-list pool, 16: LSD growth watchdog, 32: frame record buffer, 64: LSD seed sort, final-range list of the grid-wide top levels)");
         return OLF_ERR_CAPACITY;
     }
     return OLF_OK;

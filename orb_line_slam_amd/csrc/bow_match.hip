@@ -207,7 +207,7 @@ int launch_search_by_bow_batch(const uint8_t* slotDesc, const int* childOff, con
     if (n_frames < 2) return OLF_OK;
     int P = 64;
     while (P < cap) P <<= 1;
-    if (cap > 8192) { set_error("olf_search_by_bow_batch_dev: more than 8192 features per frame"); return OLF_ERR_CAPACITY; }
+    if (cap > 4096) { set_error("olf_search_by_bow_batch_dev: more than 4096 features per frame (the per-frame node sort runs in 32 KB of LDS)"); return OLF_ERR_CAPACITY; }
     hipLaunchKernelGGL(k_bow_descend_nodes, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, reinterpret_cast<const uint4*>(slotDesc), childOff, slotNode,
                        nodeWeight, reinterpret_cast<const uint4*>(d_desc), d_counts, cap, img_stride, nid_level, d_nodes);
     hipLaunchKernelGGL(k_bow_sort_nodes, dim3(n_frames), dim3(256), (size_t)P * 8, s, d_nodes, cap, P, d_sorted, d_m);

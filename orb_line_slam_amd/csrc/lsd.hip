@@ -171,6 +171,8 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const int c0 = chunk * LG_CHUNK;
     const int lo = max(0, c0 - Ws - 1), hi = min(Ps, c0 + LG_CHUNK + Ws + 1);
     if (threadIdx.x == 0) s_base = 0;
+    const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
+    const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
     // (NB independent loads in flight per thread, then their table lookups: the pass is latency bound otherwise)
     constexpr int NB = 8;
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * KEYS_THREADS) {
@@ -182,9 +184,26 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
 #pragma unroll
         for (int u = 0; u < NB; ++u) if (i0 + u * KEYS_THREADS < hi) s_deg[i0 + u * KEYS_THREADS - lo] = d[u];
+        if (ALLKEYS) {
+            // the std::sort key of every pixel of the chunk itself (not of the halo rows), while its gradient word is in a register: a second pass over
+            // the chunk would load every word again, one dependent L2 round trip per pixel and thread (16.5 -> 12 ms per 6144 images)
+            uint32_t* kall = keys + (size_t)img * Ps;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = i0 + u * KEYS_THREADS;
+                if (idx >= c0 && idx < min(Ps, c0 + LG_CHUNK)) {
+                    const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
+                    if (x < Ws - 1 && y < Hs - 1) {
+                        const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
+                        const int bin = (int)(sqrt_quarter(gx * gx + gy * gy) * bin_coef);
+                        kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
-    {   // keys of the chunks before this one
+    if (!ALLKEYS) {   // keys of the chunks before this one
         int part = 0;
         for (int c = threadIdx.x; c < chunk; c += KEYS_THREADS) part += chunkCnt[(size_t)img * nChunks + c];
 #pragma unroll
@@ -208,25 +227,9 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
 #pragma unroll
       for (int v = 0; v < NWV; ++v) { acc += s_wcnt[v]; nEnd[v] = acc; } }
     const int n3 = nEnd[NWV - 1];
-    const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
-    const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
-    if (ALLKEYS) {
-        // (a per-block table of the undefined pixels' bins -- gx^2 + gy^2 < nThr -- with the defined ones keyed by the dense loop below was
-        // slower, 22.8 against 16.9 ms per 6144 images: the dense loop's stores then scatter and nearly every wave still holds a defined pixel)
-        uint32_t* kall = keys + (size_t)img * Ps;
-        for (int li = threadIdx.x; li < LG_CHUNK && c0 + li < Ps; li += KEYS_THREADS) {
-            const int idx = c0 + li;
-            const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
-            if (x < Ws - 1 && y < Hs - 1) {
-                const uint32_t p = grad[idx];
-                const int gx = unpack_gx(p), gy = unpack_gy(p);
-                const double norm = sqrt_quarter(gx * gx + gy * gy);
-                const int bin = (int)(norm * bin_coef);
-                kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
-            }
-        }
-    }
+    // (ALLKEYS: a per-block table of the undefined pixels' bins -- gx^2 + gy^2 < nThr -- with the defined ones keyed by the dense loop below was
+    // slower, 22.8 against 16.9 ms per 6144 images: the dense loop's stores then scatter and nearly every wave still holds a defined pixel)
     // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
     for (int t = threadIdx.x; t < n3; t += KEYS_THREADS) {
         int w = 0, before = 0;
@@ -234,10 +237,13 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         for (int v = 0; v < NWV - 1; ++v) if (t >= nEnd[v]) { w = v + 1; before = nEnd[v]; }
         const int li = s_list[w * SPAN + t - before];
         const int idx = c0 + li;
-        const uint32_t p = grad[idx];
-        const int gx = unpack_gx(p), gy = unpack_gy(p);
-        const double norm = sqrt_quarter(gx * gx + gy * gy);
-        const int bin = (int)(norm * bin_coef);
+        uint32_t p = 0;
+        int bin = 0;
+        if (!ALLKEYS) {      // (ALLKEYS: the key went out with the first pass; the word is only needed again for the rare isolated seed)
+            p = grad[idx];
+            const int gx = unpack_gx(p), gy = unpack_gy(p);
+            bin = (int)(sqrt_quarter(gx * gx + gy * gy) * bin_coef);
+        }
         const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
         const float deg0 = s_deg[idx - lo];
         // isaligned() on two angles in degrees a, b: with t = | |a - b| - 180 | it is t >= 180 - ang_th (|a - b| <= ang_th, or >= 360 - ang_th after the
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
                 if (n_theta <= g.prec) iso = false;
             }
         }
-        if (iso) grad[idx] = p | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
+        if (iso) grad[idx] = (ALLKEYS ? grad[idx] : p) | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
         if (!ALLKEYS) kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
     }

@@ -698,7 +698,7 @@ __device__ __forceinline__ void ss_top_child(const SsTop& t, int* s_next, int* s
     } else {
         const int e = atomicAdd(s_fin, 1);
         if (e < SS_TOP_FINAL) { int* q = t.fin + e * 5; q[0] = first; q[1] = last; q[2] = depth; q[3] = (int)lb; q[4] = (int)ub; }
-        else atomicOr(status, 32);
+        else atomicOr(status, 64);      // (its own flag: 32 is the frame record buffer)
     }
 }
 
@@ -976,7 +976,14 @@ int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipS
     // the kernel goes 43.5 -> 37.9 ms (groups of 8; 40.2 with 4; equal at 1536 images), on the bench's 512 distinct pairs the front does not move
     // (71.3 against 71.7 ms) and the step is 278.9 against 276.8 ms -- the launch is bound by issue slots, not by its slowest image.
     // One stereo pair through olf_stereo_frames, host to host: 25.6 ms with the one-wave kernel, 16.5 ms with 4 waves, 15.1 ms with 8
-    const int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 640 ? 1 : n_images <= 1536 ? 5 : 0);
+    int mode = b.forceSortMode >= 0 ? b.forceSortMode : forced >= 0 ? forced : (n_images <= 256 ? 2 : n_images <= 640 ? 1 : n_images <= 1536 ? 5 : 0);
+    {   // the multi-wave kernels ask for 101 / 53 / 30 KB of dynamic LDS (8 / 4 / 2 waves): on a device whose workgroups cannot have that much (the Makefile
+        // accepts other ARCH values than gfx950) take the largest variant that fits instead of failing the launch -- the result does not depend on it
+        int dev = 0, maxLds = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) maxLds = 64 * 1024;
+        auto need = [](int m) { return m == 2 ? 104 * 1024 : m == 1 ? 56 * 1024 : m == 5 ? 32 * 1024 : m == 4 ? 104 * 1024 : m == 3 ? 56 * 1024 : 0; };
+        while (need(mode) > maxLds) mode = mode == 2 ? 1 : mode == 1 ? 5 : mode == 4 ? 3 : 0;
+    }
     int rc = OLF_OK;
     if (mode == 1) rc = launch_seedsort_mw<4, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 2) rc = launch_seedsort_mw<8, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);

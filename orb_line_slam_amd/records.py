@@ -20,6 +20,8 @@ def _align16(x):
 
 def _rows(arr, n_sets, row_bytes):
     a = np.ascontiguousarray(arr)
+    if n_sets == 0:      # an empty shard (more ranks than frames): no rows, the capacity still comes from the array's second dimension
+        return np.zeros((0, a.shape[1] if a.ndim >= 2 else 0, row_bytes), np.uint8)
     return a.view(np.uint8).reshape(n_sets, -1, row_bytes)
 
 
@@ -27,8 +29,8 @@ def pack_records(arrays, counts, lcounts):
     """arrays: dict name -> full-capacity array ([2n] or [n] leading dimension as in olf_frame_buffers); counts / lcounts: int32 [2n]."""
     counts = np.asarray(counts, np.int32); lcounts = np.asarray(lcounts, np.int32)
     n2 = len(counts); n = n2 // 2
-    cap = _rows(arrays["kps"], n2, 28).shape[1] if n2 else 0
-    lcap = _rows(arrays["kls"], n2, 68).shape[1] if n2 else 0
+    cap = _rows(arrays["kps"], n2, 28).shape[1]
+    lcap = _rows(arrays["kls"], n2, 68).shape[1]
     tot = (int(counts.sum()), int(lcounts.sum()), int(counts[0::2].sum()), int(lcounts[0::2].sum()))
     hdr = np.zeros(16, np.uint32)
     hdr[:8] = (MAGIC, n, cap, lcap) + tot
@@ -75,7 +77,7 @@ def merge_records(records):
     ps = [parse_records(r) for r in records]
     if not ps:
         raise ValueError("no records")
-    assert len({(p["cap"], p["lcap"]) for p in ps}) == 1
+    assert len({(p["cap"], p["lcap"]) for p in ps}) == 1, "records of contexts with different capacities"
     counts = np.concatenate([p["counts"] for p in ps]); lcounts = np.concatenate([p["lcounts"] for p in ps])
     n2 = len(counts)
     hdr = np.zeros(16, np.uint32)

@@ -139,7 +139,7 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], 
 # full-capacity output arrays of 7 stereo frames, as the fused entry writes them: rows from the committed fixture of the feature path
 # (tests/golden/frame_320x240_seed11.npz), a different number of rows in use per frame
 g = np.load(os.path.join(sys.argv[1], "tests", "golden", "frame_320x240_seed11.npz"))
-n_frames, cap, lcap = 7, 520, 100
+n_frames, cap, lcap = (int(sys.argv[3]) if len(sys.argv) > 3 else 7), 520, 100
 def frames(lo, hi):
     n = hi - lo
     a = {"kps": np.zeros((2 * n, cap, 28), np.uint8), "desc": np.zeros((2 * n, cap, 32), np.uint8), "uright": np.full((n, cap), -1, np.float32),
@@ -147,8 +147,8 @@ def frames(lo, hi):
          "lmatches12": np.full((n, lcap), -1, np.int32), "ldisp": np.full((n, lcap, 2), -1, np.float32), "lle": np.zeros((n, lcap, 3), np.float64)}
     counts, lcounts = np.zeros(2 * n, np.int32), np.zeros(2 * n, np.int32)
     for q, f in enumerate(range(lo, hi)):
-        nl_, nr_ = 504 - 31 * f, 300 + 7 * f
-        ll_, lr_ = 100 - 9 * f, 40 + 3 * f
+        nl_, nr_ = 504 - 31 * (f % 8), 300 + 7 * (f % 8)
+        ll_, lr_ = 100 - 9 * (f % 8), 40 + 3 * (f % 8)
         counts[2 * q], counts[2 * q + 1], lcounts[2 * q], lcounts[2 * q + 1] = nl_, nr_, ll_, lr_
         kb, klb = g["kpsL"].view(np.uint8).reshape(-1, 28), g["klsL"].view(np.uint8).reshape(-1, 68)
         a["kps"][2 * q, :nl_] = kb[:nl_]; a["kps"][2 * q + 1, :nr_] = np.roll(kb, f, 0)[:nr_]
@@ -169,6 +169,7 @@ if rank == 0:
     assert got == whole, "gathered records differ from the single-rank record"
     p = parse_records(got)
     assert p["n_pairs"] == n_frames and p["counts"][0] == 504 and len(p["kps"]) == p["counts"].sum() and p["bytes"] == len(whole)
+    assert all(sizes[r] > 0 for r in range(world)), sizes            # (an empty shard still sends its header)
     print("GATHER_OK", len(whole), sizes)
 else:
     assert recs is None
@@ -188,6 +189,23 @@ def test_frame_sharded_gather_world2_gloo(tmp_path):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
+
+
+@pytest.mark.parametrize("n_frames", [7, 13])
+def test_frame_sharded_gather_world8_gloo(tmp_path, n_frames):
+    """The shape of the driver's 8-GPU run, on CPU: 8 gloo ranks; 7 frames leave rank 7 EMPTY (a zero-pair record still takes part in the size
+    exchange and the point-to-point gather), 13 frames give uneven shards (2, 2, 2, 2, 2, 1, 1, 1).  Rank 0's merge must equal the 1-rank record."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(n_frames)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
 
