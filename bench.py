@@ -227,10 +227,43 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo")
+        # Bring-up under a deadline: a rendezvous that never completes (a rank that died, a wrong MASTER_PORT) or an RCCL that cannot build its rings
+        # (two ranks on one device, no peer access between the GPUs, IPC handles refused -- HSA_ENABLE_IPC_MODE_LEGACY=0 must be set on this pool)
+        # otherwise hangs until the driver's own clock kills the run; here it ends with a message that says which step failed
+        import datetime, signal
+        limit = int(os.environ.get("OLF_DIST_TIMEOUT", "240"))
+        stage_name = ["rendezvous (init_process_group)"]
+
+        def _deadline(signum, frame):
+            raise SystemExit(f"rank {rank}/{world}: distributed bring-up timed out after {limit} s in: {stage_name[0]} "
+                             f"(backend {args.backend}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, device {dev_index} of {torch.cuda.device_count()})")
+        signal.signal(signal.SIGALRM, _deadline)
+        signal.alarm(limit)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(seconds=limit))
+            else:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=limit))
+            # the first collective builds every ring / channel: if RCCL refuses the topology this is where it says so
+            stage_name[0] = "first all_reduce (RCCL communicator / xGMI rings)" if args.backend == "nccl" else "first all_reduce (gloo)"
+            probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", dev_index) if args.backend == "nccl" else torch.device("cpu"))
+            dist.all_reduce(probe)
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce of ones gave {int(probe.item())}, expected {world}")
+            if args.backend == "nccl":
+                # one rank per device: two ranks that landed on the same GPU (a launcher that did not set LOCAL_RANK) deadlock RCCL later, inside the gather
+                ids = [None] * world
+                dist.all_gather_object(ids, (os.uname().nodename, str(torch.cuda.get_device_properties(dev_index).uuid) if hasattr(torch.cuda.get_device_properties(dev_index), "uuid") else dev_index))
+                if len(set(ids)) != world:
+                    raise RuntimeError(f"ranks share a device: {ids} (RCCL needs one GPU per rank; use --backend gloo to let ranks share one)")
+        except SystemExit:
+            raise
+        except Exception as e:
+            raise SystemExit(f"rank {rank}/{world}: distributed bring-up failed in {stage_name[0]}: {type(e).__name__}: {e}")
+        finally:
+            signal.alarm(0)
     dev = torch.device("cuda", dev_index)
     cdev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")      # where the scalar reductions of the harness live
 
@@ -388,7 +421,13 @@ def main():
     ctx.synchronize()                        # outside the timed region: raises if any step overflowed a fixed-capacity device buffer
     prof = ctx.profile_read()
     ctx.profile(False)
+    rank_dt = None
     if dist is not None:
+        # every rank's own time for the K steps (the first real multi-GPU run must be diagnosable from one line: a slow rank, a slow link), then the
+        # maximum, which is the job's time
+        tl = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([dt], dtype=torch.float64, device=cdev))
+        rank_dt = [float(x.item()) for x in tl]
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -493,6 +532,9 @@ def main():
                          "path_frac_of_hbm_peak": round(ab["pair"] * fps / world / 8e12, 6), "valu_issue": valu, "valu_issue_step": valu_step},
             "stages_ms_per_step": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
         }
+        if rank_dt is not None:
+            ms = [t / args.steps * 1e3 for t in rank_dt]
+            out["per_rank_ms_per_step"] = {"min": round(min(ms), 3), "max": round(max(ms), 3), "slowest_rank": int(np.argmax(ms)), "ranks": [round(m, 3) for m in ms]}
         if alone:
             # per stage: algorithmic bytes of a launch over the whole batch / the stage's time when it runs alone -> GB/s and fraction of the 8 TB/s
             # peak (stages without a byte model -- octree, matchers, region2rect -- carry their time only)
@@ -507,6 +549,7 @@ def main():
         if gather_on:
             out["gather"] = {"mode": args.gather, "bytes_per_step": int(gstat["bytes"] / max(args.steps, 1)),
                              "GBps": round(gstat["bytes"] / max(gstat["seconds"], 1e-9) / 1e9, 3),
+                             "rank0_ingest_GBps": round(gstat["bytes"] / dt / 1e9, 3),       # bytes rank 0 received per second of the timed region
                              "host_seconds_per_step": round(gstat["seconds"] / max(args.steps, 1), 5), "verify": verify}
         if not args.no_extras:
             # measured ceiling of a plain copy kernel, next to the 8 TB/s of the specification

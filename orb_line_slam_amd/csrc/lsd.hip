@@ -861,11 +861,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
                 const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
                 PSTAMP(p_ring);
-                const uint32_t pw = grad[a];
+                const uint32_t pw = grad[(uint32_t)a];      // (an unsigned index: the 32-bit offset form of the load, no sign extension and 64-bit add)
                 const int pendv = s_pend[a & (PEND - 1)];      // (unconditional: issued beside the gradient load instead of behind it; the commit reuses it)
                 const int xy = xx | (yy << 16);
                 unsigned long long cm = inImg & wave_vote(!(pw & (kUsed | kNotDef))) & wave_vote(pendv != a);
-                double ang = 0, cs = 0, sn = 0;
+                // (left undefined for the lanes that are no candidates: nothing below looks at them, and three 64-bit zero moves per step are saved)
+                double ang, cs, sn;
+                asm volatile("" : "=v"(ang), "=v"(cs), "=v"(sn));
                 PSTAMP(p_gather);
                 uint32_t pfC = 0;
                 if (wave_bit(cm)) {
@@ -918,43 +920,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     // angle that governs it (the one after the accepts before it).  The speculation is exact up to the first candidate
                     // whose decision differs from the one under the initial angle; everything before it is committed -- at least the first
                     // accept, whose governing angle is the initial, exact one -- and the rest is classified again.
-                    unsigned long long todo = al, spec = 0;
-                    float sx = sumdx, sy = sumdy, psx = 0.f, psy = 0.f;
-                    int dupStep = 64, j = 0;
+                    unsigned long long todo = al;
+                    // lane L keeps the sums as they are when its turn comes -- after every speculated accept at a lower lane -- so the angle that governs
+                    // its test is one fastAtan2 of its own registers (no cross-lane exchange); `spare`, a lane that holds no live candidate, keeps the
+                    // sums after ALL of them (the region's new state when the whole round commits)
+                    float sx = sumdx, sy = sumdy, bsx = sumdx, bsy = sumdy;
+                    int dupLane = 64;                                            // the speculated accept this lane is another view of (its lane; 64: none)
                     while (todo) {
                         const int c = __builtin_ctzll(todo);
                         const int a_c = rlane(a, c);
                         const double cs_c = rlane_d(cs, c), sn_c = rlane_d(sn, c);
                         sx = (float)d_add((double)sx, cs_c);
                         sy = (float)d_add((double)sy, sn_c);
-                        if (lane == j) { psx = sx; psy = sy; }
-                        const bool tw = a == a_c;                                // c and the other FIFO entries' views of the same pixel
-                        if (tw && lane != c) dupStep = j;                        // (a lane can only ever equal one accepted pixel)
-                        todo &= ~wave_vote(tw);
-                        spec |= 1ull << c;
-                        ++j;
+                        if (lane > c) { bsx = sx; bsy = sy; }
+                        const unsigned long long twM = wave_vote(a == a_c);          // c and the other FIFO entries' views of the same pixel
+                        if (wave_bit(twM)) dupLane = c;                              // (a lane can only ever equal one accepted pixel; for c itself dupLane == lane)
+                        todo &= ~twM;
                     }
-                    const double th = d_mul((double)agent_fastAtan2(psy, psx), kDegToRads);       // lane j: the angle after accept j
-                    const int g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(spec >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)spec, 0u));   // speculated accepts before this lane
-                    double thg = shfl_d(th, max(g - 1, 0));
-                    if (g == 0) thg = reg_angle;
+                    // (another view always sits at a higher lane than the accept it duplicates: the lowest lane of a pixel is the one that was picked)
+                    const unsigned long long dupM = wave_vote(dupLane < lane), spec = al & ~dupM;
+                    const int c0 = __builtin_ctzll(spec);
+                    const unsigned long long freeM = ~cm;
+                    const int spare = freeM ? __builtin_ctzll(freeM) : 0;
+                    if (freeM && lane == spare) { bsx = sx; bsy = sy; }
+                    const double thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);     // the angle in force at this lane's turn (spare: after all accepts)
+                    const double thg = lane <= c0 ? reg_angle : thOwn;                              // nothing accepted before this lane: the current, exact angle
                     const double n2 = fabs(d_sub(thg, ang));
                     const unsigned long long reM = REFINE ? wave_vote((n2 > kM32PI ? fabs(d_sub(n2, kM2PI)) : n2) <= precC)
                                                           : wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
-                    const unsigned long long mis = (reM ^ wasM) & ~wave_vote(dupStep < g) & cm;
-                    const unsigned long long bm = mis ? ((1ull << __builtin_ctzll(mis)) - 1ull) : ~0ull;
-                    const unsigned long long okAcc = spec & bm;
+                    const unsigned long long mis = (reM ^ wasM) & ~dupM & cm;
+                    const int mLane = mis ? __builtin_ctzll(mis) : 64;               // everything below the first changed decision is decided
+                    const unsigned long long bm = mis ? ((1ull << mLane) - 1ull) : ~0ull;
+                    const unsigned long long okAcc = spec & bm, left = spec & ~bm;
                     const int t = __popcll(okAcc);
 #ifdef OLF_STATS
-                    ++st_rounds; st_k += j; st_t += t; if (t == j) ++st_full; if (n >= 64) { ++st_rounds_big; st_k_big += j; st_t_big += t; }
+                    ++st_rounds; st_k += __popcll(spec); st_t += t; if (!left) ++st_full; if (n >= 64) { ++st_rounds_big; st_k_big += __popcll(spec); st_t_big += t; }
 #endif
                     acc |= okAcc;
                     n += t;
-                    cm &= ~bm;                                         // everything before the first changed decision is decided
-                    cm &= ~wave_vote(dupStep < t);                      // other views of the committed pixels
-                    sumdx = __int_as_float(rlane(__float_as_int(psx), t - 1));
-                    sumdy = __int_as_float(rlane(__float_as_int(psy), t - 1));
-                    reg_angle = rlane_d(th, t - 1);
+                    cm &= ~bm;
+                    cm &= ~wave_vote(dupLane < mLane);                              // other views of the committed pixels (committed = speculated below mLane)
+                    // the region's state after the t committed accepts: what the first uncommitted speculated lane sees before its turn, or the spare lane
+                    if (left || freeM) {
+                        const int src = left ? __builtin_ctzll(left) : spare;
+                        sumdx = __int_as_float(rlane(__float_as_int(bsx), src));
+                        sumdy = __int_as_float(rlane(__float_as_int(bsy), src));
+                        reg_angle = rlane_d(thOwn, src);
+                    } else {      // all 64 lanes held live candidates and all of the round committed (never seen on images): the final angle on its own
+                        sumdx = sx; sumdy = sy;
+                        reg_angle = d_mul((double)agent_fastAtan2(sy, sx), kDegToRads);
+                    }
                 }
                 PSTAMP(p_chain);
                 // vmcnt(0) while only loads can be outstanding (they have long returned): behind this point the stores below are the only vector

@@ -381,3 +381,14 @@ def test_sequence_loaders_follow_the_reference_layouts(tmp_path):
     assert len(seq) == 3 and np.array_equal(next(seq.batches(3))[0], imgs[:6])
     with pytest.raises(ValueError):
         sequence.StereoSequence(left=l, right=r[:-1])
+
+
+def test_opencv_overloads_of_the_adaptor_type_check():
+    """The ORBLINE_WITH_OPENCV blocks of include/orbline_adaptor.hpp (cv::InputArray / cv::OutputArray / cv::Mat / KeyLine overloads -- what the
+    reference's Frame::ExtractORB / ExtractLine call, src/Frame.cc:350-364) had never been through a compiler: the image has no OpenCV.  They are
+    type-checked here against tests/opencv_decl, a DECLARATION-ONLY stand-in written from the public OpenCV 3.4 API.  That stand-in is test
+    infrastructure and pins nothing: the test proves the blocks parse and that the reference's call shapes resolve, not how OpenCV behaves."""
+    out = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-DORBLINE_WITH_OPENCV", "-I" + os.path.join(ROOT, "tests", "opencv_decl"),
+                          "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "adaptor_opencv_typecheck.cpp")],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]

@@ -32,3 +32,26 @@ def test_two_ranks_on_one_gpu_gather_and_verify(gather):
     assert g["bytes_per_step"] > 64 * 50_000                      # rank 1's trimmed records really travelled (about 0.2 MB per pair)
     # the whole-job value counts both ranks' pairs
     assert abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
+    # one line must be enough to diagnose the first real multi-GPU run: every rank's own step time and what rank 0 took in
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["ranks"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) / d["ms_per_step"] < 1e-3 and pr["slowest_rank"] in (0, 1)
+    assert g["rank0_ingest_GBps"] > 0
+
+
+def test_distributed_bring_up_fails_fast_with_a_message():
+    """bench.py --gpus N must not hang when the job cannot come up.  (a) RCCL with more ranks than GPUs on the node: refused before any collective.
+    (b) a rank whose peers never arrive: the rendezvous deadline (OLF_DIST_TIMEOUT) ends it with the step it was stuck in."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="1", LOCAL_RANK="1", WORLD_SIZE="2")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env["MASTER_PORT"] = str(port)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+        assert out.returncode != 0 and b"no GPU 1 on this node" in out.stderr, out.stderr.decode()[-1500:]
+    env.update(RANK="0", LOCAL_RANK="0", OLF_DIST_TIMEOUT="15")
+    import time
+    t = time.time()
+    out = subprocess.run(cmd + ["--backend", "gloo"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and (b"timed out" in out.stderr or b"bring-up failed" in out.stderr), out.stderr.decode()[-1500:]
+    assert b"rendezvous" in out.stderr and time.time() - t < 200
