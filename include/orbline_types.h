@@ -85,6 +85,13 @@ typedef struct olf_line_params {
     int32_t conv_gauss_sum256;
     int32_t conv_resize_exact;
     int32_t conv_seed_order;
+    /* C.6  conv_libm_float: the unqualified cos / sin / atan2 / sqrt calls on FLOAT arguments inside cv::LineSegmentDetector's region_grow
+     *      (sumdx += cos(float(angle))), LSDDetectorC::detectImpl (kl.angle = atan2(dy, dx), LSDDetector_custom.cpp:298) and BinaryDescriptor::computeLBD
+     *      (dL = cos / sin(direction), binary_descriptor_custom.cpp:1130-1131; 1 / sqrt(tempM), :1283-1341).  Which overload they resolve to depends on the
+     *      headers of the build: 0 (default) = ::cos(double) etc. -- the C functions, result rounded to float by the assignment; 1 = the float overloads
+     *      (cosf / sinf / atan2f / sqrtf and a float division), which libstdc++ >= 6 makes visible when <math.h> is included.  Both variants are restated
+     *      in the oracle and on the device (glibc 2.35's cosf / sinf / atan2f bit for bit). */
+    int32_t conv_libm_float;
 } olf_line_params;
 
 /* Camera / matching scalars read on the path:
@@ -100,12 +107,16 @@ typedef struct olf_stereo_params {
     double stereo_overlap_th;   /* Config::stereoOverlapTh()                           */
     double ls_min_disp_ratio;   /* Config::lsMinDispRatio()                            */
     int32_t best_lr_matches;    /* Config::bestLRMatches()                             */
+    /* conv_eigen_recip: `le_l = le_l / std::sqrt(...)` on an Eigen::Vector3d (src/Frame.cc:939).  Eigen 3.2+ divides every coefficient (0, default);
+     * the 3.0 / 3.1 line -- CMakeLists.txt:45 accepts 3.1.0 -- implements vector / scalar as a multiplication by the reciprocal computed once
+     * (scalar_quotient1_impl for non-integer scalars): 1.  mvle_l differs in the last bit between the two. */
+    int32_t conv_eigen_recip;
 } olf_stereo_params;
 
 /* The parameter block of olf_ctx_create.  It must be initialised by olf_default_params(), which stamps abi_version and struct_size;
  * olf_ctx_create refuses a block whose stamp differs from the library's (a caller built against an older header would otherwise hand over a
  * shorter struct, and the conv_* fields would be read from whatever follows it). */
-#define OLF_ABI_VERSION 3u
+#define OLF_ABI_VERSION 4u
 typedef struct olf_params {
     uint32_t          abi_version;   /* OLF_ABI_VERSION of the header the caller was built with */
     uint32_t          struct_size;   /* sizeof(olf_params) as the caller sees it               */

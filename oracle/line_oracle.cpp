@@ -68,6 +68,11 @@ static inline double dist(double x1, double y1, double x2, double y2) { return s
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 // cv LineSegmentDetectorImpl::region_grow (lsd.cpp): 8-neighbourhood growth from `addr0`, running region angle from float sums
+// convention C.6 (include/orbline_types.h conv_libm_float): which overload the unqualified libm calls on float arguments resolve to.  Set per thread by
+// the entry points that carry the parameter block (lsd_detect, line_extract) or take the flag (orc_lbd_compute_conv); 0 = the C functions on doubles.
+static thread_local int t_libm_float = 0;
+struct LibmScope { int prev; explicit LibmScope(int v) : prev(t_libm_float) { t_libm_float = v; } ~LibmScope() { t_libm_float = prev; } };
+
 static void region_grow(LsdState& S, int addr0, std::vector<RegionPoint>& reg, double& reg_angle, double prec)
 {
     const int W = S.w, H = S.h;
@@ -88,8 +93,11 @@ static void region_grow(LsdState& S, int addr0, std::vector<RegionPoint>& reg, d
                     S.used[c_addr] = 1;
                     const double angle = S.angles[c_addr];
                     reg.push_back({xx, yy, angle, S.modgrad[c_addr]});
-                    sumdx += std::cos((double)float(angle));   // convention C.6: double libm, rounded by the float +=
-                    sumdy += std::sin((double)float(angle));
+                    if (t_libm_float) { sumdx += cosf(float(angle)); sumdy += sinf(float(angle)); }      // convention C.6, float overloads
+                    else {
+                        sumdx += std::cos((double)float(angle));   // convention C.6: double libm, rounded by the float +=
+                        sumdy += std::sin((double)float(angle));
+                    }
                     reg_angle = fastAtan2(sumdy, sumdx) * DEG_TO_RADS;
                 }
             }
@@ -360,6 +368,7 @@ static double rect_improve(const LsdState& S, Rect& rec, double LOG_NT, double L
 // blurred + upsampled image, for stage-wise comparison.
 void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>& lines, Image* scaled_out, std::vector<int>* region_sizes)
 {
+    LibmScope libm_scope(P.conv_libm_float);
     lines.clear();
     const double SCALE = P.lsd_scale, SIGMA_SCALE = P.lsd_sigma_scale, QUANT = P.lsd_quant, ANG_TH = P.lsd_ang_th;
     const int N_BINS = P.lsd_n_bins;
@@ -486,7 +495,8 @@ void make_keylines(const std::vector<Vec4f>& segs, int cols, int rows, double mi
         // cv::LineIterator(img, Point2f, Point2f).count : end points rounded (cvRound), 8-connected
         const int x1 = cvRoundf(e[0]), y1 = cvRoundf(e[1]), x2 = cvRoundf(e[2]), y2 = cvRoundf(e[3]);
         kl.numOfPixels = std::max(std::abs(x2 - x1), std::abs(y2 - y1)) + 1;
-        kl.angle = (float)std::atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
+        kl.angle = t_libm_float ? atan2f(kl.endPointY - kl.startPointY, kl.endPointX - kl.startPointX)      // convention C.6
+                                : (float)std::atan2((double)(kl.endPointY - kl.startPointY), (double)(kl.endPointX - kl.startPointX));
         kl.class_id = ++class_counter;
         kl.octave = 0;
         kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
@@ -553,8 +563,8 @@ void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, s
         const float lineMiddlePointX = (float)(0.5 * (kl.sPointInOctaveX + kl.ePointInOctaveX));
         const float lineMiddlePointY = (float)(0.5 * (kl.sPointInOctaveY + kl.ePointInOctaveY));
         float dL[2], dO[2];
-        dL[0] = (float)std::cos((double)kl.angle);   // osl.direction = kl.angle; convention C.6
-        dL[1] = (float)std::sin((double)kl.angle);
+        if (t_libm_float) { dL[0] = cosf(kl.angle); dL[1] = sinf(kl.angle); }      // osl.direction = kl.angle; convention C.6
+        else { dL[0] = (float)std::cos((double)kl.angle); dL[1] = (float)std::sin((double)kl.angle); }
         dO[0] = -dL[1]; dO[1] = dL[0];
         float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
         float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
@@ -624,8 +634,11 @@ void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, s
             tempM += d[0] * d[0]; tempM += d[1] * d[1]; tempM += d[2] * d[2]; tempM += d[3] * d[3];
             tempS += d[4] * d[4]; tempS += d[5] * d[5]; tempS += d[6] * d[6]; tempS += d[7] * d[7];
         }
-        tempM = (float)(1 / std::sqrt((double)tempM));   // convention C.6: double sqrt, double divide
-        tempS = (float)(1 / std::sqrt((double)tempS));
+        if (t_libm_float) { tempM = 1 / sqrtf(tempM); tempS = 1 / sqrtf(tempS); }      // convention C.6: float sqrt, float divide
+        else {
+            tempM = (float)(1 / std::sqrt((double)tempM));   // convention C.6: double sqrt, double divide
+            tempS = (float)(1 / std::sqrt((double)tempS));
+        }
         for (int b = 0; b < NUM_OF_BANDS; ++b) {
             float* d = desVec + 8 * b;
             d[0] = d[0] * tempM; d[1] = d[1] * tempM; d[2] = d[2] * tempM; d[3] = d[3] * tempM;
@@ -635,7 +648,7 @@ void lbd_compute(const Image& image, const std::vector<olf_keyline>& keylines, s
             if (desVec[i] > 0.4) desVec[i] = (float)0.4;
         float temp = 0;
         for (int i = 0; i < 72; ++i) temp += desVec[i] * desVec[i];
-        temp = (float)(1 / std::sqrt((double)temp));
+        temp = t_libm_float ? 1 / sqrtf(temp) : (float)(1 / std::sqrt((double)temp));
         for (int i = 0; i < 72; ++i) desVec[i] = desVec[i] * temp;
         if (float_desc) std::memcpy(&(*float_desc)[(size_t)li * 72], desVec, sizeof(desVec));
         // binaryConversion over the 32 band pairs
@@ -659,6 +672,7 @@ struct sort_lines_by_response {
 void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort, std::vector<olf_keyline>& kls, std::vector<uint8_t>& desc,
                   std::vector<olf_keyline>* all_detected)
 {
+    LibmScope libm_scope(P.conv_libm_float);
     std::vector<Vec4f> segs;
     const auto t0 = std::chrono::steady_clock::now();
     lsd_detect(img, P, segs, nullptr, nullptr);
@@ -680,6 +694,13 @@ void line_extract(const Image& img, const olf_line_params& P, bool use_std_sort,
 }  // namespace orc
 
 using namespace orc;
+// test hook for the OpenCV fixtures (opencv34_lineiterator.npz): cv::LineIterator(img, Point2f, Point2f).count as make_keylines computes it
+extern "C" int orc_line_iterator_count(float x1f, float y1f, float x2f, float y2f, int /*w*/, int /*h*/)
+{
+    const int x1 = orc::cvRoundf(x1f), y1 = orc::cvRoundf(y1f), x2 = orc::cvRoundf(x2f), y2 = orc::cvRoundf(y2f);
+    return std::max(std::abs(x2 - x1), std::abs(y2 - y1)) + 1;
+}
+
 extern "C" {
 
 // raw LSD segments (x1,y1,x2,y2 floats) + optional scaled image (dims via sw/sh) + region sizes

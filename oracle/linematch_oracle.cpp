@@ -145,7 +145,8 @@ void stereo_lines(const std::vector<olf_keyline>& klL, const uint8_t* descL, con
         const double ep_l[3] = {klL[i1].endPointX, klL[i1].endPointY, 1.0};
         double le_l[3] = {sp_l[1] * ep_l[2] - sp_l[2] * ep_l[1], sp_l[2] * ep_l[0] - sp_l[0] * ep_l[2], sp_l[0] * ep_l[1] - sp_l[1] * ep_l[0]};
         const double nrm = std::sqrt(le_l[0] * le_l[0] + le_l[1] * le_l[1]);
-        le_l[0] = le_l[0] / nrm; le_l[1] = le_l[1] / nrm; le_l[2] = le_l[2] / nrm;
+        if (P.conv_eigen_recip) { const double inv = 1.0 / nrm; le_l[0] = le_l[0] * inv; le_l[1] = le_l[1] * inv; le_l[2] = le_l[2] * inv; }      // Eigen 3.0 / 3.1: v / s = v * (1 / s)
+        else { le_l[0] = le_l[0] / nrm; le_l[1] = le_l[1] / nrm; le_l[2] = le_l[2] / nrm; }
         double sp_r[3] = {klR[i2].startPointX, klR[i2].startPointY, 1.0};
         double ep_r[3] = {klR[i2].endPointX, klR[i2].endPointY, 1.0};
         const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], P.line_horiz_th);

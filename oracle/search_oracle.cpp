@@ -612,6 +612,16 @@ static void r3_mul_add(const float* R9, const float* v, const float* t3, float o
     }
 }
 
+// test hook for the OpenCV fixtures (tests/test_oracle_cpu.py, opencv34_gemm.npz): the two CV_32F product forms of convention C.12 on one 3x3 matrix --
+// out1 = R * x + t (small-matrix path), out2 = -R.t() * t (transposed operand, generic path)
+extern "C" void orc_gemm3_check(const float* R9, const float* x3, const float* t3, float* out1, float* out2)
+{
+    r3_mul_add(R9, x3, t3, out1);
+    float Rt[9];
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Rt[3 * r + k] = R9[3 * k + r];
+    r3_mul_add(Rt, t3, nullptr, out2, -1.0, true);
+}
+
 // src/ORBmatcher.cc:985-989: Scw -> Rcw, tcw, Ow
 extern "C" void orc_sim3_decompose(const float* Scw /*4x4 row-major*/, float* Rcw9, float* tcw3, float* Ow3)
 {

@@ -35,13 +35,15 @@ class LineParams(C.Structure):
     _fields_ = [("lsd_nfeatures", C.c_int32), ("min_line_length", C.c_double), ("lsd_refine", C.c_int32),
                 ("lsd_scale", C.c_double), ("lsd_sigma_scale", C.c_double), ("lsd_quant", C.c_double),
                 ("lsd_ang_th", C.c_double), ("lsd_log_eps", C.c_double), ("lsd_density_th", C.c_double),
-                ("lsd_n_bins", C.c_int32), ("conv_gauss_sum256", C.c_int32), ("conv_resize_exact", C.c_int32), ("conv_seed_order", C.c_int32)]
+                ("lsd_n_bins", C.c_int32), ("conv_gauss_sum256", C.c_int32), ("conv_resize_exact", C.c_int32), ("conv_seed_order", C.c_int32),
+                ("conv_libm_float", C.c_int32)]
 
 
 class StereoParams(C.Structure):
     _fields_ = [("fx", C.c_float), ("bf", C.c_float), ("matching_s_ws", C.c_int32), ("line_sim_th", C.c_double),
                 ("min_ratio_12_l", C.c_double), ("min_disp", C.c_double), ("line_horiz_th", C.c_double),
-                ("stereo_overlap_th", C.c_double), ("ls_min_disp_ratio", C.c_double), ("best_lr_matches", C.c_int32)]
+                ("stereo_overlap_th", C.c_double), ("ls_min_disp_ratio", C.c_double), ("best_lr_matches", C.c_int32),
+                ("conv_eigen_recip", C.c_int32)]
 
 
 class OlfParams(C.Structure):

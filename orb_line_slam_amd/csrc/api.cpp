@@ -93,10 +93,11 @@ struct AngleTables { float* angDeg = nullptr; void* angEnt = nullptr; int refs =
 std::mutex g_tab_mu;
 std::map<int, AngleTables> g_tabs;
 
-int angle_tables_acquire(int device, LineDeviceBufs& l, hipStream_t s)
+// (one table per device AND per convention C.6 variant: the entries' cos / sin differ between them)
+int angle_tables_acquire(int device, int libmFloat, LineDeviceBufs& l, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    AngleTables& t = g_tabs[device];
+    AngleTables& t = g_tabs[device * 2 + (libmFloat ? 1 : 0)];
     if (t.refs == 0) {
         if (hipMalloc(&t.angDeg, sizeof(float) << 22) != hipSuccess || hipMalloc(&t.angEnt, (size_t)32 << 22) != hipSuccess) {
             (void)hipFree(t.angDeg); (void)hipFree(t.angEnt);
@@ -105,7 +106,7 @@ int angle_tables_acquire(int device, LineDeviceBufs& l, hipStream_t s)
             return OLF_ERR_HIP;
         }
         l.angDeg = t.angDeg; l.angEnt = t.angEnt;
-        if (launch_lsd_angle_table(l, s) != OLF_OK || hipStreamSynchronize(s) != hipSuccess) {
+        if (launch_lsd_angle_table(l, libmFloat, s) != OLF_OK || hipStreamSynchronize(s) != hipSuccess) {
             (void)hipFree(t.angDeg); (void)hipFree(t.angEnt);
             t = AngleTables();
             set_error("LSD angle table build failed");
@@ -117,10 +118,10 @@ int angle_tables_acquire(int device, LineDeviceBufs& l, hipStream_t s)
     return OLF_OK;
 }
 
-void angle_tables_release(int device)
+void angle_tables_release(int device, int libmFloat)
 {
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    auto it = g_tabs.find(device);
+    auto it = g_tabs.find(device * 2 + (libmFloat ? 1 : 0));
     if (it == g_tabs.end() || it->second.refs <= 0) return;
     if (--it->second.refs == 0) {
         (void)hipFree(it->second.angDeg); (void)hipFree(it->second.angEnt);
@@ -205,7 +206,7 @@ int olf_default_params(olf_params* p)
 void olf_ctx_destroy(olf_ctx* c)
 {
     if (!c) return;
-    if (c->has_tables) angle_tables_release(c->device);
+    if (c->has_tables) angle_tables_release(c->device, c->params.line.conv_libm_float);
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -264,7 +265,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
         return fail(OLF_ERR_HIP);
     }
     // ---- line side ----
-    rc = c->line.build(p->line, width, height);
+    rc = c->line.build(p->line, width, height, max_images);
     if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
     const LineGeom& lg = c->line.geom;
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
@@ -296,7 +297,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (hipMemcpy(l.rx, c->line.rx.data(), c->line.rx.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.ry, c->line.ry.data(), c->line.ry.size() * sizeof(ResizeCoef), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(l.geom, &lg, sizeof(LineGeom), hipMemcpyHostToDevice) != hipSuccess) { set_error("line table upload failed"); return fail(OLF_ERR_HIP); }
-    if ((rc = angle_tables_acquire(c->device, l, c->stream)) != OLF_OK) return fail(rc);
+    if ((rc = angle_tables_acquire(c->device, p->line.conv_libm_float, l, c->stream)) != OLF_OK) return fail(rc);
     c->has_tables = true;
     *out = c;
     return OLF_OK;

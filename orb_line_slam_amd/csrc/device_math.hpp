@@ -144,4 +144,96 @@ OLF_HD float glibc_sincosf_core(float y, int want_cos)
 OLF_HD float glibc_cosf(float y) { return glibc_sincosf_core(y, 1); }
 OLF_HD float glibc_sinf(float y) { return glibc_sincosf_core(y, 0); }
 
+// ---- glibc's atan2f (2.35: the fdlibm float code, sysdeps/ieee754/flt-32/e_atan2f.c + s_atanf.c): only float mul / add / sub / div, no fused
+// operations (x86-64 glibc carries no FMA variant of it), so a restatement with the same constants and the same operation order gives the same bits.
+// Convention C.6, variant conv_libm_float = 1 (KeyLine.angle = atan2(dy, dx) on floats resolving to the float overload).  Arguments here are finite
+// and not both zero-or-huge, but every branch of the original is kept.  tests/test_host_cpu.py sweeps it against this box's libm.
+OLF_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+OLF_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+OLF_HD float glibc_atanf(float x)
+{
+    // (the decimal literals of the source, converted double -> float as the C compiler does; the hexadecimal comments of fdlibm are not all exact)
+    const float atanhi0 = (float)4.6364760399e-01, atanhi1 = (float)7.8539812565e-01, atanhi2 = (float)9.8279368877e-01, atanhi3 = (float)1.5707962513e+00;
+    const float atanlo0 = (float)5.0121582440e-09, atanlo1 = (float)3.7748947079e-08, atanlo2 = (float)3.4473217170e-08, atanlo3 = (float)7.5497894159e-08;
+    const float aT0 = (float)3.3333334327e-01, aT1 = (float)-2.0000000298e-01, aT2 = (float)1.4285714924e-01, aT3 = (float)-1.1111110449e-01,
+                aT4 = (float)9.0908870101e-02, aT5 = (float)-7.6918758452e-02, aT6 = (float)6.6610731184e-02, aT7 = (float)-5.8335702866e-02,
+                aT8 = (float)4.9768779427e-02, aT9 = (float)-3.6531571299e-02, aT10 = (float)1.6285819933e-02;
+    const int32_t hx = (int32_t)f2bits(x);
+    const int32_t ix = hx & 0x7fffffff;
+    int id;
+    float hi = 0.f, lo = 0.f;
+    if (ix >= 0x4c000000) {                          // |x| >= 2^25
+        if (ix > 0x7f800000) return f_add(x, x);     // NaN
+        if (hx > 0) return f_add(atanhi3, atanlo3);
+        return f_sub(-atanhi3, atanlo3);
+    }
+    if (ix < 0x3ee00000) {                           // |x| < 0.4375
+        if (ix < 0x31000000) return x;               // |x| < 2^-29
+        id = -1;
+    } else {
+        x = bits2f((uint32_t)ix);                    // fabsf
+        if (ix < 0x3f980000) {                       // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; hi = atanhi0; lo = atanlo0; x = f_div(f_sub(f_mul(2.0f, x), 1.0f), f_add(2.0f, x)); }      // 7/16 <= |x| < 11/16
+            else { id = 1; hi = atanhi1; lo = atanlo1; x = f_div(f_sub(x, 1.0f), f_add(x, 1.0f)); }                                    // 11/16 <= |x| < 19/16
+        } else {
+            if (ix < 0x401c0000) { id = 2; hi = atanhi2; lo = atanlo2; x = f_div(f_sub(x, 1.5f), f_add(1.0f, f_mul(1.5f, x))); }       // |x| < 2.4375
+            else { id = 3; hi = atanhi3; lo = atanlo3; x = f_div(-1.0f, x); }                                                           // 2.4375 <= |x| < 2^25
+        }
+    }
+    const float z = f_mul(x, x), w = f_mul(z, z);
+    const float s1 = f_mul(z, f_add(aT0, f_mul(w, f_add(aT2, f_mul(w, f_add(aT4, f_mul(w, f_add(aT6, f_mul(w, f_add(aT8, f_mul(w, aT10)))))))))));
+    const float s2 = f_mul(w, f_add(aT1, f_mul(w, f_add(aT3, f_mul(w, f_add(aT5, f_mul(w, f_add(aT7, f_mul(w, aT9)))))))));
+    if (id < 0) return f_sub(x, f_mul(x, f_add(s1, s2)));
+    const float r = f_sub(hi, f_sub(f_sub(f_mul(x, f_add(s1, s2)), lo), x));
+    return hx < 0 ? -r : r;
+}
+
+OLF_HD float glibc_atan2f(float y, float x)
+{
+    const float tiny = (float)1.0e-30, pi_o_4 = (float)7.8539818525e-01, pi_o_2 = (float)1.5707963705e+00, pi = (float)3.1415927410e+00, pi_lo = (float)-8.7422776573e-08;
+    const int32_t hx = (int32_t)f2bits(x), hy = (int32_t)f2bits(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return f_add(x, y);            // NaN
+    if (hx == 0x3f800000) return glibc_atanf(y);                             // x == 1.0
+    const int m = (int)(((uint32_t)hy >> 31) & 1u) | (int)(((uint32_t)hx >> 30) & 2u);      // 2 * sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+            case 0: case 1: return y;
+            case 2: return f_add(pi, tiny);
+            default: return f_sub(-pi, tiny);
+        }
+    }
+    if (ix == 0) return hy < 0 ? f_sub(-pi_o_2, tiny) : f_add(pi_o_2, tiny);
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return f_add(pi_o_4, tiny);
+                case 1: return f_sub(-pi_o_4, tiny);
+                case 2: return f_add(f_mul(3.0f, pi_o_4), tiny);
+                default: return f_sub(f_mul(-3.0f, pi_o_4), tiny);
+            }
+        } else {
+            switch (m) {
+                case 0: return 0.0f;
+                case 1: return -0.0f;
+                case 2: return f_add(pi, tiny);
+                default: return f_sub(-pi, tiny);
+            }
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? f_sub(-pi_o_2, tiny) : f_add(pi_o_2, tiny);
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = f_add(pi_o_2, f_mul(0.5f, pi_lo));
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = glibc_atanf(bits2f(f2bits(f_div(y, x)) & 0x7fffffffu));
+    switch (m) {
+        case 0: return z;
+        case 1: return bits2f(f2bits(z) ^ 0x80000000u);
+        case 2: return f_sub(pi, f_sub(z, pi_lo));
+        default: return f_sub(f_sub(z, pi_lo), pi);
+    }
+}
+
 }  // namespace olf

@@ -199,12 +199,13 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
 // Line side: constants of cv::LineSegmentDetector (OpenCV 3.4 lsd.cpp) as set up
 // by LSDDetectorC::detectImpl (Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:246-253) and the
 // LBD weights of BinaryDescriptor (binary_descriptor_custom.cpp:217-259).
-int LineHostTables::build(const olf_line_params& p, int W, int H)
+int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images)
 {
     LineGeom& g = geom;
     g = LineGeom();
     if (p.lsd_refine < 0 || p.lsd_refine > 2) return OLF_ERR_INVALID;        // LSD_REFINE_NONE / STD / ADV
     if (p.conv_seed_order != 0 && p.conv_seed_order != 1) return OLF_ERR_INVALID;
+    if (p.conv_libm_float != 0 && p.conv_libm_float != 1) return OLF_ERR_INVALID;
     if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
     g.W = W; g.H = H; g.pitchW = (W + 63) & ~63; g.pitchD = (W + 3) & ~3;
@@ -221,6 +222,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
         const unsigned long long M = ((1ull << p) + (unsigned long long)g.Ws - 1) / (unsigned long long)g.Ws;
         g.divWsM = (uint32_t)M; g.divWsS = p - 32;
     }
+    g.libmFloat = p.conv_libm_float ? 1 : 0;
     g.alignDeg = p.lsd_ang_th < 90 ? (float)(180.0 - p.lsd_ang_th) : -1.f;      // (tolerances of 90 degrees and more: the folded form does not hold, k_lsd_keys decides in double)
     g.regionStride = std::max(1024 + g.Ps / 32 + 64, (2 * g.Ps + 31) / 32) * 32;
     if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
@@ -241,7 +243,11 @@ int LineHostTables::build(const olf_line_params& p, int W, int H)
     g.minRegSize = int(-LOG_NT / std::log10(pp));
     g.logNT = LOG_NT; g.logEps = p.lsd_log_eps; g.pProb = pp;
     g.minLength = p.min_line_length * std::min(W, H);
-    g.maxDetect = std::min(8192, std::max(4096, g.Ps / 256));       // raw segments kept per image before the top-N (k_line_select sorts them in LDS)
+    // raw segments kept per image before the top-N: a region owns at least minRegSize pixels, and only noise comes near one segment per 48 pixels
+    // (round 3's 4096 / 8192 refused pure noise at lsd_scale 2; k_line_select sorts lists beyond 8192 in global memory)
+    g.maxDetect = std::min(32768, std::max(4096, g.Ps / 48));
+    // lsd_nfeatures = 0 keeps every segment: the LBD row sums (63 x 16 bytes per kept line) then scale with maxDetect -- a big batch keeps round 3's capacity
+    if (p.lsd_nfeatures == 0) g.maxDetect = std::min(g.maxDetect, std::max(4096, (int)(16e9 / ((double)std::max(max_images, 1) * 63 * 16))));
     // 16-byte region records alias the unsorted key buffer, 24-byte segment candidates the sorted one (4 bytes per pixel each)
     g.maxRegions = std::min(g.Ps / std::max(g.minRegSize, 1) + 1, g.Ps / 6 - 1);
     g.rectGrid = g.maxRegions;

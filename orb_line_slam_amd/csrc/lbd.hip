@@ -18,8 +18,30 @@ __constant__ int8_t c_bandPairs[64] = {
 };
 
 // ---------------------------------------------------------------------------------------------
+constexpr int LS_LDS_KEYS = 8192;      // raw segments whose sort keys fit the 64 KB of LDS a launch may ask for without a function attribute
+
+// bitonic sort of sortN 64-bit keys, descending, by one 256-thread workgroup; `sk` in LDS or -- a list too long for it (noise images, lsd_scale 2) --
+// in a per-image slice of global memory (all waves of a workgroup share their CU's L1, so a barrier orders their global accesses too)
+template <typename P>
+__device__ __forceinline__ void ls_bitonic_desc(P sk, int sortN, int tid)
+{
+    for (int k = 2; k <= sortN; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < sortN; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = sk[i], b = sk[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) { sk[i] = b; sk[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
 __global__ __launch_bounds__(256) void k_line_select(const LineGeom* __restrict__ gp, const olf_keyline* __restrict__ rawLines,
-                                                     const int* __restrict__ rawCount, olf_keyline* __restrict__ kls, int* __restrict__ counts)
+                                                     const int* __restrict__ rawCount, olf_keyline* __restrict__ kls, int* __restrict__ counts,
+                                                     unsigned long long* __restrict__ scratchAll, size_t scratchStride)
 {
     extern __shared__ unsigned long long skeys[];
     const LineGeom& g = *gp;
@@ -35,26 +57,17 @@ __global__ __launch_bounds__(256) void k_line_select(const LineGeom* __restrict_
     }
     int sortN = 64;
     while (sortN < R) sortN <<= 1;
+    const bool inLds = sortN <= LS_LDS_KEYS;          // (wave-uniform)
+    unsigned long long* gk = scratchAll + (size_t)img * scratchStride;
     for (int i = tid; i < sortN; i += 256) {
         unsigned long long k = 0;
         if (i < R) k = ((unsigned long long)__float_as_uint(raw[i].response) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-        skeys[i] = k;   // responses are >= 0, so the float bit pattern orders like the value
+        if (inLds) skeys[i] = k; else gk[i] = k;   // responses are >= 0, so the float bit pattern orders like the value
     }
     __syncthreads();
-    for (int k = 2; k <= sortN; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < sortN; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = skeys[i], b = skeys[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < b) : (a > b)) { skeys[i] = b; skeys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    if (inLds) ls_bitonic_desc(skeys, sortN, tid); else ls_bitonic_desc(gk, sortN, tid);
     for (int i = tid; i < g.nFeatures; i += 256) {
-        const unsigned idx = 0xffffffffu - (unsigned)(skeys[i] & 0xffffffffull);
+        const unsigned idx = 0xffffffffu - (unsigned)((inLds ? skeys[i] : gk[i]) & 0xffffffffull);
         olf_keyline kl = raw[idx];
         kl.class_id = i;
         out[i] = kl;
@@ -126,7 +139,9 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
     const short imageWidth = (short)(g.W - 1), imageHeight = (short)(g.H - 1);
     const float midX = (float)(0.5 * (double)f_add(kl.sPointInOctaveX, kl.ePointInOctaveX));
     const float midY = (float)(0.5 * (double)f_add(kl.sPointInOctaveY, kl.ePointInOctaveY));
-    const float dL0 = (float)cos((double)kl.angle), dL1 = (float)sin((double)kl.angle);   // convention C.6
+    // convention C.6: the C functions on doubles, or the float overloads (glibc's cosf / sinf bit for bit, device_math.hpp; kl.angle lies in [-pi, pi])
+    const float dL0 = g.libmFloat ? glibc_cosf(kl.angle) : (float)cos((double)kl.angle);
+    const float dL1 = g.libmFloat ? glibc_sinf(kl.angle) : (float)sin((double)kl.angle);
     const float dO0 = -dL1, dO1 = dL0;
     float sCorX0 = f_add(f_add(f_mul(-dL0, (float)halfWidth), f_mul(dL1, (float)halfHeight)), midX);
     float sCorY0 = f_add(f_sub(f_mul(-dL1, (float)halfWidth), f_mul(dL0, (float)halfHeight)), midY);
@@ -231,8 +246,8 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const LineGeom* __restrict__ gp
 #pragma unroll
         for (int k = 4; k < 8; ++k) tempS = f_add(tempS, f_mul(d[8 * b + k], d[8 * b + k]));
     }
-    tempM = (float)(1 / sqrt((double)tempM));
-    tempS = (float)(1 / sqrt((double)tempS));
+    if (g.libmFloat) { tempM = f_div(1.0f, sqrtf(tempM)); tempS = f_div(1.0f, sqrtf(tempS)); }      // convention C.6: float sqrt, float divide
+    else { tempM = (float)(1 / sqrt((double)tempM)); tempS = (float)(1 / sqrt((double)tempS)); }
 #pragma unroll
     for (int b = 0; b < 9; ++b) {
 #pragma unroll
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const LineGeom* __restrict__ gp
     float temp = 0;
 #pragma unroll
     for (int i = 0; i < 72; ++i) temp = f_add(temp, f_mul(d[i], d[i]));
-    temp = (float)(1 / sqrt((double)temp));
+    temp = g.libmFloat ? f_div(1.0f, sqrtf(temp)) : (float)(1 / sqrt((double)temp));
 #pragma unroll
     for (int i = 0; i < 72; ++i) d[i] = f_mul(d[i], temp);
     uint8_t* o = desc + ((size_t)img * g.outCap + li) * OLF_DESC_BYTES;
@@ -270,8 +285,10 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
 {
     int sortN = 64;
     while (sortN < g.maxDetect) sortN <<= 1;
-    hipLaunchKernelGGL(k_line_select, dim3(n_images), dim3(256), sortN * sizeof(unsigned long long), s, b.geom, b.rawLines, b.rawCount, d_kls,
-                       d_counts);
+    // (longer lists than LS_LDS_KEYS are sorted in the key buffer, which is dead once the segments have been emitted: 4 Ps bytes per image, and
+    // maxDetect <= Ps / 48 keeps 8 bytes x the next power of two below that)
+    hipLaunchKernelGGL(k_line_select, dim3(n_images), dim3(256), std::min(sortN, LS_LDS_KEYS) * sizeof(unsigned long long), s, b.geom, b.rawLines, b.rawCount, d_kls,
+                       d_counts, reinterpret_cast<unsigned long long*>(b.keysA), (size_t)g.Ps / 2);
     // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel)
     OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
     hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);

@@ -46,6 +46,7 @@ struct LineGeom {
     int refine;                // lsd_refine: 0 LSD_REFINE_NONE, 1 LSD_REFINE_STD (density check, second growth, reduce_region_radius inside the agent)
     double densityTh;          // lsd_density_th
     double logNT, logEps, pProb;   // LSD_REFINE_ADV: 5 (log10 Ws + log10 Hs) / 2 + log10 11 (host libm), lsd_log_eps, ang_th / 180
+    int libmFloat;             // convention C.6 (conv_libm_float): 1 = the float overloads of cos / sin / atan2 / sqrt inside LSD / KeyLine / LBD
     uint32_t divWsM; int divWsS; // idx / Ws for 0 <= idx < 2^22 without a division: __umulhi(idx, divWsM) >> divWsS (exact: host_tables.cpp)
     float alignDeg;            // 180 - lsd_ang_th as a float: two level-line angles (degrees) a, b are aligned <=> | |a - b| - 180 | >= alignDeg (decided exactly in double near the boundary)
     int regionStride;          // 32-bit words per image of LineDeviceBufs::region: ONE stride for both pixel-list formats (chunk chains of the multi-wave growth: regionStride / 32
@@ -92,7 +93,7 @@ struct LineDeviceBufs {
 struct LineHostTables {
     LineGeom geom;
     std::vector<ResizeCoef> rx, ry;
-    int build(const olf_line_params& p, int W, int H);
+    int build(const olf_line_params& p, int W, int H, int max_images = 2);
 };
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s);
@@ -104,7 +105,7 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
                     uint8_t* d_desc, const int* d_counts, hipStream_t s);
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,
                       const LineGeom& g, int which, int n_images, hipStream_t s);
-int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s);
+int launch_lsd_angle_table(LineDeviceBufs& b, int libmFloat, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void k_lines_resolve(const olf_keyline* __rest
         // le_l = sp_l x ep_l, normalised by its first two components
         double c0 = d_sub(spl1, epl1), c1 = d_sub(epl0, spl0), c2 = d_sub(d_mul(spl0, epl1), d_mul(spl1, epl0));
         const double nrm = sqrt(d_add(d_mul(c0, c0), d_mul(c1, c1)));
-        c0 = c0 / nrm; c1 = c1 / nrm; c2 = c2 / nrm;
+        if (P.conv_eigen_recip) { const double inv = 1.0 / nrm; c0 = d_mul(c0, inv); c1 = d_mul(c1, inv); c2 = d_mul(c2, inv); }      // Eigen 3.0 / 3.1: v / s = v * (1 / s)
+        else { c0 = c0 / nrm; c1 = c1 / nrm; c2 = c2 / nrm; }
         double spr0 = b.startPointX, spr1 = b.startPointY, epr0 = b.endPointX, epr1 = b.endPointY;
         // lineSegmentOverlapStereo(sp_l(1), ep_l(1), sp_r(1), ep_r(1))
         double overlap = 1.0;

@@ -332,7 +332,7 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 // context over the packed 22-bit (gx:11 | gy:11) field of the gradient word -- 84 MB, image independent, shared by every agent; real
 // images touch a small, L2 / Infinity-Cache resident part of it.  This takes fastAtan2 and the double sincos out of the agent's
 // per-iteration instruction stream (the agent is VALU-issue bound), at the price of one more dependent load.
-__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, AngEnt* __restrict__ ent)
+__global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ angDeg, AngEnt* __restrict__ ent, int libmFloat)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const int gx = unpack_gx(i), gy = unpack_gy(i);
@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ ang
     const double ang = d_mul((double)deg, kDegToRads);
     double sn, cs;
     sincos_2pi((double)(float)ang, &sn, &cs);
+    // convention C.6, float overloads: what region_grow adds is cosf / sinf of the float angle (glibc's, bit for bit: device_math.hpp); a float added
+    // to the float sum is the same as its double added and rounded once, so the entry keeps its layout
+    if (libmFloat) { cs = (double)glibc_cosf((float)ang); sn = (double)glibc_sinf((float)ang); }
     angDeg[i] = deg;
     // region_grow starts its sums at float(cos(reg_angle)), float(sin(reg_angle)) with the seed's angle as a double
     double s0, c0;
@@ -348,9 +351,9 @@ __global__ __launch_bounds__(256) void k_lsd_angle_table(float* __restrict__ ang
     ent[i] = e;
 }
 
-int launch_lsd_angle_table(LineDeviceBufs& b, hipStream_t s)
+int launch_lsd_angle_table(LineDeviceBufs& b, int libmFloat, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, reinterpret_cast<AngEnt*>(b.angEnt));
+    hipLaunchKernelGGL(k_lsd_angle_table, dim3((1u << 22) / 256), dim3(256), 0, s, b.angDeg, reinterpret_cast<AngEnt*>(b.angEnt), libmFloat);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
@@ -1323,7 +1326,7 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
                 kl.lineLength = c.length;
                 const int rx1 = __float2int_rn(e0), ry1 = __float2int_rn(e1), rx2 = __float2int_rn(e2), ry2 = __float2int_rn(e3);
                 kl.numOfPixels = max(abs(rx2 - rx1), abs(ry2 - ry1)) + 1;
-                kl.angle = (float)atan2((double)f_sub(e3, e1), (double)f_sub(e2, e0));
+                kl.angle = g.libmFloat ? glibc_atan2f(f_sub(e3, e1), f_sub(e2, e0)) : (float)atan2((double)f_sub(e3, e1), (double)f_sub(e2, e0));      // convention C.6
                 kl.class_id = pos; kl.octave = 0;
                 kl.size = f_mul(f_sub(e2, e0), f_sub(e3, e1));
                 kl.response = f_div(kl.lineLength, (float)max(g.W, g.H));

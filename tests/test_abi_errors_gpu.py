@@ -68,24 +68,47 @@ def test_bad_arguments_are_reported():
     assert L.olf_orb_extract(ctx.handle, _p(np.full((1, 480, 640), 50, np.uint8)), 1, _p(k), _p(dd), _p(c)) == OLF_OK and c[0] == 0
 
 
-def test_async_overflow_is_reported():
-    """a *_dev call that overflows a device buffer (pure noise: more raw segments than the per-image capacity) does not fail by itself --
-    it is asynchronous -- but the next olf_ctx_synchronize / olf_ctx_poll_status reports it, once"""
+def test_noise_beyond_the_old_segment_capacity_and_async_overflow_report(oracle):
+    """Pure noise at lsd_scale 2 gives 9105 raw segments: rounds 1-3 refused it at run time (capacity 4096 / 8192, fuzz configuration #678).  The raw list is
+    now sized by the working image (Ps / 48) and k_line_select sorts lists beyond its 64 KB of LDS in global memory: the top 100 must equal the oracle's.
+    Then the asynchronous error report itself: a *_dev call that overflows a device buffer (here: a record buffer that is too small) does not fail by
+    itself, the next olf_ctx_synchronize / olf_ctx_poll_status reports it -- once."""
     import torch
     L = _lib.lib()
     p = _lib.default_params()
     p.line.lsd_scale, p.line.min_line_length, p.line.lsd_quant, p.line.lsd_nfeatures = 2.0, 0.0, 1.0, 100
     w, h = 620, 470
-    ctx = _lib.Context(p, w, h, 1)
+    ctx = _lib.Context(p, w, h, 2)
     rng = np.random.default_rng(3)
-    img = torch.from_numpy(rng.integers(0, 256, (1, h, w), dtype=np.uint8)).cuda()
+    img_h = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+    img = torch.from_numpy(img_h).cuda()
     lcap = ctx.line_capacity
-    kls = torch.zeros(lcap * _lib.KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
-    desc = torch.zeros(lcap * 32, dtype=torch.uint8, device="cuda")
-    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-    rc = L.olf_line_extract_dev(ctx.handle, C.c_void_p(img.data_ptr()), 1, C.c_void_p(kls.data_ptr()), C.c_void_p(desc.data_ptr()),
+    kls = torch.zeros(2 * lcap * _lib.KEYLINE_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    desc = torch.zeros(2 * lcap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rc = L.olf_line_extract_dev(ctx.handle, C.c_void_p(img.data_ptr()), 2, C.c_void_p(kls.data_ptr()), C.c_void_p(desc.data_ptr()),
                                 C.c_void_p(cnt.data_ptr()), None)
     assert rc == OLF_OK
+    assert L.olf_ctx_synchronize(ctx.handle) == OLF_OK, L.olf_last_error()
+    got = kls.cpu().numpy().view(_lib.KEYLINE_DTYPE).reshape(2, lcap)
+    gd = desc.cpu().numpy().reshape(2, lcap, 32)
+    for i in range(2):
+        o = oracle.line_extract(img_h[i], p.line)
+        assert int(cnt[i]) == len(o["kls"]) == 100
+        assert np.array_equal(got[i, :100], o["kls"]) and np.array_equal(gd[i, :100], o["desc"])
+    # an overflow is reported by the next synchronize, once
+    cap = ctx.orb_capacity
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+    t = {"kps": z((2, cap, 28), torch.uint8), "desc": z((2, cap, 32), torch.uint8), "counts": z((2,), torch.int32), "uright": z((1, cap), torch.float32),
+         "depth": z((1, cap), torch.float32), "kls": z((2, lcap, 68), torch.uint8), "ldesc": z((2, lcap, 32), torch.uint8), "lcounts": z((2,), torch.int32),
+         "lmatches12": z((1, lcap), torch.int32), "ldisp": z((1, lcap, 2), torch.float32), "lle": z((1, lcap, 3), torch.float64)}
+    fb = _lib.FrameBuffers(*[t[k].data_ptr() for k in ("kps", "desc", "counts", "uright", "depth", "kls", "ldesc", "lcounts", "lmatches12", "ldisp", "lle")])
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.olf_stereo_frames_dev(ctx.handle, C.c_void_p(img.data_ptr()), 1, C.byref(fb), C.c_void_p(s)) == OLF_OK
+    small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    nbytes = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert L.olf_frames_pack_dev(ctx.handle, C.byref(fb), 1, C.c_void_p(small.data_ptr()), 2048, C.c_void_p(nbytes.data_ptr()), C.c_void_p(s)) == OLF_OK     # asynchronous: no error yet
+    torch.cuda.synchronize()
     assert L.olf_ctx_synchronize(ctx.handle) == OLF_ERR_CAPACITY and b"overflow" in L.olf_last_error()
     assert L.olf_ctx_synchronize(ctx.handle) == OLF_OK                       # reported once, then cleared
     assert L.olf_ctx_poll_status(ctx.handle) == OLF_OK

