@@ -118,6 +118,122 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
     }
 }
 
+// ---- the same filter without LDS (round 4): one thread = a strip of 4 columns x SS_ROWS rows, everything in registers.  Per input row three dwords
+// (bytes x0-4 .. x0+7; rows of neighbouring strips overlap in L1 / L2), the 7-tap row sums of the four columns by v_dot4_u32_u8 on byte windows, row pairs
+// packed into dwords, the column sums by v_dot2_u32_u16 -- the arithmetic of k_sep7, 13 instead of 32 vector instructions per pixel: no staging pass, no
+// u16 round trip through LDS, no barriers (which also makes it a better guest beside the growth agents: a block's time is its own loads, nothing else).
+// BORDER_REFLECT_101 in y is an index computation per row; the strips whose window leaves the image in x (strip 0, strips beyond nsx) are a second, small
+// launch of the same kernel with a byte-wise row window (k_sep7_strip<true>).
+constexpr int SS_ROWS = 16;
+
+__device__ __forceinline__ int ss_reflect(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; }
+
+// BORDER: the strips whose window leaves the image -- strip 0 and the strips right of nsx -- with the row window assembled byte by byte under
+// BORDER_REFLECT_101 and the quad stored byte by byte; a separate small launch, so that no wave of the interior pays for it.
+template <bool BORDER>
+__global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, uint8_t* __restrict__ dst,
+                                                    size_t dstImgStride, int dstPitch, int W, int H, Taps7 taps, int nsx, int nsy)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int nb = BORDER ? 1 + ((W + 3) / 4 - (nsx + 1)) : nsx;      // strips per strip row of this launch
+    if (t >= nb * nsy) return;
+    const int sy = t / nb, si = t - sy * nb;
+    const int sx = BORDER ? (si == 0 ? 0 : nsx + si) : si + 1;
+    const int x0 = 4 * sx, y0 = sy * SS_ROWS;
+    const uint8_t* s = src + (size_t)blockIdx.y * srcImgStride + (x0 - 4);
+    uint8_t* d = dst + (size_t)blockIdx.y * dstImgStride + x0;
+    const uint32_t tlo = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
+    const uint32_t thi = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 8) | ((uint32_t)taps.t[6] << 16);
+    const uint32_t t01 = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 16), t23 = (uint32_t)taps.t[2] | ((uint32_t)taps.t[3] << 16);
+    const uint32_t t45 = (uint32_t)taps.t[4] | ((uint32_t)taps.t[5] << 16), t6lo = (uint32_t)taps.t[6], t6hi = (uint32_t)taps.t[6] << 16;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
+        us2 va, vb;
+        __builtin_memcpy(&va, &a, 4); __builtin_memcpy(&vb, &b, 4);
+        return __builtin_amdgcn_udot2(va, vb, c, false);
+    };
+    // one input row of the strip: 12 bytes x0-4 .. x0+7 of image row y (reflected into the image; rows beyond H + 2 only feed output rows that do not exist)
+    struct Raw { uint32_t w[3]; };
+    auto load_row = [&](int y) -> Raw {
+        Raw r;
+        const uint8_t* row = s + (size_t)ss_reflect(min(y, H + 2), H) * srcPitch;
+        if (!BORDER) __builtin_memcpy(r.w, row, 12);
+        else {
+            // (row points at column x0 - 4; columns beyond W + 2 only feed outputs that do not exist)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int x = x0 - 4 + 4 * k + b;
+                    v |= (uint32_t)row[ss_reflect(min(x, W + 2), W) - (x0 - 4)] << (8 * b);
+                }
+                r.w[k] = v;
+            }
+        }
+        return r;
+    };
+    // the 7-tap row sums (u16 range) of the strip's four columns: output x0 + p uses bytes p + 1 .. p + 7 of the 12
+    auto hrow = [&](const Raw& r, uint32_t* o) {
+        const uint32_t* w = r.w;
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[2], w[1], 1u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[1], w[0], 1u), tlo, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[2], w[1], 2u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[1], w[0], 2u), tlo, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[2], w[1], 3u), thi, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w[1], w[0], 3u), tlo, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(w[2], thi, __builtin_amdgcn_udot4(w[1], tlo, 0u, false), false);
+    };
+    // pair j = the row sums of image rows y0 - 3 + 2j (low half) and y0 - 2 + 2j (high half), per column
+    auto pair = [&](const Raw& ra, const Raw& rb, uint32_t* Pj) {
+        uint32_t a[4], b[4];
+        hrow(ra, a); hrow(rb, b);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Pj[c] = a[c] | (b[c] << 16);
+    };
+    uint32_t P[SS_ROWS / 2 + 3][4];
+    Raw nx[4];      // the four input rows of the NEXT group of output rows: requested one group ahead, so that their latency (and the acknowledgement of the
+                    // stores in between: one counter for both on this part) is covered by a group's arithmetic
+    {
+        Raw r0 = load_row(y0 - 3), r1 = load_row(y0 - 2), r2 = load_row(y0 - 1), r3 = load_row(y0), r4 = load_row(y0 + 1), r5 = load_row(y0 + 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nx[k] = load_row(y0 + 3 + k);
+        pair(r0, r1, P[0]); pair(r2, r3, P[1]); pair(r4, r5, P[2]);
+    }
+#pragma unroll
+    for (int g = 0; g < SS_ROWS / 4; ++g) {
+        // output rows y0 + 4g .. y0 + 4g + 3 need image rows y0 + 4g - 3 .. y0 + 4g + 6 = pairs 2g .. 2g + 4
+        const Raw c0 = nx[0], c1 = nx[1], c2 = nx[2], c3 = nx[3];
+        if (g + 1 < SS_ROWS / 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nx[k] = load_row(y0 + 4 * (g + 1) + 3 + k);
+            __builtin_amdgcn_sched_barrier(0);      // (the requests stay in front of the arithmetic below)
+        }
+        pair(c0, c1, P[2 * g + 3]); pair(c2, c3, P[2 * g + 4]);
+        uint32_t res[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t D0 = P[2 * g][c], D1 = P[2 * g + 1][c], D2 = P[2 * g + 2][c], D3 = P[2 * g + 3][c], D4 = P[2 * g + 4][c];
+            const uint32_t E0 = __builtin_amdgcn_alignbyte(D1, D0, 2u), E1 = __builtin_amdgcn_alignbyte(D2, D1, 2u);
+            const uint32_t E2 = __builtin_amdgcn_alignbyte(D3, D2, 2u), E3 = __builtin_amdgcn_alignbyte(D4, D3, 2u);
+            res[0][c] = dot2(D3, t6lo, dot2(D2, t45, dot2(D1, t23, dot2(D0, t01, 32768u))));
+            res[1][c] = dot2(D3, t6hi, dot2(E2, t45, dot2(E1, t23, dot2(E0, t01, 32768u))));
+            res[2][c] = dot2(D4, t6lo, dot2(D3, t45, dot2(D2, t23, dot2(D1, t01, 32768u))));
+            res[3][c] = dot2(D4, t6hi, dot2(E3, t45, dot2(E2, t23, dot2(E1, t01, 32768u))));
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int gy = y0 + 4 * g + rr;
+            if (gy < H) {
+                const uint32_t a0 = min(res[rr][0] >> 16, 255u), a1 = min(res[rr][1] >> 16, 255u), a2 = min(res[rr][2] >> 16, 255u), a3 = min(res[rr][3] >> 16, 255u);
+                const uint32_t v = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+                if (!BORDER) __builtin_memcpy(d + (size_t)gy * dstPitch, &v, 4);
+                else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) if (x0 + b < W) d[(size_t)gy * dstPitch + b] = (uint8_t)(v >> (8 * b));
+                }
+            }
+        }
+    }
+}
+
 int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
                 const int* taps7, int n_images, hipStream_t s)
 {
@@ -131,6 +247,15 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
     }
     for (int i = 0; i < 7; ++i)
         if (t.t[i] < 0 || t.t[i] > 255) { set_error("launch_sep7: taps must be 8-bit fractions"); return OLF_ERR_INVALID; }
+    // OLF_SEP7=0: the LDS-tiled kernel of rounds 1-3 (A/B measurements); images too small for a strip (or a reflection that would leave them) take it too
+    static const bool strips = [] { const char* e = getenv("OLF_SEP7"); return !e || atoi(e) != 0; }();
+    if (strips && W >= 16 && H >= 8 && (dstPitch & 3) == 0 && (dstImgStride & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        const int nsx = (W - 7) / 4, nsy = (H + SS_ROWS - 1) / SS_ROWS, nb = 1 + ((W + 3) / 4 - (nsx + 1));
+        hipLaunchKernelGGL(k_sep7_strip<false>, dim3((nsx * nsy + 255) / 256, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, t, nsx, nsy);
+        hipLaunchKernelGGL(k_sep7_strip<true>, dim3((nb * nsy + 255) / 256, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, t, nsx, nsy);
+        OLF_HIP_CHECK(hipGetLastError());
+        return OLF_OK;
+    }
     hipLaunchKernelGGL(k_sep7, dim3((W + SF_TW - 1) / SF_TW, (H + SF_TH - 1) / SF_TH, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch,
                        dst, dstImgStride, dstPitch, W, H, t);
     OLF_HIP_CHECK(hipGetLastError());
@@ -252,6 +377,101 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     }
 }
 
+// ---- the same resize without LDS (round 4): one thread = 4 output columns x RS_ROWS output rows, one wave per block so that the row bookkeeping is scalar.
+// The two source bytes of a column sit inside an 8-byte window that starts at the quad's first source column (host check: resize_strip_fits); a
+// v_perm_b32 puts them into the halves of a dword and one v_dot2_u32_u16 with the packed (a0, a1) gives S[sx] a0 + S[sx1] a1.  A source row's sums are
+// kept while the next output row still needs them (every second row of a x1.2 reduction, most rows of LSD's x1.2 enlargement).  15 instead of 40 vector
+// instructions per pixel; no staging, no barriers.
+constexpr int RS_ROWS = 8;
+
+__global__ __launch_bounds__(64) void k_resize_strip(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, int sw, int sh,
+                                                     uint8_t* __restrict__ dst, size_t dstImgStride, int dstPitch, int dw, int dh,
+                                                     const ResizeCoef* __restrict__ rx, const ResizeCoef* __restrict__ ry, int nsx)
+{
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= nsx) return;
+    const int dx0 = 4 * q, dy0 = blockIdx.y * RS_ROWS;
+    const uint8_t* s = src + (size_t)blockIdx.z * srcImgStride;
+    uint8_t* d = dst + (size_t)blockIdx.z * dstImgStride + dx0;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint32_t sel[4], coef[4];
+    const int base = min((int)rx[dx0].ofs, srcPitch - 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const ResizeCoef c = rx[min(dx0 + k, dw - 1)];
+        const int o0 = (int)c.ofs - base, o1 = min((int)c.ofs + 1, sw - 1) - base;
+        sel[k] = (uint32_t)o0 | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;      // (byte o0, 0, byte o1, 0) of the 8-byte window
+        coef[k] = (uint32_t)(uint16_t)c.a0 | ((uint32_t)(uint16_t)c.a1 << 16);
+    }
+    struct Raw { uint32_t w[2]; };
+    auto load_row = [&](int r) -> Raw { Raw v; __builtin_memcpy(v.w, s + (size_t)r * srcPitch + base, 8); return v; };
+    // (S[sx] a0 + S[sx1] a1) >> 4 of the quad's four columns from a source row's 8-byte window -- the reference only ever uses h >> 4
+    auto hrow = [&](const Raw& v, uint32_t* h) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t pr = __builtin_amdgcn_perm(v.w[1], v.w[0], sel[k]);
+            us2 va, vb;
+            __builtin_memcpy(&va, &pr, 4); __builtin_memcpy(&vb, &coef[k], 4);
+            h[k] = __builtin_amdgcn_udot2(va, vb, 0u, false) >> 4;
+        }
+    };
+    auto rows_of = [&](int dy, int& r0, int& r1, uint32_t& b0, uint32_t& b1) {
+        const ResizeCoef cy = ry[min(dy, dh - 1)];
+        r0 = min(max((int)cy.ofs, 0), sh - 1); r1 = min(max((int)cy.ofs + 1, 0), sh - 1);
+        b0 = (uint32_t)cy.a0; b1 = (uint32_t)cy.a1;
+    };
+    // (everything about rows is wave-uniform: one strip row per block.)  A source row's sums are kept while the next output row still needs them; the
+    // rows an output row needs and does not have are requested one output row ahead, so their latency is covered by a row's arithmetic
+    int r0, r1, ra = -1, rb = -1;
+    uint32_t b0, b1;
+    rows_of(dy0, r0, r1, b0, b1);
+    Raw p0 = load_row(r0), p1 = load_row(r1);
+    uint32_t hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rr = 0; rr < RS_ROWS; ++rr) {
+        const int dy = dy0 + rr;
+        if (dy >= dh) break;
+        int n0, n1;
+        uint32_t c0, c1;
+        rows_of(dy + 1, n0, n1, c0, c1);
+        Raw q0 = p0, q1 = p1;
+        if (rr + 1 < RS_ROWS) {
+            if (n0 != r0 && n0 != r1) q0 = load_row(n0);
+            if (n1 != n0 && n1 != r1) q1 = load_row(n1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t h0[4], h1[4];
+        if (r0 == ra) { for (int k = 0; k < 4; ++k) h0[k] = hA[k]; }
+        else if (r0 == rb) { for (int k = 0; k < 4; ++k) h0[k] = hB[k]; }
+        else hrow(p0, h0);
+        if (r1 == r0) { for (int k = 0; k < 4; ++k) h1[k] = h0[k]; }
+        else if (r1 == rb) { for (int k = 0; k < 4; ++k) h1[k] = hB[k]; }
+        else hrow(p1, h1);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t v = (((b0 * h0[k]) >> 16) + ((b1 * h1[k]) >> 16) + 2u) >> 2;
+            out |= (v & 0xffu) << (8 * k);
+        }
+        // columns beyond dw inside the last quad are scratch bytes of the padded pitch
+        __builtin_memcpy(d + (size_t)dy * dstPitch, &out, 4);
+        ra = r0; rb = r1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hA[k] = h0[k]; hB[k] = h1[k]; }
+        r0 = n0; r1 = n1; b0 = c0; b1 = c1; p0 = q0; p1 = q1;
+    }
+}
+
+// host: every quad of output columns finds its source bytes inside 8 consecutive bytes (any scale factor up to about 1.7)
+bool resize_strip_fits(const ResizeCoef* rx, int sw, int dw)
+{
+    for (int x0 = 0; x0 < dw; x0 += 4) {
+        const int last = std::min(x0 + 3, dw - 1);
+        if (std::min((int)rx[last].ofs + 1, sw - 1) - (int)rx[x0].ofs > 7) return false;
+    }
+    return sw >= 8;
+}
+
 // host: largest source window any tile needs; the tiled kernel is used when it fits the LDS staging area
 bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int sh, int dw, int dh)
 {
@@ -269,8 +489,17 @@ bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int s
 }
 
 int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,
-                        int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s)
+                        int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s, bool strip)
 {
+    static const bool stripsOn = [] { const char* e = getenv("OLF_RESIZE"); return !e || atoi(e) != 0; }();
+    strip = strip && stripsOn && (dstPitch & 3) == 0 && (dstImgStride & 3) == 0 && srcPitch >= 8;
+    if (strip) {      // (resize_strip_fits on the host tables; OLF_RESIZE=0 keeps the LDS-tiled kernel for A/B measurements)
+        const int nsx = (dw + 3) / 4;
+        hipLaunchKernelGGL(k_resize_strip, dim3((nsx + 63) / 64, (dh + RS_ROWS - 1) / RS_ROWS, n_images), dim3(64), 0, s, src, srcImgStride, srcPitch, sw, sh,
+                           dst, dstImgStride, dstPitch, dw, dh, d_rx, d_ry, nsx);
+        OLF_HIP_CHECK(hipGetLastError());
+        return OLF_OK;
+    }
     hipLaunchKernelGGL(k_resize_tiled, dim3((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, n_images), dim3(256), 0, s, src, srcImgStride,
                        srcPitch, sw, sh, dst, dstImgStride, dstPitch, dw, dh, d_rx, d_ry);
     OLF_HIP_CHECK(hipGetLastError());

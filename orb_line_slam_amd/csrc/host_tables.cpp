@@ -170,6 +170,7 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
             resize_axis_coefs(P.w, L.w, 1. / inv_x, true, &rx[L.resizeTabX]);
             resize_axis_coefs(P.h, L.h, 1. / inv_y, false, &ry[L.resizeTabY]);
             L.resizeTiled = resize_tiled_fits(&rx[L.resizeTabX], &ry[L.resizeTabY], P.w, P.h, L.w, L.h) ? 1 : 0;
+            if (L.resizeTiled && resize_strip_fits(&rx[L.resizeTabX], P.w, L.w)) L.resizeTiled |= 2;      // the register-only kernel applies too
         }
     }
     g.pyrBytes = off;
@@ -294,6 +295,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
         resize_axis_coefs(W, g.Ws, 1. / p.lsd_scale, true, rx.data());
         resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
         g.resizeTiled = resize_tiled_fits(rx.data(), ry.data(), W, H, g.Ws, g.Hs) ? 1 : 0;
+        if (g.resizeTiled && resize_strip_fits(rx.data(), W, g.Ws)) g.resizeTiled |= 2;
     }
     return OLF_OK;
 }

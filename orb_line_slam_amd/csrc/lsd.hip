@@ -489,7 +489,7 @@ __device__ __forceinline__ AgentRect agent_region2rect(const uint2* lg, int n, d
 // ---- LSD_REFINE_ADV: rect_improve / rect_nfa / nfa / log_gamma (convention C.14; oracle/line_oracle.cpp).  The numbers of false alarms are
 // compared with each other and with log_eps only; their libm calls (log, exp, pow, sinh, log10) are the device library's, so a decision can differ
 // from the host's where two of these doubles are closer than the libraries' last-bit differences.
-__device__ __noinline__ double agent_log_gamma(double x)
+__device__ __forceinline__ double agent_log_gamma(double x)
 {
     if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
     const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
@@ -502,7 +502,7 @@ __device__ __noinline__ double agent_log_gamma(double x)
     return a + log(b);
 }
 
-__device__ __noinline__ double agent_nfa(int n, int k, double p, double LOG_NT)
+__device__ __forceinline__ double agent_nfa(int n, int k, double p, double LOG_NT)
 {
     if (n == 0 || k == 0) return -LOG_NT;
     if (n == k) return -LOG_NT - (double)n * log10(p);
@@ -535,7 +535,7 @@ __device__ __noinline__ double agent_nfa(int n, int k, double p, double LOG_NT)
 // rect_nfa: the rectangle's corners (truncated to int), ordered by x then y; rows from the lowest to the highest corner, the left and right ends of a
 // row advance by the edge steps (integer divisions, and tailp's x where its y is meant: as in the original).  The pixels of a row are counted across the
 // lanes (the counts do not depend on the order).
-__device__ __noinline__ double agent_rect_nfa(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, const AgentRect& rec, int lane)
+__device__ __forceinline__ double agent_rect_nfa(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, const AgentRect& rec, int lane)
 {
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
@@ -601,7 +601,7 @@ __device__ __noinline__ double agent_rect_nfa(const LineGeom& g, const uint32_t*
     return agent_nfa(total_pts, alg_pts, rec.p, g.logNT);
 }
 
-__device__ __noinline__ double agent_rect_improve(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, AgentRect& rec, int lane)
+__device__ __forceinline__ double agent_rect_improve(const LineGeom& g, const uint32_t* __restrict__ grad, const AngEnt* __restrict__ ent, AgentRect& rec, int lane)
 {
     const double delta = 0.5, delta_2 = delta / 2.0, LOG_EPS = g.logEps;
     double log_nfa = agent_rect_nfa(g, grad, ent, rec, lane);
@@ -680,7 +680,9 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // below every live seed of a window are requested when the window starts (a region's first 3x3 gather then finds them in the cache instead of in HBM),
 // 4 = the row beyond every candidate of a growth step is requested beside its table entry (the next step's gather).
 template <int REFINE, int PF>      // REFINE 0: LSD_REFINE_NONE, 1: STD, 2: ADV
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
+// (REFINE = 2: rect_improve / rect_nfa / nfa inlined with the AgentRect in registers need 200 VGPRs: two agents per SIMD, no scratch, no generic-pointer
+// loads; as four out-of-line functions with a stack object they were 128 VGPRs + 496 B of scratch -- 16 % slower up to 2048 images, 7 % faster at 4096)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 ? 2 : 4, 8))) void k_lsd_grow(const LineGeom* __restrict__ gp, uint32_t* __restrict__ gradAll,
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
                                                  int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt,
@@ -1358,7 +1360,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
       if (rc != OLF_OK) return rc; }
     if (g.resizeTiled) {
         int rc = launch_resize_tiled(b.lsdBlur, (size_t)g.pitchW * g.H, g.pitchW, g.W, g.H, b.scaled, (size_t)g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, b.rx,
-                                     b.ry, n_images, s);
+                                     b.ry, n_images, s, (g.resizeTiled & 2) != 0);
         if (rc != OLF_OK) return rc;
     } else {
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;

@@ -341,7 +341,7 @@ int launch_orb_pyramid(const OrbGeom& g, const OrbDeviceBufs& b, const uint8_t* 
         const LevelGeom &P = g.lv[l - 1], &L = g.lv[l];
         if (L.resizeTiled) {
             int rc = launch_resize_tiled(b.pyr + P.offset, (size_t)g.pyrBytes, P.pitch, P.w, P.h, b.pyr + L.offset, (size_t)g.pyrBytes, L.pitch, L.w, L.h,
-                                         b.rx + L.resizeTabX, b.ry + L.resizeTabY, n_images, s);
+                                         b.rx + L.resizeTabX, b.ry + L.resizeTabY, n_images, s, (L.resizeTiled & 2) != 0);
             if (rc != OLF_OK) return rc;
         } else {
             const int quads = ((L.w + 3) >> 2) * L.h;

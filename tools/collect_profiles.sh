@@ -15,7 +15,12 @@ OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-form
 python $R/tools/pmc_budget.py /tmp/pb 1024 $O/${T}_valu_budget.json > $O/${T}_valu_budget_per_kernel.txt 2>&1; cp $O/${T}_valu_budget.json $R/profiles/
 timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_C3.json; cut -c1-160 $O/${T}_bench_C3.json
 OLF_ONE_STREAM=1 timeout 600 python $R/bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_one_stream.json
-for c in C2 C4 C5; do timeout 600 python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_$c.json; done
+# the other configurations: the bench line AND the rocprofv3 kernel summary of the same command
+for c in C2 C4 C5; do
+  rm -rf /tmp/ks_$c; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -o run -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | grep '^{' | tail -1 > $O/${T}_bench_$c.json
+  cp $(ls /tmp/ks_$c/*kernel_stats.csv | head -1) $O/${T}_bench_${c}_kernel_stats.csv
+done
+timeout 600 python $R/bench.py --sequence 6 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_sequence6.json
 timeout 600 python $R/bench.py --scene bars --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_long_scene.json
 rm -rf /tmp/ks; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o run -- python $R/bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /tmp/ks.log 2>&1
 cp $(ls /tmp/ks/*kernel_stats.csv | head -1) $O/${T}_bench_C3_kernel_stats.csv
