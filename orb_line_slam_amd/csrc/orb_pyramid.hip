@@ -97,9 +97,9 @@ __device__ __forceinline__ bool run9(uint32_t m)   // >= 9 contiguous set bits i
     return (r & 0xffffu) != 0;
 }
 
-constexpr int FT_W = 128, FT_H = 32;                 // processed tile; LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+34
-constexpr int FT_EW = 124, FT_EH = 30;               // emitted part: columns 2 .. 125, rows 1 .. 30 (the rest is the NMS halo of the neighbours)
-constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
+constexpr int FT_W = 128;                            // processed tile: 128 x FT_H pixels, FT_H = NT / 8 (32 rows for 256 threads); LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+FT_H+2
+constexpr int FT_EW = 124;                           // emitted part: columns 2 .. 125, rows 1 .. FT_H - 2 (the rest is the NMS halo of the neighbours)
+constexpr int FT_INW = (FT_W + 8) / 4;
 
 
 // FAST-9/16 corners of one level, straight into the per-cell candidate lists of ComputeKeyPointsOctTree (src/ORBextractor.cc:791-831):
@@ -109,10 +109,14 @@ constexpr int FT_INW = (FT_W + 8) / 4, FT_INH = FT_H + 6;
 // survivors to their cell's list.  No dense score map exists in memory; k_cells_sort orders each list and applies the dual threshold.
 // Footprint: 17.4 KB of LDS and <= 64 VGPRs, so that TWO blocks per CU fit beside the 24 resident growth agents (they leave 37 KB of LDS, two wave
 // slots and 128 VGPRs per SIMD): in the fused entry this kernel runs in the agents' shadow (api.cpp, OLF_SCHED).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+// NT threads per block: 256 (128 x 32 tile, 17.4 KB of LDS) or 128 (128 x 16, 9 KB): beside the resident growth agents a CU has eight free wave slots and
+// 40 KB of LDS -- two big blocks or four small ones; the small ones overlap each other's barriers and loads better (OLF_FAST_NT, api.cpp schedule)
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, int minTh,
                   uint32_t* __restrict__ cells, int* __restrict__ cellCount, int totalCells, int cellCap)
 {
+    constexpr int FT_H = NT / 8, FT_EH = FT_H - 2, FT_INH = FT_H + 6;
     __shared__ uint32_t tile[FT_INH * FT_INW];
     __shared__ unsigned short s_cand[FT_W * FT_H];      // A1's survivors, compacted in place to the corners by A2 (s_list)
     unsigned short* const s_list = s_cand;
@@ -123,13 +127,13 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     const int x0 = kMinBorder - 4 + blockIdx.x * FT_EW, y0 = kMinBorder + 2 + blockIdx.y * FT_EH;
     const int xBeg = kMinBorder + 3, yBeg = kMinBorder + 3, xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
     const uint8_t* src = pyr + (size_t)img * pyrBytes + L.offset;
-    for (int i = threadIdx.x; i < FT_INH * FT_INW; i += 256) {
+    for (int i = threadIdx.x; i < FT_INH * FT_INW; i += NT) {
         const int r = i / FT_INW, j = i - r * FT_INW;
         const int gy = min(y0 - 3 + r, L.h - 1);
         const int xw = min(x0 - 4 + 4 * j, L.pitch - 4);          // rows are 64-byte aligned and padded to the pitch
         tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw);
     }
-    reinterpret_cast<uint4*>(s_score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(s_score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);      // (FT_H * FT_W bytes = NT x 16)
     if (threadIdx.x == 0) { s_nc = 0; s_n = 0; }
     __syncthreads();
     const int q = threadIdx.x & 31, ry0 = (threadIdx.x >> 5) * 4;
@@ -194,7 +198,7 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     // masks, >= 9 contiguous.  Corners are queued for scoring.
     // (in place: a round's 256 entries are all read before any corner is appended, and the append position never passes the round's end)
     const int nCand = s_nc;
-    for (int i0 = 0; i0 < nCand; i0 += 256) {
+    for (int i0 = 0; i0 < nCand; i0 += NT) {
         const int i = i0 + threadIdx.x;
         bool corner = false;
         int id = 0;
@@ -222,7 +226,7 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     __syncthreads();
     // ---- phase B: scores of the queued corners into the LDS score tile, one corner per thread (dense lanes)
     const int nC = s_n;
-    for (int i = threadIdx.x; i < nC; i += 256) {
+    for (int i = threadIdx.x; i < nC; i += NT) {
         const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
         const uint8_t* c = tb + (ty + 3) * P + tx + 4;
         const int v = c[0];
@@ -239,7 +243,7 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     }
     __syncthreads();
     // ---- phase C: strict 3x3 non-maximum suppression inside the cell interior, survivors appended to their cell
-    for (int i = threadIdx.x; i < nC; i += 256) {
+    for (int i = threadIdx.x; i < nC; i += NT) {
         const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
         if (tx < 2 || tx >= 2 + FT_EW || ty < 1 || ty >= 1 + FT_EH) continue;           // halo: emitted by the neighbouring tile
         const int cur = s_score[id];
@@ -359,8 +363,13 @@ int launch_orb_fast(const OrbGeom& g, const OrbDeviceBufs& b, int n_images, hipS
         const LevelGeom& L = g.lv[l];
         const int fw = L.maxBorderX - 3 - (kMinBorder - 2), fh = L.maxBorderY - 3 - (kMinBorder + 3);   // emitted columns start at 14, rows at 19
         if (fw <= 0 || fh <= 0) continue;
-        hipLaunchKernelGGL(k_fast_score, dim3((fw + FT_EW - 1) / FT_EW, (fh + FT_EH - 1) / FT_EH, n_images), dim3(256), 0, s, b.pyr,
-                           g.pyrBytes, L, g.minTh, b.cells, b.cellCount, g.totalCells, g.cellCap);
+        static const int nt = [] { const char* e = getenv("OLF_FAST_NT"); const int v = e ? atoi(e) : 256; return v == 128 ? 128 : 256; }();
+        if (nt == 128)
+            hipLaunchKernelGGL(k_fast_score<128>, dim3((fw + FT_EW - 1) / FT_EW, (fh + 14 - 1) / 14, n_images), dim3(128), 0, s, b.pyr,
+                               g.pyrBytes, L, g.minTh, b.cells, b.cellCount, g.totalCells, g.cellCap);
+        else
+            hipLaunchKernelGGL(k_fast_score<256>, dim3((fw + FT_EW - 1) / FT_EW, (fh + 30 - 1) / 30, n_images), dim3(256), 0, s, b.pyr,
+                               g.pyrBytes, L, g.minTh, b.cells, b.cellCount, g.totalCells, g.cellCap);
     }
     hipLaunchKernelGGL(k_cells_sort, dim3(g.totalCells, n_images), dim3(64), 0, s, b.geom, b.cells, b.cellCount);
     OLF_HIP_CHECK(hipGetLastError());
