@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--scene", choices=("default", "long", "bars"), default="default", help="long: fewer, larger shapes; bars: long thin bars -> key lines of about 0.08*W pixels (SURVEY App. D model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bow", action="store_true", help="frame-to-frame ORB matching by the dense kNN stand-in of rounds 1-2 instead of SearchByBoW")
+    ap.add_argument("--pipeline", action="store_true", help="hand the context an input-ready event (olf_ctx_set_input_event, include/orbline.h): the line path of step k + 1 then starts "
+                                                            "beside the tail of step k instead of behind it (measured: no gain, profiles/r4q_pipelined_steps_ab.txt)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the pass that runs every stage alone (counter collections that must see exactly the timed steps)")
     ap.add_argument("--no-extras", action="store_true", help="skip the copy ceiling, small-batch latency and PCIe-inclusive legs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -323,6 +325,10 @@ def main():
         idx = np.stack([2 * order, 2 * order + 1], 1).reshape(-1)
         return torch.from_numpy(host[idx].copy()).to(dev)
     imgs = make_input(rank)
+    # the inputs are resident before the timed region starts: their "ready" event lets the line stream of a step start beside the previous step's tail
+    in_ev = torch.cuda.Event(); in_ev.record(); torch.cuda.synchronize()
+    if args.pipeline:
+        ctx.set_input_event(in_ev)
 
     def z(shape, dt):
         return torch.zeros(shape, dtype=dt, device=dev)
@@ -334,7 +340,7 @@ def main():
     fb = FrameBuffers(*[t.data_ptr() for t in (kps, desc, counts, ur, dp, kls, ldesc, lcounts, lm, ldisp, lle)])
     Lh = lib()
     nnr_l = float(params.stereo.min_ratio_12_l)
-    kf_valid = z((B, cap), torch.uint8); kf_valid_b = z((B, cap), torch.bool); f2f_n = z((B,), torch.int32)
+    kf_valid = z((B, cap), torch.uint8); f2f_n = z((B,), torch.int32)
     voc = None
     if not args.no_bow:
         # vocabulary of ORBvoc's shape from the descriptors of a few frames of this input (built once, outside the timed region)
@@ -354,9 +360,8 @@ def main():
                                       lcounts.data_ptr(), 2 * lcap, 2, B - 1, nnr_l, 1, f2f_lines.data_ptr(), s), "olf_match_bf_dev(lines)")
             if voc is not None:
                 # configuration 3's matcher: cur.ComputeBoW() + ORBmatcher(0.7).SearchByBoW(previous frame as key frame, cur) (src/Tracking.cc:963-970),
-                # batched on the device; the key frame's map points = its stereo points (mvuRight >= 0)
-                torch.ge(ur, 0, out=kf_valid_b)
-                kf_valid.copy_(kf_valid_b)
+                # batched on the device; the key frame's map points = its stereo points (mvDepth > 0, src/Tracking.cc:586-588)
+                check(Lh.olf_stereo_points_mask_dev(ctx.handle, dp.data_ptr(), B * cap, kf_valid.data_ptr(), s), "olf_stereo_points_mask_dev")
                 check(Lh.olf_search_by_bow_batch_dev(ctx.handle, voc._h, B, 2, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), kf_valid.data_ptr(), None,
                                                      0.7, 1, 4, f2f_orb.data_ptr(), f2f_n.data_ptr(), s), "olf_search_by_bow_batch_dev")
             else:
@@ -454,7 +459,9 @@ def main():
             recs, sizes = gstat["last"]
             verify = {"ranks": world, "identical": True}
             for r in range(1, world):
-                step(make_input(r))
+                other = make_input(r)
+                torch.cuda.synchronize()          # (the input event set above speaks for `imgs`: another input has to be complete before the call)
+                step(other)
                 pack(0)
                 torch.cuda.synchronize()
                 n = int(nbytes[0].item())

@@ -44,6 +44,13 @@ void olf_ctx_destroy(olf_ctx* ctx);
  * by olf_ctx_poll_status (call it once the caller's own stream has passed the work in question).  The reference has no such limits
  * (std::vector growth); a refused frame is the equivalent of its std::bad_alloc. */
 int  olf_ctx_synchronize(olf_ctx* ctx);
+/* Batch pipelining for olf_stereo_frames_dev.  By default the line stream of a call forks from `stream` at the call (the images may have been
+ * produced on it), i.e. behind the ORB / stereo / matching tail of the PREVIOUS call on that stream.  With an input event (a hipEvent_t the
+ * caller records on whichever stream produces d_images, before the call; NULL = default) the line stream waits for that event only, and the
+ * LSD front of batch k + 1 runs beside the tail of batch k.  The context's buffers allow it: the LSD front writes line-path scratch only, and
+ * everything of batch k + 1 that touches the output buffers or the shared LBD planes is ordered behind batch k's work on `stream` (api.cpp,
+ * olf_stereo_frames_dev).  The caller still orders `stream` itself behind the production of d_images. */
+int  olf_ctx_set_input_event(olf_ctx* ctx, void* hip_event);
 int  olf_ctx_poll_status(olf_ctx* ctx);
 
 /* Stage timing with HIP events recorded on the stream each stage is launched on (the reference's only
@@ -382,6 +389,12 @@ int olf_line_coords(double x1, double y1, double x2, double y2, int32_t* xy, int
  * capacity flag (olf_ctx_synchronize) and writes only the header. */
 size_t olf_frames_pack_bound(const olf_ctx* ctx, int n_pairs);
 int olf_frames_pack_dev(olf_ctx* ctx, const olf_frame_buffers* out, int n_pairs, uint8_t* d_dst, size_t dst_capacity, uint64_t* d_bytes, void* stream);
+/* The map points a frame owns right after stereo matching: d_mask[i] = d_depth[i] > 0, the test of Tracking::StereoInitialization /
+ * UpdateLastFrame on mvDepth (src/Tracking.cc:584-588, 1096-1099: `float z = mvDepth[i]; if(z>0)`), as the byte mask d_mp_valid of
+ * olf_search_by_bow_batch_dev.  n = number of floats (n_pairs * olf_orb_capacity() for the depth plane of olf_stereo_points_dev);
+ * d_depth 16-byte aligned, d_mask 4-byte aligned. */
+int olf_stereo_points_mask_dev(olf_ctx* ctx, const float* d_depth, size_t n, uint8_t* d_mask, void* stream);
+
 /* measurement: rate of a plain 16-byte-per-thread device copy kernel over `bytes` (read + written bytes per second): the practical HBM
  * ceiling bench.py reports next to the specification's 8 TB/s */
 int olf_debug_copy_bandwidth(olf_ctx* ctx, size_t bytes, int reps, double* gbytes_per_s);

@@ -154,6 +154,8 @@ def lib():
         L.olf_frames_pack_bound.argtypes = [C.c_void_p, C.c_int]
         L.olf_frames_pack_bound.restype = C.c_size_t
         L.olf_frames_pack_dev.argtypes = [C.c_void_p, C.POINTER(FrameBuffers), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.olf_ctx_set_input_event.argtypes = [C.c_void_p, C.c_void_p]
+        L.olf_stereo_points_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.olf_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.olf_debug_fdiv_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.olf_debug_sqrtq_sweep.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
@@ -245,6 +247,12 @@ class Context:
     def synchronize(self):
         """wait for the context's streams; raises OlfError if a *_dev call issued since the last check overflowed a device buffer"""
         check(lib().olf_ctx_synchronize(self.handle), "olf_ctx_synchronize")
+
+    def set_input_event(self, event):
+        """olf_ctx_set_input_event: `event` a recorded torch.cuda.Event (or None): the line stream of olf_stereo_frames_dev then waits for it instead of
+        forking from the caller's stream, so batch k + 1's LSD front runs beside batch k's tail.  The context keeps the raw handle only: keep the
+        event alive while it is set."""
+        check(lib().olf_ctx_set_input_event(self.handle, C.c_void_p(event.cuda_event) if event is not None else None), "olf_ctx_set_input_event")
 
     def poll_status(self):
         """the same check without waiting for any stream (the caller has synchronised its own)"""

@@ -51,6 +51,11 @@ struct olf_ctx {
     bool mark_front = false;
     int orb_wait_after = 0;        // fused entry: the ORB stream waits for the LSD front behind this many of its own dense stages (pyramid, blur, FAST)
     hipEvent_t ev_front = nullptr;
+    hipEvent_t input_event = nullptr;  // olf_ctx_set_input_event: not owned; the fused entry's line stream waits for it instead of forking from the caller's stream
+    hipEvent_t ev_lbd = nullptr;       // fused entry: the LBD gradient images are ready (computed on the ORB stream in the seed ordering's shadow)
+    bool defer_lbd = false;            // fused entry: olf_line_extract_dev stops behind the rectangles; selection + LBD are enqueued by the caller
+    bool lbd_pre = false;              // fused entry: olf_orb_extract_dev computes the LBD gradient images behind its blur and records ev_lbd
+    hipEvent_t ev_sort = nullptr;      // recorded in front of the seed ordering (the dense, bandwidth-bound half of the LSD front is through)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stage profiling (olf_profile_*): HIP events recorded on the stream each stage is launched on
     bool prof_on = false;
@@ -135,6 +140,7 @@ int launch_pack_records(const olf_frame_buffers& fb, int n_pairs, int cap, int l
                         unsigned long long* d_bytes, int* d_status, hipStream_t s);
 size_t pack_records_bound(int n_pairs, int cap, int lcap);
 int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);
+int launch_depth_mask(const float* depth, uint8_t* mask, size_t n, hipStream_t s);
 }
 
 namespace olf {
@@ -213,6 +219,8 @@ void olf_ctx_destroy(olf_ctx* c)
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_front) (void)hipEventDestroy(c->ev_front);
+    if (c->ev_sort) (void)hipEventDestroy(c->ev_sort);
+    if (c->ev_lbd) (void)hipEventDestroy(c->ev_lbd);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -269,7 +277,8 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
     const LineGeom& lg = c->line.geom;
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_lbd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }
     LineDeviceBufs& l = c->lb;
 #define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
@@ -282,7 +291,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     A(l.region, n * (size_t)lg.regionStride); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
-    A(l.rowSums, n * lg.outCap * 63 * 4); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
+    A(l.rowSums, n * lg.outCap * 63 * 4); A(l.lbdStarts, n * lg.outCap * 64 * 2); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
     {
         const size_t np = (n + 1) / 2;
@@ -311,6 +320,13 @@ int olf_ctx_synchronize(olf_ctx* c)
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream2));
     return check_status(c);
+}
+
+int olf_ctx_set_input_event(olf_ctx* c, void* hip_event)
+{
+    if (!c) return OLF_ERR_INVALID;
+    c->input_event = static_cast<hipEvent_t>(hip_event);
+    return OLF_OK;
 }
 
 int olf_ctx_poll_status(olf_ctx* c)
@@ -394,8 +410,14 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
     const int wa = c->orb_wait_after;
     { StageScope t(c, s, ST_ORB_PYRAMID); OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s)); }
     if (wa == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    // wa == 4 (OLF_SCHED=5): the blur in the shadow of the seed sort -- it waits for the dense half of the LSD front only (ev_sort), FAST for all of it
+    if (wa == 4) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_sort, 0));
     if (wa >= 2) { StageScope t(c, s, ST_ORB_BLUR); OLF_TRY(launch_orb_blur(g, c->ob, n_images, s)); }
-    if (wa == 2) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    if (c->lbd_pre) {      // (also beside the seed sort: GaussianBlur + Sobel of the LBD octave need the input images only)
+        OLF_TRY(launch_lbd_dense(c->line.geom, c->lb, d_images, c->W, n_images, s));
+        OLF_HIP_CHECK(hipEventRecord(c->ev_lbd, s));
+    }
+    if (wa == 2 || wa == 4) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_FAST); OLF_TRY(launch_orb_fast(g, c->ob, n_images, s)); }
     if (wa == 3) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_OCTREE); OLF_TRY(launch_orb_octree(g, c->ob, n_images, s)); }
@@ -466,6 +488,13 @@ int olf_debug_status(olf_ctx* c, int32_t* out64)
 size_t olf_frames_pack_bound(const olf_ctx* c, int n_pairs)
 {
     return c && n_pairs >= 0 ? olf::pack_records_bound(n_pairs, c->orb.geom.outCap, c->line.geom.outCap) : 0;
+}
+
+int olf_stereo_points_mask_dev(olf_ctx* c, const float* d_depth, size_t n, uint8_t* d_mask, void* stream)
+{
+    if (!c || !d_depth || !d_mask) { set_error("olf_stereo_points_mask_dev: null argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_stereo_points_mask_dev"));
+    return olf::launch_depth_mask(d_depth, d_mask, n, stream ? (hipStream_t)stream : c->stream);
 }
 
 int olf_frames_pack_dev(olf_ctx* c, const olf_frame_buffers* fb, int n_pairs, uint8_t* d_dst, size_t dst_capacity, uint64_t* d_bytes, void* stream)
@@ -878,11 +907,13 @@ int olf_line_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_
     // still meet the growth agents afterwards), kept as a switch for experiments.
     static const bool front_before_sort = getenv("OLF_SCHED") && (atoi(getenv("OLF_SCHED")) & 16);
     const bool early = c->mark_front && c->line.geom.seedOrder == 1 && front_before_sort;
-    c->lb.sortEvent = early ? c->ev_front : nullptr;
+    c->lb.sortEvent = early ? c->ev_front : (c->mark_front && c->line.geom.seedOrder == 1) ? c->ev_sort : nullptr;
+    if (c->mark_front && c->line.geom.seedOrder != 1) OLF_HIP_CHECK(hipEventRecord(c->ev_sort, s));      // (no sort kernel to hide behind: the event is already true)
     { StageScope t(c, s, ST_LSD_FRONT); const int rc = launch_lsd_front(c->line.geom, c->lb, d_images, c->W, n_images, s); c->lb.sortEvent = nullptr; OLF_TRY(rc); }
     if (c->mark_front && !early) OLF_HIP_CHECK(hipEventRecord(c->ev_front, s));
     { StageScope t(c, s, ST_LSD_GROW); OLF_TRY(launch_lsd_grow(c->line.geom, c->lb, n_images, s)); }
     { StageScope t(c, s, ST_LSD_RECT); OLF_TRY(launch_lsd_rect(c->line.geom, c->lb, n_images, s)); }
+    if (c->defer_lbd) return OLF_OK;
     { StageScope t(c, s, ST_LINE_LBD); OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, d_kls, d_ldesc, d_lcounts, s)); }
     return OLF_OK;
 }
@@ -990,7 +1021,8 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     // stream builds its pyramid beside the dense half of the LSD front and then waits for the front's end: two dense pipelines at once only
     // slow each other down (OLF_SCHED=0: 290 ms per 3072-pair step), whereas FAST beside the latency-bound growth agents is hidden almost
     // completely (105 ms beside them, 24 alone, and the agents keep their stand-alone speed).  Round 3, ms per step: wait before the pyramid
-    // 266.3, behind it 260.3 (default), behind pyramid + blur 262.5, behind FAST 279.  OLF_ONE_STREAM serialises the two paths.
+    // 266.3, behind it 260.3, behind pyramid + blur 262.5, behind FAST 279.  Round 4 (profiles/r4o_*): behind the pyramid 241.6, and with the blur moved
+    // into the shadow of the one-wave seed sort (schedule 5, the default) 235.6 .. 239.5.  OLF_ONE_STREAM serialises the two paths.
     static const bool one_stream = getenv("OLF_ONE_STREAM") != nullptr;
     if (one_stream) {
         OLF_TRY(olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, s));
@@ -1000,21 +1032,42 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
         return OLF_OK;
     }
     // OLF_SCHED: 0 both paths at once; 1 .. 4: the ORB stream waits for the LSD front before its pyramid / behind the pyramid / behind pyramid + blur /
-    // behind pyramid + blur + FAST (+ 16: the front ends before the seed sort)
-    static const int sched = (getenv("OLF_SCHED") ? atoi(getenv("OLF_SCHED")) : 2) & 15;
-    OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
-    OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    // behind pyramid + blur + FAST (+ 16: the front ends before the seed sort); 5: pyramid beside the dense front, blur beside the seed sort, FAST behind it
+    static const int sched = (getenv("OLF_SCHED") ? atoi(getenv("OLF_SCHED")) : 5) & 15;
+    // schedule 5 also moves the LBD gradient images (GaussianBlur + Sobel of the input, 6 ms of dense work) from the tail of the line stream into the
+    // seed ordering's shadow on the ORB stream (OLF_LBD_PRE=0: off); the line stream's selection + LBD then wait for ev_lbd, so they are enqueued
+    // behind the ORB extraction here (an event has to be recorded before the wait for it is enqueued)
+    static const bool lbd_pre = sched == 5 && !(getenv("OLF_LBD_PRE") && atoi(getenv("OLF_LBD_PRE")) == 0);
+    // Fork.  With the caller's input event (olf_ctx_set_input_event) the line stream does not wait for what is still queued on `s` -- the ORB / stereo /
+    // matching tail of the previous batch -- and the LSD front of this batch runs beside it.  Safe with lbd_pre only: the LSD front, growth and rectangles
+    // write line-path scratch that nothing on `s` reads, and selection / LBD / line stereo (which write the output buffers the previous batch's matchers
+    // and packer on `s` may still read) sit behind ev_lbd, recorded on `s` behind all of the previous batch's work there.
+    if (c->input_event && lbd_pre) OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->input_event, 0));
+    else {
+        OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+        OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
     c->mark_front = sched != 0;
+    c->defer_lbd = lbd_pre;
     const int rcl = olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2);
-    c->mark_front = false;
+    c->mark_front = false; c->defer_lbd = false;
     OLF_TRY(rcl);
-    OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
-    OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    if (!lbd_pre) {
+        OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
+        OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    }
     if (sched == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     c->orb_wait_after = sched >= 2 ? sched - 1 : 0;
+    c->lbd_pre = lbd_pre;
     const int rco = olf_orb_extract_dev(c, d_images, n_images, o->kps, o->desc, o->counts, s);
-    c->orb_wait_after = 0;
+    c->orb_wait_after = 0; c->lbd_pre = false;
     OLF_TRY(rco);
+    if (lbd_pre) {
+        OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_lbd, 0));
+        { StageScope t(c, c->stream2, ST_LINE_LBD); OLF_TRY(launch_line_select_lbd(c->line.geom, c->lb, d_images, c->W, n_images, o->kls, o->ldesc, o->lcounts, c->stream2, true)); }
+        OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));
+        OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    }
     OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
     OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     return OLF_OK;

@@ -463,10 +463,10 @@ __global__ __launch_bounds__(64) void k_resize_strip(const uint8_t* __restrict__
 }
 
 // host: every quad of output columns finds its source bytes inside 8 consecutive bytes (any scale factor up to about 1.7)
-bool resize_strip_fits(const ResizeCoef* rx, int sw, int dw)
+bool resize_strip_fits(const ResizeCoef* rx, int sw, int dw, int ncols)
 {
     for (int x0 = 0; x0 < dw; x0 += 4) {
-        const int last = std::min(x0 + 3, dw - 1);
+        const int last = std::min(x0 + ncols - 1, dw - 1);
         if (std::min((int)rx[last].ofs + 1, sw - 1) - (int)rx[x0].ofs > 7) return false;
     }
     return sw >= 8;

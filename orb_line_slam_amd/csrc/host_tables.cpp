@@ -296,6 +296,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
         resize_axis_coefs(H, g.Hs, 1. / p.lsd_scale, false, ry.data());
         g.resizeTiled = resize_tiled_fits(rx.data(), ry.data(), W, H, g.Ws, g.Hs) ? 1 : 0;
         if (g.resizeTiled && resize_strip_fits(rx.data(), W, g.Ws)) g.resizeTiled |= 2;
+        if ((g.resizeTiled & 2) && resize_strip_fits(rx.data(), W, g.Ws, 5) && g.pitchW >= 8 && (g.pitchS & 3) == 0) g.resizeTiled |= 4;      // k_lsd_upgrad
     }
     return OLF_OK;
 }

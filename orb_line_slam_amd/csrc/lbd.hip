@@ -119,33 +119,55 @@ __global__ __launch_bounds__(256) void k_sobel3(const uint8_t* __restrict__ blur
     if (x0 + 4 < g.pitchD) *reinterpret_cast<uint4*>(out + 4) = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
+// Per line, once: the direction vector dL = (cos, sin)(direction) and the start of each of the 63 support-region rows -- a sequential float chain from the
+// first row's start (sCorX0 -= dL[1]; sCorY0 += dL[0] per row, computeLBD :1143-1150).  One thread per line (round 4): with one thread per (line, row)
+// every one of the 63 threads evaluated the double-precision sin / cos and walked the chain up to its own row -- a third of k_lbd_rows's instructions.
+// starts: [image][line][64] float4 slots of which .x/.y = (sCorX0, sCorY0) of row h and, in slot 63, (dL0, dL1).
+__global__ __launch_bounds__(64) void k_lbd_prep(const LineGeom* __restrict__ gp, const olf_keyline* __restrict__ kls, const int* __restrict__ counts,
+                                                 float2* __restrict__ starts)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.y, li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= counts[img]) return;
+    const olf_keyline kl = kls[(size_t)img * g.outCap + li];
+    const short heightOfLSP = 63;
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfWidth = (short)((lengthOfLSP - 1) / 2);
+    const short halfHeight = (short)((heightOfLSP - 1) / 2);
+    const float midX = (float)(0.5 * (double)f_add(kl.sPointInOctaveX, kl.ePointInOctaveX));
+    const float midY = (float)(0.5 * (double)f_add(kl.sPointInOctaveY, kl.ePointInOctaveY));
+    // convention C.6: the C functions on doubles, or the float overloads (glibc's cosf / sinf bit for bit, device_math.hpp; kl.angle lies in [-pi, pi])
+    const float dL0 = g.libmFloat ? glibc_cosf(kl.angle) : (float)cos((double)kl.angle);
+    const float dL1 = g.libmFloat ? glibc_sinf(kl.angle) : (float)sin((double)kl.angle);
+    float sCorX0 = f_add(f_add(f_mul(-dL0, (float)halfWidth), f_mul(dL1, (float)halfHeight)), midX);
+    float sCorY0 = f_add(f_sub(f_mul(-dL1, (float)halfWidth), f_mul(dL0, (float)halfHeight)), midY);
+    float2* o = starts + ((size_t)img * g.outCap + li) * 64;
+    for (int h = 0; h < 63; ++h) {
+        o[h] = make_float2(sCorX0, sCorY0);
+        sCorX0 = f_sub(sCorX0, dL1); sCorY0 = f_add(sCorY0, dL0);
+    }
+    o[63] = make_float2(dL0, dL1);
+}
+
 // one thread per (line, support-region row): the four weighted row sums of computeLBD (:1143-1196)
 __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ dxdyAll,
                                                   const olf_keyline* __restrict__ kls, const int* __restrict__ counts,
-                                                  float4* __restrict__ rowSums)
+                                                  const float2* __restrict__ starts, float4* __restrict__ rowSums)
 {
     const LineGeom& g = *gp;
     const int img = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int li = t / 63, hID = t - li * 63;
     if (li >= counts[img]) return;
-    const olf_keyline kl = kls[(size_t)img * g.outCap + li];
     const uint32_t* dxdy = dxdyAll + (size_t)img * g.pitchD * g.H;
-    const short heightOfLSP = 63;
-    const short lengthOfLSP = (short)kl.numOfPixels;
-    const short halfWidth = (short)((lengthOfLSP - 1) / 2);
-    const short halfHeight = (short)((heightOfLSP - 1) / 2);
+    const short lengthOfLSP = (short)kls[(size_t)img * g.outCap + li].numOfPixels;
     const int realWidth = g.pitchD;      // row stride of the gradient image (the reference's realWidth, padded to a multiple of 4 pixels)
     const short imageWidth = (short)(g.W - 1), imageHeight = (short)(g.H - 1);
-    const float midX = (float)(0.5 * (double)f_add(kl.sPointInOctaveX, kl.ePointInOctaveX));
-    const float midY = (float)(0.5 * (double)f_add(kl.sPointInOctaveY, kl.ePointInOctaveY));
-    // convention C.6: the C functions on doubles, or the float overloads (glibc's cosf / sinf bit for bit, device_math.hpp; kl.angle lies in [-pi, pi])
-    const float dL0 = g.libmFloat ? glibc_cosf(kl.angle) : (float)cos((double)kl.angle);
-    const float dL1 = g.libmFloat ? glibc_sinf(kl.angle) : (float)sin((double)kl.angle);
+    const float2* st = starts + ((size_t)img * g.outCap + li) * 64;
+    const float2 dL = st[63], s0 = st[hID];
+    const float dL0 = dL.x, dL1 = dL.y;
     const float dO0 = -dL1, dO1 = dL0;
-    float sCorX0 = f_add(f_add(f_mul(-dL0, (float)halfWidth), f_mul(dL1, (float)halfHeight)), midX);
-    float sCorY0 = f_add(f_sub(f_mul(-dL1, (float)halfWidth), f_mul(dL0, (float)halfHeight)), midY);
-    for (int h = 0; h < hID; ++h) { sCorX0 = f_sub(sCorX0, dL1); sCorY0 = f_add(sCorY0, dL0); }
+    const float sCorX0 = s0.x, sCorY0 = s0.y;
     float sCorX = sCorX0, sCorY = sCorY0;
     float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
     // the sample coordinates are a cheap sequential float chain, the sums a sequential one on the loaded values: 8 samples are
@@ -280,8 +302,18 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const LineGeom* __restrict__ gp
     }
 }
 
+// LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel) -- they depend on the input images only, so the
+// fused entry runs them on the ORB stream in the shadow of the seed ordering (api.cpp, schedule 5)
+int launch_lbd_dense(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
+{
+    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
+    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images,
-                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s)
+                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s, bool denseDone)
 {
     int sortN = 64;
     while (sortN < g.maxDetect) sortN <<= 1;
@@ -289,11 +321,10 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
     // maxDetect <= Ps / 48 keeps 8 bytes x the next power of two below that)
     hipLaunchKernelGGL(k_line_select, dim3(n_images), dim3(256), std::min(sortN, LS_LDS_KEYS) * sizeof(unsigned long long), s, b.geom, b.rawLines, b.rawCount, d_kls,
                        d_counts, reinterpret_cast<unsigned long long*>(b.keysA), (size_t)g.Ps / 2);
-    // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel)
-    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
-    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    if (!denseDone) OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
+    hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<float4*>(b.rowSums));
+                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums));
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());
@@ -304,10 +335,10 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
 int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
                     uint8_t* d_desc, const int* d_counts, hipStream_t s)
 {
-    OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
-    hipLaunchKernelGGL(k_sobel3, dim3((((g.W + 7) >> 3) * g.H + 255) / 256, n_images), dim3(256), 0, s, b.lbdBlur, b.dxdy, b.geom);
+    OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
+    hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
     hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<float4*>(b.rowSums));
+                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums));
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());

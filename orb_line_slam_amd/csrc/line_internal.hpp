@@ -70,6 +70,7 @@ struct LineDeviceBufs {
     uint8_t* lbdBlur = nullptr;
     uint32_t* dxdy = nullptr;
     float* rowSums = nullptr;      // [n][outCap][63][4]
+    float* lbdStarts = nullptr;    // [n][outCap][64][2] start of every support-region row + (dL0, dL1) in slot 63 (k_lbd_prep)
     ResizeCoef* rx = nullptr;
     ResizeCoef* ry = nullptr;
     LineGeom* geom = nullptr;
@@ -99,8 +100,9 @@ struct LineHostTables {
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s);
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
+int launch_lbd_dense(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s);
 int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images,
-                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s);
+                           olf_keyline* d_kls, uint8_t* d_desc, int* d_counts, hipStream_t s, bool denseDone = false);
 int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, const olf_keyline* d_kls,
                     uint8_t* d_desc, const int* d_counts, hipStream_t s);
 int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_t* dst, int dstPitch, size_t dstStride, int W, int H,

@@ -130,6 +130,124 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
     }
 }
 
+// LSD's x1.2 enlargement (cv::resize INTER_LINEAR) and ll_angle's gradient in ONE pass (round 4): the register-only resize of filters.hip
+// (k_resize_strip: one thread = 4 output columns x 8 rows, a wave per block, source rows requested one output row ahead) computes a fifth column and a
+// ninth row, and the 2 x 2 differences of the values it holds are the gradient words -- the working image is still written (the debug entry and
+// LSD_REFINE_ADV's rect_nfa read nothing of it, but olf_lsd_debug_scaled does) and never read back.  Saves k_lsd_grad's pass (its loads, unpacking and
+// index arithmetic: 0.49 M instructions per image) and a kernel boundary.  Only for the std::sort seed order, which does not need k_lsd_grad's per-chunk
+// counts of defined pixels.
+constexpr int UG_ROWS = 8;
+__global__ __launch_bounds__(64) void k_lsd_upgrad(const uint8_t* __restrict__ src, uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
+                                                   const LineGeom* __restrict__ gp, const ResizeCoef* __restrict__ rx, const ResizeCoef* __restrict__ ry,
+                                                   int* __restrict__ maxN, int nsx)
+{
+    const LineGeom& g = *gp;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const int img = blockIdx.z;
+    const int sw = g.W, sh = g.H, dw = g.Ws, dh = g.Hs, srcPitch = g.pitchW;
+    int nmax = 0;
+    if (q < nsx) {
+        const int dx0 = 4 * q, dy0 = blockIdx.y * UG_ROWS;
+        const uint8_t* s = src + (size_t)img * g.pitchW * g.H;
+        uint8_t* d = scaled + (size_t)img * g.pitchS * g.Hs + dx0;
+        uint32_t* gout = grad + (size_t)img * g.Ps;
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        uint32_t sel[5], coef[5];
+        const int base = min((int)rx[dx0].ofs, srcPitch - 8);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const ResizeCoef c = rx[min(dx0 + k, dw - 1)];
+            const int o0 = (int)c.ofs - base, o1 = min((int)c.ofs + 1, sw - 1) - base;
+            sel[k] = (uint32_t)o0 | 0x0c00u | ((uint32_t)o1 << 16) | 0x0c000000u;
+            coef[k] = (uint32_t)(uint16_t)c.a0 | ((uint32_t)(uint16_t)c.a1 << 16);
+        }
+        struct Raw { uint32_t w[2]; };
+        auto load_row = [&](int r) -> Raw { Raw v; __builtin_memcpy(v.w, s + (size_t)r * srcPitch + base, 8); return v; };
+        auto hrow = [&](const Raw& v, uint32_t* h) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint32_t pr = __builtin_amdgcn_perm(v.w[1], v.w[0], sel[k]);
+                us2 va, vb;
+                __builtin_memcpy(&va, &pr, 4); __builtin_memcpy(&vb, &coef[k], 4);
+                h[k] = __builtin_amdgcn_udot2(va, vb, 0u, false) >> 4;
+            }
+        };
+        auto rows_of = [&](int dy, int& r0, int& r1, uint32_t& b0, uint32_t& b1) {
+            const ResizeCoef cy = ry[min(dy, dh - 1)];
+            r0 = min(max((int)cy.ofs, 0), sh - 1); r1 = min(max((int)cy.ofs + 1, 0), sh - 1);
+            b0 = (uint32_t)cy.a0; b1 = (uint32_t)cy.a1;
+        };
+        int r0, r1, ra = -1, rb = -1;
+        uint32_t b0, b1;
+        rows_of(dy0, r0, r1, b0, b1);
+        Raw p0 = load_row(r0), p1 = load_row(r1);
+        uint32_t hA[5] = {0, 0, 0, 0, 0}, hB[5] = {0, 0, 0, 0, 0};
+        int prev[5] = {0, 0, 0, 0, 0};       // the working image's row above the current one, columns dx0 .. dx0 + 4
+#pragma unroll
+        for (int rr = 0; rr <= UG_ROWS; ++rr) {
+            const int dy = dy0 + rr;          // (rr == UG_ROWS: the row below the strip, for the last row's differences only)
+            if (dy > dh || (rr > 0 && dy - 1 >= dh)) break;
+            int n0, n1;
+            uint32_t c0, c1;
+            rows_of(dy + 1, n0, n1, c0, c1);
+            Raw q0 = p0, q1 = p1;
+            if (rr < UG_ROWS) {
+                if (n0 != r0 && n0 != r1) q0 = load_row(n0);
+                if (n1 != n0 && n1 != r1) q1 = load_row(n1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t h0[5], h1[5];
+            if (r0 == ra) { for (int k = 0; k < 5; ++k) h0[k] = hA[k]; }
+            else if (r0 == rb) { for (int k = 0; k < 5; ++k) h0[k] = hB[k]; }
+            else hrow(p0, h0);
+            if (r1 == r0) { for (int k = 0; k < 5; ++k) h1[k] = h0[k]; }
+            else if (r1 == rb) { for (int k = 0; k < 5; ++k) h1[k] = hB[k]; }
+            else hrow(p1, h1);
+            int cur[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cur[k] = (int)(((((b0 * h0[k]) >> 16) + ((b1 * h1[k]) >> 16) + 2u) >> 2) & 0xffu);
+            if (rr < UG_ROWS && dy < dh) {
+                const uint32_t out = (uint32_t)cur[0] | ((uint32_t)cur[1] << 8) | ((uint32_t)cur[2] << 16) | ((uint32_t)cur[3] << 24);
+                __builtin_memcpy(d + (size_t)dy * g.pitchS, &out, 4);      // (columns beyond Ws inside the last quad are scratch bytes of the padded pitch)
+            }
+            if (rr > 0) {
+                // ll_angle's differences for row dy - 1: A = (x, y), B = (x + 1, y), C = (x, y + 1), D = (x + 1, y + 1)
+                const int y = dy - 1;
+                uint32_t packed[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int A = prev[k], B = prev[k + 1], Cc = cur[k], D = cur[k + 1];
+                    const int DA = D - A, BC = B - Cc;
+                    const int gx = DA + BC, gy = DA - BC;
+                    const int nn = gx * gx + gy * gy;
+                    const bool inside = dx0 + k < dw - 1 && y < dh - 1;
+                    packed[k] = inside ? (pack_g(gx, gy) | (nn >= g.nThr ? 0u : kNotDef)) : kNotDef;
+                    if (inside && nn >= g.nThr) nmax = max(nmax, nn);
+                }
+                // (one 16-byte store per quad and row: four dword stores per lane wrote every sector in four partial pieces)
+                uint32_t* o = gout + (size_t)y * dw + dx0;
+                const uintptr_t oa = reinterpret_cast<uintptr_t>(o);
+                if (dx0 + 3 < dw && (oa & 15) == 0) *reinterpret_cast<uint4*>(o) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+                else if (dx0 + 3 < dw && (oa & 7) == 0) {
+                    reinterpret_cast<uint2*>(o)[0] = make_uint2(packed[0], packed[1]); reinterpret_cast<uint2*>(o)[1] = make_uint2(packed[2], packed[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (dx0 + k < dw) o[k] = packed[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) prev[k] = cur[k];
+            ra = r0; rb = r1;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { hA[k] = h0[k]; hB[k] = h1[k]; }
+            r0 = n0; r1 = n1; b0 = c0; b1 = c1; p0 = q0; p1 = q1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    if (threadIdx.x == 0 && nmax > 0) atomicMax(&maxN[img * 32], nmax);   // counters padded to one per 128-byte line
+}
+
 // ll_angle, second half, and the isolated-seed test, in one pass over the gradient words.
 //
 // Keys: bin of every defined pixel -> sort key.  The keys are emitted in raster order (each wave compacts a contiguous quarter of the chunk,
@@ -689,7 +807,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                                  SegCand* __restrict__ candAll)
 {
     __shared__ uint32_t s_ring[RING];
-    __shared__ int s_pend[PEND];
+    __shared__ __attribute__((aligned(16))) int s_pend[PEND];
     const LineGeom& g = *gp;
     const int img = blockIdx.x, lane = threadIdx.x;
     // growFmt != nullptr: the launch behind the multi-wave kernel -- only the images that kernel gave up (-1) are grown here, and marked 1
@@ -704,7 +822,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec, precWrap = g.precWrap;
-    for (int i = lane; i < PEND; i += 64) s_pend[i] = -1;
+// (the table is cleared with 16-byte LDS stores: 4 instructions instead of a 16-trip loop of 7 -- a flush happens 1.5 k times per image)
+#define PEND_CLEAR() do { _Pragma("unroll") for (int _i = 0; _i < PEND / 256; ++_i) reinterpret_cast<int4*>(s_pend)[_i * 64 + lane] = make_int4(-1, -1, -1, -1); } while (0)
+    PEND_CLEAR();
     __builtin_amdgcn_wave_barrier();
     int nreg = 0, rbase = 0;
     int flushEpoch = 0;        // number of PEND_FLUSHes so far: between two flushes every pixel this wave has marked USED is in s_pend
@@ -733,7 +853,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 // (a window's words as loaded + every pixel marked since), and a window is never gathered again
 #define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; \
                           if (PIPE) { mask &= ~wave_vote(s_pend[addr & (PEND - 1)] == addr); deadN |= wave_vote(s_pend[addrN & (PEND - 1)] == addrN); } \
-                          __threadfence_block(); for (int _i = lane; _i < PEND; _i += 64) s_pend[_i] = -1; __builtin_amdgcn_wave_barrier(); } while (0)
+                          __threadfence_block(); PEND_CLEAR(); __builtin_amdgcn_wave_barrier(); } while (0)
 // wave-uniform: set the USED bit of pixel A (its current word is W)
 #define MARK_USED(A, W) do { const int _slot = (A) & (PEND - 1); if (s_pend[_slot] != -1) PEND_FLUSH(); \
                              if (lane == 0) { grad[(A)] = (W) | kUsed; s_pend[_slot] = (A); } __builtin_amdgcn_wave_barrier(); } while (0)
@@ -902,7 +1022,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                                            : wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
                     const unsigned long long al = wasM & cm;      // cm only ever holds live candidates
                     if (!al) break;
-                    if ((al & (al - 1ull)) == 0) {
+#ifndef OLF_GROW_SINGLE_MAX
+#define OLF_GROW_SINGLE_MAX 2      // (two aligned candidates: two plain steps are 110 instructions, a speculative round 139; from three on the round wins -- profiles/r4p_stages.txt)
+#endif
+                    if (OLF_GROW_SINGLE_MAX == 1 ? (al & (al - 1ull)) == 0 : __popcll(al) <= OLF_GROW_SINGLE_MAX) {
                         // a single aligned candidate: the plain sequential step
 #ifdef OLF_STATS
                         ++st_single;
@@ -1135,6 +1258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     }
 #undef MARK_USED
 #undef PEND_FLUSH
+#undef PEND_CLEAR
 #ifdef OLF_TIMING
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = t_seed; o[1] = t_small; o[2] = t_big; o[3] = t_rect; o[4] = n_small; o[5] = n_big; o[6] = it_small; o[7] = it_big; }
 #endif
@@ -1358,7 +1482,14 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));
     { int rc = launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lsdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 0, n_images, s);
       if (rc != OLF_OK) return rc; }
-    if (g.resizeTiled) {
+    // OLF_UPGRAD=0: enlargement and gradient as two kernels (A/B measurements)
+    static const bool upgrad = [] { const char* e = getenv("OLF_UPGRAD"); return !e || atoi(e) != 0; }();
+    const bool fused = upgrad && (g.resizeTiled & 4) && g.seedOrder == 1;
+    if (fused) {
+        const int nsx = (g.Ws + 3) / 4;
+        hipLaunchKernelGGL(k_lsd_upgrad, dim3((nsx + 63) / 64, (g.Hs + UG_ROWS - 1) / UG_ROWS, n_images), dim3(64), 0, s, b.lsdBlur, b.scaled, b.grad, b.geom, b.rx, b.ry,
+                           b.maxN, nsx);
+    } else if (g.resizeTiled) {
         int rc = launch_resize_tiled(b.lsdBlur, (size_t)g.pitchW * g.H, g.pitchW, g.W, g.H, b.scaled, (size_t)g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, b.rx,
                                      b.ry, n_images, s, (g.resizeTiled & 2) != 0);
         if (rc != OLF_OK) return rc;
@@ -1366,7 +1497,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const int quads = ((g.Ws + 3) >> 2) * g.Hs;
         hipLaunchKernelGGL(k_lsd_upsample, dim3((quads + 255) / 256, n_images), dim3(256), 0, s, b.lsdBlur, b.scaled, b.geom, b.rx, b.ry);
     }
-    hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
+    if (!fused) hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
     {
         const int nChunks = (g.Ps + LG_CHUNK - 1) / LG_CHUNK, total = nChunks * n_images;
         const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);

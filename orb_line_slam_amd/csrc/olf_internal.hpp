@@ -135,7 +135,7 @@ int launch_sep_wide(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8
                     const int* taps, int r, int n_images, hipStream_t s);
 
 bool resize_tiled_fits(const ResizeCoef* rx, const ResizeCoef* ry, int sw, int sh, int dw, int dh);
-bool resize_strip_fits(const ResizeCoef* rx, int sw, int dw);      // the register-only kernel (bit 1 of resizeTiled)
+bool resize_strip_fits(const ResizeCoef* rx, int sw, int dw, int ncols = 4);      // the register-only kernel (bit 1 of resizeTiled; ncols = 5: the fused LSD kernel, bit 2)
 int launch_resize_tiled(const uint8_t* src, size_t srcImgStride, int srcPitch, int sw, int sh, uint8_t* dst, size_t dstImgStride, int dstPitch,
                         int dw, int dh, const ResizeCoef* d_rx, const ResizeCoef* d_ry, int n_images, hipStream_t s, bool strip = false);
 

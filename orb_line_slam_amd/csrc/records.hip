@@ -132,4 +132,28 @@ int launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s)
     return OLF_OK;
 }
 
+// ---- map-point mask of freshly matched stereo points: 4 depths in, 4 mask bytes out per thread (the last thread takes the 0 .. 3 left over)
+__global__ __launch_bounds__(256) void k_depth_mask(const float* __restrict__ depth, uint8_t* __restrict__ mask, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 z = *reinterpret_cast<const float4*>(depth + i);
+        *reinterpret_cast<uint32_t*>(mask + i) = (z.x > 0.f ? 1u : 0u) | (z.y > 0.f ? 0x100u : 0u) | (z.z > 0.f ? 0x10000u : 0u) | (z.w > 0.f ? 0x1000000u : 0u);
+    } else {
+        for (size_t k = i; k < n; ++k) mask[k] = depth[k] > 0.f;
+    }
+}
+
+int launch_depth_mask(const float* depth, uint8_t* mask, size_t n, hipStream_t s)
+{
+    if (n == 0) return OLF_OK;
+    if ((reinterpret_cast<uintptr_t>(depth) & 15) || (reinterpret_cast<uintptr_t>(mask) & 3)) {
+        set_error("launch_depth_mask: depth must be 16-byte and mask 4-byte aligned"); return OLF_ERR_INVALID; }
+    const size_t nt = (n + 3) / 4;
+    if ((nt + 255) / 256 > 0x7fffffffull) { set_error("launch_depth_mask: buffer too large for one launch"); return OLF_ERR_INVALID; }
+    hipLaunchKernelGGL(k_depth_mask, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, depth, mask, n);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 }  // namespace olf

@@ -164,3 +164,21 @@ def test_search_by_bow_batch_on_device(oracle, k, L, levelsup, check):
         total += n_o
     assert total > 100 * (B - 1)
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 1027, 2064 * 13 + 2])
+def test_stereo_points_mask(n):
+    """olf_stereo_points_mask_dev: mask[i] = mvDepth[i] > 0 (src/Tracking.cc:586-588), the d_mp_valid plane of the batched SearchByBoW; lengths that are
+    not a multiple of the 4 floats one thread takes, -1 (no match), 0, NaN and denormal depths."""
+    import torch
+    from orb_line_slam_amd._lib import check as chk, lib
+    ctx = _lib.Context(_lib.default_params(), 320, 240, 2)
+    rng = np.random.default_rng(n)
+    z = rng.choice(np.array([-1.0, 0.0, -0.0, np.nan, 1e-42, 0.5, 37.25, np.inf], np.float32), size=n + 8).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    d_z = torch.from_numpy(z).to(dev); d_m = torch.full((n + 8,), 9, dtype=torch.uint8, device=dev)
+    chk(lib().olf_stereo_points_mask_dev(ctx.handle, d_z.data_ptr(), n, d_m.data_ptr(), torch.cuda.current_stream().cuda_stream), "olf_stereo_points_mask_dev")
+    torch.cuda.synchronize()
+    m = d_m.cpu().numpy()
+    assert np.array_equal(m[:n], (z[:n] > 0).astype(np.uint8)) and (m[n:] == 9).all()
+    ctx.close()

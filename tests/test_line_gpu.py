@@ -438,3 +438,51 @@ def test_convention_variants_libm_float_and_eigen_reciprocal(oracle, libm_float,
             _, _, le0 = oracle.stereo_lines(o0["kls"], o0["desc"], o0r["kls"], o0r["desc"], w, h, p0.stereo)
             differs = differs or not np.array_equal(le0.view(np.uint64), le.view(np.uint64))
     assert differs, "the convention switch changed nothing on these images"
+
+
+def test_pipelined_batches_with_input_event(oracle):
+    """olf_ctx_set_input_event: with the caller's input-ready event the line stream of a call no longer forks from the caller's stream, so the LSD front
+    of batch k + 1 runs beside the ORB / stereo tail of batch k (and beside whatever the caller queued behind it -- here device-side copies of every
+    output).  Three batches back to back on one context and ONE set of output buffers, alternating between two resident inputs, must give what the
+    same calls give one at a time."""
+    import ctypes as C
+    import torch
+    from orb_line_slam_amd import _lib
+    from orb_line_slam_amd._lib import FrameBuffers, check as chk, lib
+    w, h, n = 1242, 375, 192
+    p = oracle.full_params(2000, 500, 718.856, 386.1448)
+    dev = torch.device("cuda", 0)
+    inputs = [torch.from_numpy(np.tile(synth.stereo_batch(7400 + 10 * k, 8, w, h), (n // 8, 1, 1))).to(dev) for k in range(2)]
+    ctx = _lib.Context(p, w, h, 2 * n)
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    spec = [((2 * n, cap, 28), torch.uint8), ((2 * n, cap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, cap), torch.float32), ((n, cap), torch.float32),
+            ((2 * n, lcap, 68), torch.uint8), ((2 * n, lcap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, lcap), torch.int32), ((n, lcap, 2), torch.float32),
+            ((n, lcap, 3), torch.float64)]
+    out = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in spec]
+    fb = FrameBuffers(*[t.data_ptr() for t in out])
+    s = torch.cuda.current_stream().cuda_stream
+    order = [0, 1, 0]
+
+    def run(pipelined):
+        got = []
+        for t in out:
+            t.zero_()                                     # (rows past a count keep what the previous call left there: both runs start from the same state)
+        ev = torch.cuda.Event(); ev.record(); torch.cuda.synchronize()
+        ctx.set_input_event(ev if pipelined else None)
+        for k in order:
+            chk(lib().olf_stereo_frames_dev(ctx.handle, inputs[k].data_ptr(), n, C.byref(fb), s), "olf_stereo_frames_dev")
+            got.append([t.clone() for t in out])          # on the caller's stream, behind the call: the next call's line stream must not overtake it
+            if not pipelined:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        ctx.set_input_event(None)
+        return [[t.cpu().numpy() for t in g] for g in got]
+
+    ref, pip = run(False), run(True)
+    for i in range(len(order)):
+        for a, b in zip(ref[i], pip[i]):
+            assert a.tobytes() == b.tobytes(), i
+    assert ref[0][2].sum() > 1000 * n and not np.array_equal(ref[0][0], ref[1][0])      # key points were found, and the two inputs differ
+    assert np.array_equal(ref[0][2], ref[2][2]) and np.array_equal(ref[0][7], ref[2][7])      # (counts; rows past a count keep the previous batch's bytes)
+    ctx.close()
