@@ -806,6 +806,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                                  int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt,
                                                  SegCand* __restrict__ candAll)
 {
+    OLF_SET_AGENT_PRIO();
     __shared__ uint32_t s_ring[RING];
     __shared__ __attribute__((aligned(16))) int s_pend[PEND];
     const LineGeom& g = *gp;

@@ -30,6 +30,7 @@ constexpr int ST_TILE = 128;
 __global__ __launch_bounds__(256) void k_stereo_rowsort(const olf_keypoint* __restrict__ kps, const int* __restrict__ counts, int cap, int sortN,
                                                         unsigned* __restrict__ perm)
 {
+    OLF_SET_GUEST_PRIO();
     extern __shared__ unsigned keys[];
     const int img = blockIdx.x, tid = threadIdx.x;
     const int n = counts[img];
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void k_stereo_cand(const OrbGeom* __restrict__
                                                      const uint8_t* __restrict__ desc, const int* __restrict__ counts, int cap, float mbf,
                                                      float fx, const unsigned* __restrict__ perm, unsigned* __restrict__ bestKey)
 {
+    OLF_SET_GUEST_PRIO();
     __shared__ uint4 s_d[ST_TILE * 2];
     __shared__ int s_rows[ST_TILE];      // minr | maxr << 16
     __shared__ int s_oct[ST_TILE];
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
                                                       const unsigned* __restrict__ bestKey, float* __restrict__ uRight,
                                                       float* __restrict__ depth, int* __restrict__ sad)
 {
+    OLF_SET_GUEST_PRIO();
     __shared__ uint8_t s_strip[4][11 * 21 + 1];
     const OrbGeom& g = *gp;
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
 __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ counts, int cap, int sortN, float* __restrict__ uRight,
                                                        float* __restrict__ depth, const int* __restrict__ sad)
 {
+    OLF_SET_GUEST_PRIO();
     extern __shared__ unsigned keys[];
     __shared__ int nMatched;
     const int pair = blockIdx.x, tid = threadIdx.x;

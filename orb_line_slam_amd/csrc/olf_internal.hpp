@@ -35,6 +35,16 @@ void set_error(const std::string& s);
 #ifdef __HIPCC__
 // Wave-wide vote.  hip's __ballot() converts the predicate to an int first and compares that with 0 (a v_cndmask + v_cmp_ne pair per vote);
 // the wave64 builtin takes the compare's lane mask as it is.
+// Wave priority experiments (profiles/r4t_wave_priority_ab.txt): -DOLF_GUEST_PRIO=n raises the ORB-stream kernels that run beside the growth agents,
+// -DOLF_AGENT_PRIO=n the agents themselves (s_setprio 0 .. 3; 0 = the hardware default, no instruction emitted)
+#ifndef OLF_GUEST_PRIO
+#define OLF_GUEST_PRIO 0
+#endif
+#ifndef OLF_AGENT_PRIO
+#define OLF_AGENT_PRIO 0
+#endif
+#define OLF_SET_GUEST_PRIO() do { if (OLF_GUEST_PRIO) __builtin_amdgcn_s_setprio(OLF_GUEST_PRIO); } while (0)
+#define OLF_SET_AGENT_PRIO() do { if (OLF_AGENT_PRIO) __builtin_amdgcn_s_setprio(OLF_AGENT_PRIO); } while (0)
 __device__ __forceinline__ unsigned long long wave_vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // set bits of a lane mask below this lane (v_mbcnt pair; "__popcll(m & ((1ull << lane) - 1))" compiles to a 64-bit shift, two bit-field inserts and two counts)
 __device__ __forceinline__ int wave_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }

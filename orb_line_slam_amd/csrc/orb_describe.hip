@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
                                                   uint8_t* __restrict__ desc, int* __restrict__ counts, int out_cap,
                                                   int* __restrict__ status)
 {
+    OLF_SET_GUEST_PRIO();
     constexpr int PR = 18, PW = 2 * PR + 1, PDW = 10;      // patch radius (|rotated pattern coordinate| <= round(13 * sqrt 2) = 18), 37 rows of 10 dwords
     __shared__ uint32_t s_pat[256];
     __shared__ uint32_t s_w0[256], s_w1[256];             // IC_Angle disc as byte weights per (row, dword) slot: 1 / (u + 16) inside, 0 outside

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void k_octree(const OrbGeom* __restrict__ gp, 
                                                 uint32_t* __restrict__ lvlKp, int* __restrict__ lvlCount, int* __restrict__ status,
                                                 unsigned char* __restrict__ spill, size_t spillBytes)
 {
+    OLF_SET_GUEST_PRIO();
     extern __shared__ __align__(16) unsigned char lds_smem[];
     unsigned char* smem = SPILL ? spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * spillBytes : lds_smem;
     const OrbGeom& g = *gp;

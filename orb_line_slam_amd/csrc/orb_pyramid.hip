@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, int minTh,
                   uint32_t* __restrict__ cells, int* __restrict__ cellCount, int totalCells, int cellCap)
 {
+    OLF_SET_GUEST_PRIO();
     constexpr int FT_H = NT / 8, FT_EH = FT_H - 2, FT_INH = FT_H + 6;
     __shared__ uint32_t tile[FT_INH * FT_INW];
     __shared__ unsigned short s_cand[FT_W * FT_H];      // A1's survivors, compacted in place to the corners by A2 (s_list)
@@ -276,6 +277,7 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
 constexpr int CS_MAX = 1024;    // a cell is < 60 px wide and high (ceil(width / (width / 30))), so at most 30 x 30 strict local maxima
 __global__ __launch_bounds__(64) void k_cells_sort(const OrbGeom* __restrict__ gp, uint32_t* __restrict__ cells, int* __restrict__ cellCount)
 {
+    OLF_SET_GUEST_PRIO();
     __shared__ uint32_t s_k[CS_MAX];
     const OrbGeom& g = *gp;
     const int img = blockIdx.y, cell = blockIdx.x, lane = threadIdx.x;
