@@ -267,6 +267,9 @@ def main():
         finally:
             signal.alarm(0)
     dev = torch.device("cuda", dev_index)
+    # The path runs on torch's current stream, and that must not be the legacy default stream: its handle is NULL, which the C ABI reads as "the context's
+    # own stream" (include/orbline.h) -- the harness's events (pack -> gather hand-over) and copies would then not be ordered with the path's work.
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     cdev = dev if (dist is None or args.backend == "nccl") else torch.device("cpu")      # where the scalar reductions of the harness live
 
     cfg = CONFIGS[args.config]

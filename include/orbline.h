@@ -6,7 +6,10 @@
  *   - an olf_ctx serves one image size, one parameter block and up to max_images images per call;
  *     a stereo pair is two images: image index = 2*pair + side (0 = left, 1 = right);
  *   - *_dev entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t, NULL = the
- *     context's own stream) without synchronising; the others take HOST pointers, copy and block;
+ *     context's own stream, a non-blocking one) without synchronising; the others take HOST pointers, copy and
+ *     block.  The legacy default stream cannot be named -- its handle IS NULL -- and is not ordered with the
+ *     context's streams: a caller that works on it (torch.cuda.current_stream() outside a stream context)
+ *     has to synchronise, or work on a stream of its own and pass that;
  *   - per-image outputs are fixed-stride records: image i's key points start at
  *     kps[i * olf_orb_capacity(ctx)], descriptors at desc[i * capacity * 32]; counts[i] says how
  *     many are valid;

@@ -263,11 +263,24 @@ __global__ __launch_bounds__(64) void k_lsd_upgrad(const uint8_t* __restrict__ s
 // either side into LDS -- the neighbours' angles come from there, not from a second pass over memory -- and blocks are numbered so that
 // the chunks of an image follow each other on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, each with an L2 of its own): the
 // halo rows are then L2 hits.
-constexpr float kDegUndef = -1000.f;
+// (the level-line angle of an undefined pixel, and of every position outside the image, is NaN in the block's LDS copy: every comparison with it is false and
+// v_max / v_min skip it, so the isolated-seed test needs no bounds predicates at all -- the image's last column and last row are undefined by construction
+// (ll_angle), which makes the row-major wrap-around neighbours of columns 0 and Ws - 2 undefined pixels too)
 constexpr int KEYS_THREADS = 512;      // 8 waves share the 36 KB of LDS a chunk needs: 4 blocks = 32 waves per CU (256 threads: 14.9 ms per 6144 images, 512: 11.5, 1024: 15.5)
 // ALLKEYS (convention C.9, variant 1 -- OpenCV >= 3.3): the key of EVERY pixel with x < Ws - 1, y < Hs - 1, defined or not, at its raster position
 // y * (Ws - 1) + x of `keys` -- the vector ll_angle hands to std::sort; lsd_seedsort.hip replays that sort and writes the seed list and its
 // length, so the compacted emission below is skipped.
+// The bin of a pixel, int(sqrt(n / 4.0) * bin_coef) in double: decided in float wherever the float product is farther than 10^-3 from an integer (its error is
+// below 2.6 x 10^-4: one ulp of v_sqrt_f32, the coefficient's and the product's rounding, t <= 1023), the reference's double expression only for the rest
+__device__ __forceinline__ int lsd_bin(int n, double bin_coef, float bin_coef_half_f)
+{
+    const float tf = __builtin_amdgcn_sqrtf((float)n) * bin_coef_half_f;
+    const int b = (int)tf;
+    const float fr = tf - (float)b;
+    if (n != 0 && (fr < 1e-3f || fr > 0.999f)) return (int)(sqrt_quarter(n) * bin_coef);
+    return b;
+}
+
 template <bool OWNER, bool ALLKEYS>
 __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
                                                   int nChunks, int total)
 {
     constexpr int NWV = KEYS_THREADS / 64, SPAN = LG_CHUNK / NWV;
-    extern __shared__ float s_deg[];           // [LG_CHUNK + 2 * Ws + 2]
+    extern __shared__ float s_deg[];           // [LG_CHUNK + 2 * Ws + 2]: image positions c0 - Ws - 1 .. c0 + LG_CHUNK + Ws (NaN outside the image)
     __shared__ uint16_t s_list[LG_CHUNK];      // the chunk's defined pixels (offset in the chunk), per wave quarter, raster order
     __shared__ int s_wcnt[NWV], s_base;
     const LineGeom& g = *gp;
@@ -284,22 +297,28 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const int L = blockIdx.x, per = total >> 3;
     const int V = L < per * 8 ? (L & 7) * per + (L >> 3) : L;
     const int img = V / nChunks, chunk = V - img * nChunks;
-    const int Ws = g.Ws, Hs = g.Hs, Ps = g.Ps;
+    // (fields of *gp used inside the loops are copied out: the compiler reloads them behind every store otherwise)
+    const int Ws = g.Ws, Hs = g.Hs, Ps = g.Ps, nBins1 = g.nBins - 1;
+    const uint32_t divM = g.divWsM, divS = g.divWsS;
+    const float alignDeg = g.alignDeg;
+    const double precG = g.prec;
     uint32_t* grad = gradAll + (size_t)img * Ps;
     const int c0 = chunk * LG_CHUNK;
-    const int lo = max(0, c0 - Ws - 1), hi = min(Ps, c0 + LG_CHUNK + Ws + 1);
+    const int lo = c0 - Ws - 1, hi = c0 + LG_CHUNK + Ws + 1;      // (may leave the image at either end: NaN there)
+    const float kNaN = __builtin_nanf("");
     if (threadIdx.x == 0) s_base = 0;
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
-    const double bin_coef = (max_grad > 0) ? (double)(g.nBins - 1) / max_grad : 0;
+    const double bin_coef = (max_grad > 0) ? (double)nBins1 / max_grad : 0;
+    const float bin_coef_half_f = 0.5f * (float)bin_coef;
     // (NB independent loads in flight per thread, then their table lookups: the pass is latency bound otherwise)
     constexpr int NB = 8;
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * KEYS_THREADS) {
         uint32_t p[NB];
         float d[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) p[u] = i0 + u * KEYS_THREADS < hi ? grad[i0 + u * KEYS_THREADS] : kNotDef;
+        for (int u = 0; u < NB; ++u) { const int idx = i0 + u * KEYS_THREADS; p[u] = (unsigned)idx < (unsigned)Ps && idx < hi ? grad[idx] : kNotDef; }
 #pragma unroll
-        for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kDegUndef : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
+        for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kNaN : angDeg[p[u] & 0x3fffffu];      // fastAtan2(gx, -gy), tabulated per context
 #pragma unroll
         for (int u = 0; u < NB; ++u) if (i0 + u * KEYS_THREADS < hi) s_deg[i0 + u * KEYS_THREADS - lo] = d[u];
         if (ALLKEYS) {
@@ -310,11 +329,11 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
             for (int u = 0; u < NB; ++u) {
                 const int idx = i0 + u * KEYS_THREADS;
                 if (idx >= c0 && idx < min(Ps, c0 + LG_CHUNK)) {
-                    const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
+                    const int y = (int)(__umulhi((uint32_t)idx, divM) >> divS), x = idx - y * Ws;
                     if (x < Ws - 1 && y < Hs - 1) {
                         const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
-                        const int bin = (int)(sqrt_quarter(gx * gx + gy * gy) * bin_coef);
-                        kall[y * (Ws - 1) + x] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+                        const int bin = lsd_bin(gx * gx + gy * gy, bin_coef, bin_coef_half_f);
+                        kall[y * (Ws - 1) + x] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx;
                     }
                 }
             }
@@ -328,32 +347,35 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0 && part) atomicAdd(&s_base, part);
     }
-    {   // the defined pixels of this wave's quarter, compacted in raster order
+    // the defined pixels of the chunk, compacted in raster order: every wave counts its eighth, then writes it behind the waves before it (one dense list:
+    // the loop below then reads entry t, no search for the wave a position belongs to)
+    unsigned long long defM[SPAN / 64];
+    {
         int wc = 0;
+#pragma unroll
         for (int k = 0; k < SPAN / 64; ++k) {
-            const int li = wv * SPAN + k * 64 + lane;
-            const bool def = c0 + li < Ps && s_deg[c0 + li - lo] != kDegUndef;
-            const unsigned long long m = wave_vote(def);
-            if (def) s_list[wv * SPAN + wc + wave_rank_below(m)] = (uint16_t)li;
-            wc += __popcll(m);
+            const float dv = s_deg[c0 + wv * SPAN + k * 64 + lane - lo];
+            defM[k] = wave_vote(dv == dv);          // (not NaN; positions beyond the image are NaN too)
+            wc += __popcll(defM[k]);
         }
         if (lane == 0) s_wcnt[wv] = wc;
     }
     __syncthreads();
-    int nEnd[NWV];      // end of each wave's run in the dense order
-    { int acc = 0;
+    int n3 = 0, wbase = 0;
 #pragma unroll
-      for (int v = 0; v < NWV; ++v) { acc += s_wcnt[v]; nEnd[v] = acc; } }
-    const int n3 = nEnd[NWV - 1];
+    for (int v = 0; v < NWV; ++v) { const int cv = s_wcnt[v]; if (v < wv) wbase += cv; n3 += cv; }
+#pragma unroll
+    for (int k = 0; k < SPAN / 64; ++k) {
+        if (wave_bit(defM[k])) s_list[wbase + wave_rank_below(defM[k])] = (uint16_t)(wv * SPAN + k * 64 + lane);
+        wbase += __popcll(defM[k]);
+    }
+    __syncthreads();
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
     // (ALLKEYS: a per-block table of the undefined pixels' bins -- gx^2 + gy^2 < nThr -- with the defined ones keyed by the dense loop below was
     // slower, 22.8 against 16.9 ms per 6144 images: the dense loop's stores then scatter and nearly every wave still holds a defined pixel)
     // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
     for (int t = threadIdx.x; t < n3; t += KEYS_THREADS) {
-        int w = 0, before = 0;
-#pragma unroll
-        for (int v = 0; v < NWV - 1; ++v) if (t >= nEnd[v]) { w = v + 1; before = nEnd[v]; }
-        const int li = s_list[w * SPAN + t - before];
+        const int li = s_list[t];
         const int idx = c0 + li;
         uint32_t p = 0;
         int bin = 0;
@@ -362,42 +384,38 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
             const int gx = unpack_gx(p), gy = unpack_gy(p);
             bin = (int)(sqrt_quarter(gx * gx + gy * gy) * bin_coef);
         }
-        const int y = (int)(__umulhi((uint32_t)idx, g.divWsM) >> g.divWsS), x = idx - y * Ws;
-        const float deg0 = s_deg[idx - lo];
+        const float* sd = s_deg + (idx - lo);
+        const float deg0 = sd[0];
         // isaligned() on two angles in degrees a, b: with t = | |a - b| - 180 | it is t >= 180 - ang_th (|a - b| <= ang_th, or >= 360 - ang_th after the
-        // wrap); an undefined neighbour (-1000) gives t > 800.  Decided in float wherever t is farther than 10^-3 degrees from the boundary (the
-        // float differences are good to 10^-4, the reference's double radians to 10^-13); the exact double form only for the rest
-        bool iso = true;
-        float margin = 1.0f;
-        const bool xl = x > 0, xr = x < Ws - 1, yu = y > 0, yd = y < Hs - 1;
+        // wrap), i.e. d = t - alignDeg >= 0; an undefined or outside neighbour gives NaN.  Decided in float wherever d is farther than 10^-3 degrees from 0
+        // (the float differences are good to 10^-4, the reference's double radians to 10^-13); the exact double form only for the rest
+        float dmax = -1.f, margin = 1.0f;
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
             if (q == 4) continue;
-            const int dx = (q % 3) - 1, dy = (q / 3) - 1;
-            const bool inb = (dx < 0 ? xl : dx > 0 ? xr : true) && (dy < 0 ? yu : dy > 0 ? yd : true);
-            const float dn = s_deg[idx - lo + dy * Ws + dx];
-            const float t = fabsf(f_sub(fabsf(f_sub(deg0, dn)), 180.f));
-            if (inb) { if (t >= g.alignDeg && t <= 181.f) iso = false; margin = fminf(margin, fabsf(f_sub(t, g.alignDeg))); }
+            const float dn = sd[((q / 3) - 1) * Ws + (q % 3) - 1];
+            const float dd = f_sub(fabsf(f_sub(fabsf(f_sub(deg0, dn)), 180.f)), alignDeg);
+            dmax = fmaxf(dmax, dd);
+            margin = fminf(margin, fabsf(dd));
         }
-        if (margin < 1e-3f || g.alignDeg < 0.f) {
+        bool iso = !(dmax >= 0.f);
+        if (margin < 1e-3f || alignDeg < 0.f) {
             const double a0 = d_mul((double)deg0, kDegToRads);
             iso = true;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 if (q == 4) continue;
-                const int dx = (q % 3) - 1, dy = (q / 3) - 1;
-                if (x + dx < 0 || x + dx >= Ws || y + dy < 0 || y + dy >= Hs) continue;
-                const float dn = s_deg[idx - lo + dy * Ws + dx];
-                if (dn == kDegUndef) continue;
+                const float dn = sd[((q / 3) - 1) * Ws + (q % 3) - 1];
+                if (dn != dn) continue;
                 double n_theta = d_sub(a0, d_mul((double)dn, kDegToRads));
                 if (n_theta < 0) n_theta = -n_theta;
                 if (n_theta > kM32PI) { n_theta = d_sub(n_theta, kM2PI); if (n_theta < 0) n_theta = -n_theta; }
-                if (n_theta <= g.prec) iso = false;
+                if (n_theta <= precG) iso = false;
             }
         }
         if (iso) grad[idx] = (ALLKEYS ? grad[idx] : p) | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
-        if (!ALLKEYS) kout[t] = ((uint32_t)(g.nBins - 1 - bin) << 22) | (uint32_t)idx;
+        if (!ALLKEYS) kout[t] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx;
     }
     if (!ALLKEYS && chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
@@ -500,13 +518,23 @@ __global__ __launch_bounds__(256) void k_fdiv_sweep(unsigned long long seed, int
     if (bad) atomicAdd(mismatches, bad);
 }
 
-// debug / test: sqrt_quarter against the compiler's sqrt on every n in [0, count)
+// debug / test: sqrt_quarter against the compiler's sqrt, and lsd_bin against the double expression, on every n in [0, count)
 __global__ __launch_bounds__(256) void k_sqrtq_sweep(int count, unsigned long long* __restrict__ mismatches)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= count) return;
     const double a = sqrt((double)n / 4.0), b = sqrt_quarter(n);
     if (__double_as_longlong(a) != __double_as_longlong(b)) atomicAdd(mismatches, 1ull);
+    // ... and the float-first bin of k_lsd_keys against the reference's double expression, for 97 image maxima between 36 and the largest norm a pair of
+    // 8-bit differences can have (every n that can occur under each of them)
+    int bad = 0;
+    for (int c = 0; c < 97; ++c) {
+        const int mN = 36 + c * 5418;      // ... 520 164 (gx, gy in [-510, 510])
+        if (n > mN) continue;
+        const double bin_coef = 1023.0 / sqrt((double)mN / 4.0);
+        bad += lsd_bin(n, bin_coef, 0.5f * (float)bin_coef) != (int)(a * bin_coef);
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s)

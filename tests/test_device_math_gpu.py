@@ -18,7 +18,8 @@ def test_agent_division_is_ieee_exact():
 
 def test_key_kernel_sqrt_is_ieee_exact():
     """k_lsd_keys takes sqrt(n / 4.0) of n = gx^2 + gy^2 <= 2 * 510^2 with the compiler's expansion stripped of its range scaling (lsd_device.hpp
-    sqrt_quarter): every n up to 2^20 must give the bits of the IEEE square root."""
+    sqrt_quarter): every n up to 2^20 must give the bits of the IEEE square root.  The same sweep checks the float-first bin (lsd.hip lsd_bin: float product,
+    the double expression only within 10^-3 of an integer) against int(sqrt(n / 4.0) * bin_coef) for 97 image maxima and every n that can occur under them."""
     ctx = _lib.Context(_lib.default_params(), 640, 480, 1)
     bad = C.c_uint64(123)
     _lib.check(_lib.lib().olf_debug_sqrtq_sweep(ctx.handle, 1 << 20, C.byref(bad)), "olf_debug_sqrtq_sweep")

@@ -460,21 +460,27 @@ def test_pipelined_batches_with_input_event(oracle):
             ((n, lcap, 3), torch.float64)]
     out = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in spec]
     fb = FrameBuffers(*[t.data_ptr() for t in out])
-    s = torch.cuda.current_stream().cuda_stream
-    order = [0, 1, 0]
+    # (a stream of the caller's own: torch's default stream has the handle NULL, which the C ABI reads as "the context's stream" -- the copies below
+    # would then run on a stream that is not ordered with the calls)
+    st = torch.cuda.Stream(dev)
+    s = st.cuda_stream
+    assert s != 0
+    order = [0, 1, 0, 1]
 
     def run(pipelined):
         got = []
-        for t in out:
-            t.zero_()                                     # (rows past a count keep what the previous call left there: both runs start from the same state)
-        ev = torch.cuda.Event(); ev.record(); torch.cuda.synchronize()
-        ctx.set_input_event(ev if pipelined else None)
-        for k in order:
-            chk(lib().olf_stereo_frames_dev(ctx.handle, inputs[k].data_ptr(), n, C.byref(fb), s), "olf_stereo_frames_dev")
-            got.append([t.clone() for t in out])          # on the caller's stream, behind the call: the next call's line stream must not overtake it
-            if not pipelined:
-                torch.cuda.synchronize()
         torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            for t in out:
+                t.zero_()                                     # (rows past a count keep what the previous call left there: both runs start from the same state)
+            ev = torch.cuda.Event(); ev.record(st); torch.cuda.synchronize()
+            ctx.set_input_event(ev if pipelined else None)
+            for k in order:
+                chk(lib().olf_stereo_frames_dev(ctx.handle, inputs[k].data_ptr(), n, C.byref(fb), s), "olf_stereo_frames_dev")
+                got.append([t.clone() for t in out])          # on the caller's stream, behind the call: the next call's line stream must not overtake it
+                if not pipelined:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
         ctx.synchronize()
         ctx.set_input_event(None)
         return [[t.cpu().numpy() for t in g] for g in got]
@@ -483,6 +489,7 @@ def test_pipelined_batches_with_input_event(oracle):
     for i in range(len(order)):
         for a, b in zip(ref[i], pip[i]):
             assert a.tobytes() == b.tobytes(), i
-    assert ref[0][2].sum() > 1000 * n and not np.array_equal(ref[0][0], ref[1][0])      # key points were found, and the two inputs differ
+    assert ref[0][2].sum() > 1000 * n and not np.array_equal(ref[0][0], ref[1][0])      # key points were found (by the FIRST call already), and the two inputs differ
     assert np.array_equal(ref[0][2], ref[2][2]) and np.array_equal(ref[0][7], ref[2][7])      # (counts; rows past a count keep the previous batch's bytes)
+    assert np.array_equal(ref[1][2], ref[3][2]) and not np.array_equal(ref[0][2], ref[1][2])
     ctx.close()
