@@ -281,15 +281,17 @@ __device__ __forceinline__ int lsd_bin(int n, double bin_coef, float bin_coef_ha
     return b;
 }
 
-template <bool OWNER, bool ALLKEYS>
+// CH: pixels per block (CH for the compacted emission, whose chunk counts come from k_lsd_grad; ALLKEYS may take larger chunks: the two halo rows a
+// block evaluates on top of its chunk are 73 % extra at 4096 pixels and a 1490-pixel row, 36 % at 8192)
+template <bool OWNER, bool ALLKEYS, int CH>
 __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
                                                   int* __restrict__ keyCount, uint32_t* __restrict__ owner, const float* __restrict__ angDeg,
                                                   int nChunks, int total)
 {
-    constexpr int NWV = KEYS_THREADS / 64, SPAN = LG_CHUNK / NWV;
-    extern __shared__ float s_deg[];           // [LG_CHUNK + 2 * Ws + 2]: image positions c0 - Ws - 1 .. c0 + LG_CHUNK + Ws (NaN outside the image)
-    __shared__ uint16_t s_list[LG_CHUNK];      // the chunk's defined pixels (offset in the chunk), per wave quarter, raster order
+    constexpr int NWV = KEYS_THREADS / 64, SPAN = CH / NWV;
+    extern __shared__ float s_deg[];           // [CH + 2 * Ws + 2]: image positions c0 - Ws - 1 .. c0 + CH + Ws (NaN outside the image)
+    __shared__ uint16_t s_list[CH];      // the chunk's defined pixels (offset in the chunk), per wave quarter, raster order
     __shared__ int s_wcnt[NWV], s_base;
     const LineGeom& g = *gp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -303,8 +305,8 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const float alignDeg = g.alignDeg;
     const double precG = g.prec;
     uint32_t* grad = gradAll + (size_t)img * Ps;
-    const int c0 = chunk * LG_CHUNK;
-    const int lo = c0 - Ws - 1, hi = c0 + LG_CHUNK + Ws + 1;      // (may leave the image at either end: NaN there)
+    const int c0 = chunk * CH;
+    const int lo = c0 - Ws - 1, hi = c0 + CH + Ws + 1;      // (may leave the image at either end: NaN there)
     const float kNaN = __builtin_nanf("");
     if (threadIdx.x == 0) s_base = 0;
     const double max_grad = sqrt((double)maxN[img * 32] / 4.0);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int idx = i0 + u * KEYS_THREADS;
-                if (idx >= c0 && idx < min(Ps, c0 + LG_CHUNK)) {
+                if (idx >= c0 && idx < min(Ps, c0 + CH)) {
                     const int y = (int)(__umulhi((uint32_t)idx, divM) >> divS), x = idx - y * Ws;
                     if (x < Ws - 1 && y < Hs - 1) {
                         const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
@@ -1528,17 +1530,23 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     }
     if (!fused) hipLaunchKernelGGL(k_lsd_grad, dim3((g.Ps + LG_CHUNK - 1) / LG_CHUNK, n_images), dim3(256), 0, s, b.scaled, b.grad, b.geom, b.maxN, b.chunkCnt);
     {
-        const int nChunks = (g.Ps + LG_CHUNK - 1) / LG_CHUNK, total = nChunks * n_images;
-        const size_t lds = (size_t)(LG_CHUNK + 2 * g.Ws + 2) * sizeof(float);
+        // (ALLKEYS, OLF_KEYS_CHUNK=8192: 8192-pixel chunks -- the stage alone 62.6 against 63.4 ms per 6144 images, the two-stream step 231-236 against 232-234:
+        // two blocks of 61 KB per CU overlap worse with the pyramid beside them than four of 36 KB; 4096 stays the default, profiles/r4y_keys_chunk_ab.txt)
+        static const int envCh = getenv("OLF_KEYS_CHUNK") ? atoi(getenv("OLF_KEYS_CHUNK")) : 4096;
+        const bool big = g.seedOrder == 1 && envCh == 8192 && (size_t)(8192 + 2 * g.Ws + 2) * sizeof(float) + 8192 * 2 + 64 <= 64 * 1024;
+        const int CHK = big ? 8192 : LG_CHUNK;
+        const int nChunks = (g.Ps + CHK - 1) / CHK, total = nChunks * n_images;
+        const size_t lds = (size_t)(CHK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
         const bool ow = lsd_grow_path(g, b, n_images) != 0;
+#define KEYS_LAUNCH(OW, AK, C, KBUF) hipLaunchKernelGGL((k_lsd_keys<OW, AK, C>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, KBUF, b.keyCount, b.owner, b.angDeg, nChunks, total)
         if (g.seedOrder == 1) {
-            if (ow) hipLaunchKernelGGL((k_lsd_keys<true, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
-            else hipLaunchKernelGGL((k_lsd_keys<false, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            if (big) { if (ow) KEYS_LAUNCH(true, true, 8192, b.keysA); else KEYS_LAUNCH(false, true, 8192, b.keysA); }
+            else { if (ow) KEYS_LAUNCH(true, true, LG_CHUNK, b.keysA); else KEYS_LAUNCH(false, true, LG_CHUNK, b.keysA); }
         } else {
-            if (ow) hipLaunchKernelGGL((k_lsd_keys<true, false>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
-            else hipLaunchKernelGGL((k_lsd_keys<false, false>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysB, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            if (ow) KEYS_LAUNCH(true, false, LG_CHUNK, b.keysB); else KEYS_LAUNCH(false, false, LG_CHUNK, b.keysB);
         }
+#undef KEYS_LAUNCH
     }
     OLF_HIP_CHECK(hipGetLastError());
     if (b.sortEvent) OLF_HIP_CHECK(hipEventRecord(b.sortEvent, s));
