@@ -1348,7 +1348,7 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
             if (q0 + u < n) {
                 const int px = (int)(rp[u] & 0xffffu), py = (int)(rp[u] >> 16);
                 const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
-                const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const double wt = sqrt_quarter(gx * gx + gy * gy);      // (= sqrt(n / 4.0) bit for bit: tests/test_device_math_gpu.py)
                 x = d_add(x, d_mul((double)px, wt));
                 y = d_add(y, d_mul((double)py, wt));
                 sum = d_add(sum, wt);
@@ -1376,7 +1376,7 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
             if (q0 + u < n) {
                 const int px = (int)(rp[u] & 0xffffu), py = (int)(rp[u] >> 16);
                 const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
-                const double wt = sqrt((double)(gx * gx + gy * gy) / 4.0);
+                const double wt = sqrt_quarter(gx * gx + gy * gy);      // (= sqrt(n / 4.0) bit for bit: tests/test_device_math_gpu.py)
                 const double ex = d_sub((double)px, x), ey = d_sub((double)py, y);
                 Ixx = d_add(Ixx, d_mul(d_mul(ey, ey), wt));
                 Iyy = d_add(Iyy, d_mul(d_mul(ex, ex), wt));
@@ -1620,6 +1620,9 @@ int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         hipLaunchKernelGGL(k_lsd_rect_mixed, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
                            reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks, b.growFmt);
     else
+        // (one thread per region in index order.  Dealing an image's regions out by size -- one block per image, (size, index) keys sorted in LDS, so that a wave's 64
+        // lists have similar lengths -- was built and measured: 10.2 against 8.1 ms per 6144 images (profiles/r4ac_rect_sorted_ab.txt); the fit waits for its list
+        // loads, not for the longest list of its wave)
         hipLaunchKernelGGL(k_lsd_rect<false>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
                            reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);
     hipLaunchKernelGGL(k_lsd_emit, dim3(n_images), dim3(256), 0, s, b.geom, reinterpret_cast<const SegCand*>(b.keysB), b.regCount, b.rawLines,
