@@ -143,16 +143,13 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const unsigned long long*
                         __popc(a1.z ^ x1.z) + __popc(a1.w ^ x1.w);
                 }
                 // smallest (distance, lane) of the chunk, then the smallest distance among the other lanes
-                int key = (d << 6) | lane;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));
+                // (DPP minima with a scalar result: the two 6-step butterflies through the LDS crossbar were the dependent chain of this serial walk)
+                const int key = wave_min_i32((d << 6) | lane);
                 const int c1 = key >> 6, cl = key & 63;
-                int d2 = lane == cl ? 0x7fff : d;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) d2 = min(d2, __shfl_xor(d2, o));
+                const int d2 = wave_min_i32(lane == cl ? 0x7fff : d);
                 if (c1 < 0x7fff) {
                     // the chunk's candidates come after the earlier chunks' in the reference's scan: `<` keeps the earlier one on a tie
-                    const int ci = __shfl(iF, cl);
+                    const int ci = __builtin_amdgcn_readlane(iF, cl);
                     if (c1 < b1) { b2 = min(b1, min(d2, 256)); b1 = c1; bi = ci; }
                     else b2 = min(b2, c1);
                 }

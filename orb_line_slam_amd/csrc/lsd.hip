@@ -1340,8 +1340,14 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
 #pragma unroll
             for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
         } else {
+            // (two log entries per 16-byte load: a wave's 64 lists are 64 different cache lines per instruction, and the fit waits for the texture path)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint2 e = q0 + u < n ? log2[q0 + u] : make_uint2(0u, 0u); rp[u] = e.x; p[u] = e.y; }
+            for (int u = 0; u < U; u += 2) {
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (q0 + u + 1 < n) __builtin_memcpy(&e, log2 + q0 + u, 16);
+                else if (q0 + u < n) { const uint2 e1 = log2[q0 + u]; e.x = e1.x; e.y = e1.y; }
+                rp[u] = e.x; p[u] = e.y; rp[u + 1] = e.z; p[u + 1] = e.w;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1368,8 +1374,14 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
 #pragma unroll
             for (int u = 0; u < U; ++u) p[u] = grad[(int)(rp[u] >> 16) * Ws + (int)(rp[u] & 0xffffu)];
         } else {
+            // (two log entries per 16-byte load: a wave's 64 lists are 64 different cache lines per instruction, and the fit waits for the texture path)
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint2 e = q0 + u < n ? log2[q0 + u] : make_uint2(0u, 0u); rp[u] = e.x; p[u] = e.y; }
+            for (int u = 0; u < U; u += 2) {
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (q0 + u + 1 < n) __builtin_memcpy(&e, log2 + q0 + u, 16);
+                else if (q0 + u < n) { const uint2 e1 = log2[q0 + u]; e.x = e1.x; e.y = e1.y; }
+                rp[u] = e.x; p[u] = e.y; rp[u + 1] = e.z; p[u + 1] = e.w;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1409,7 +1421,12 @@ __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int 
             for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? blk[u] : 0u;
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) rp[u] = q0 + u < n ? log2[q0 + u].x : 0u;
+            for (int u = 0; u < U; u += 2) {
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (q0 + u + 1 < n) __builtin_memcpy(&e, log2 + q0 + u, 16);
+                else if (q0 + u < n) e.x = log2[q0 + u].x;
+                rp[u] = e.x; rp[u + 1] = e.z;
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

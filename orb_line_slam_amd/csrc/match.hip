@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
                 a[k] = idx < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
             }
             __builtin_amdgcn_wave_barrier();
-            int dists[11];
+            // the 11 sums of absolute differences: per lane two shifts' partial sums share a dword (a sum is below 121 * 255 < 2^15), six wave sums through
+            // DPP instead of eleven butterflies through the LDS crossbar (66 dependent ds_bpermute per key point were most of the kernel's latency)
+            int part[11];
 #pragma unroll
             for (int inc = -Ls; inc <= Ls; ++inc) {
                 const int cR = strip[w * 21 + (w + Ls) + inc];
@@ -203,10 +205,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
                         s += df < 0 ? -df : df;
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                dists[inc + Ls] = s;
+                part[inc + Ls] = s;
             }
+            int dists[11];
+#pragma unroll
+            for (int k = 0; k < 10; k += 2) {
+                const int t = wave_sum_i32(part[k] | (part[k + 1] << 16));
+                dists[k] = t & 0xffff; dists[k + 1] = (int)((unsigned)t >> 16);
+            }
+            dists[10] = wave_sum_i32(part[10]);
             int bestS = 0x7fffffff, bestinc = 0;
 #pragma unroll
             for (int k = 0; k < 11; ++k)

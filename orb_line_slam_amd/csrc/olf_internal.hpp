@@ -45,6 +45,25 @@ void set_error(const std::string& s);
 #endif
 #define OLF_SET_GUEST_PRIO() do { if (OLF_GUEST_PRIO) __builtin_amdgcn_s_setprio(OLF_GUEST_PRIO); } while (0)
 #define OLF_SET_AGENT_PRIO() do { if (OLF_AGENT_PRIO) __builtin_amdgcn_s_setprio(OLF_AGENT_PRIO); } while (0)
+// sum over the 64 lanes of a wave, wave-uniform result: two quad permutes, the two row mirrors (DPP, no LDS), then the four rows' sums through scalar registers
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);       // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);      // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);      // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// minimum over the 64 lanes of a wave (signed), wave-uniform result: the same four DPP steps, then the four rows' minima through scalar registers
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 __device__ __forceinline__ unsigned long long wave_vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // set bits of a lane mask below this lane (v_mbcnt pair; "__popcll(m & ((1ull << lane) - 1))" compiles to a 64-bit shift, two bit-field inserts and two counts)
 __device__ __forceinline__ int wave_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }

@@ -15,16 +15,6 @@ __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "orb_pattern_31.inc"
 };
 
-// sum over the 64 lanes of a wave, wave-uniform result: two quad permutes, the two row mirrors (DPP, no LDS), then the four rows' sums through scalar registers
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]
-    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);       // quad_perm [2, 3, 0, 1]
-    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);      // row_half_mirror
-    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);      // row_mirror
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-}
-
 #ifndef OLF_DESC_KPW
 #define OLF_DESC_KPW 1
 #endif

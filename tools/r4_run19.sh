@@ -1,0 +1,21 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4ae; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+timeout 1800 python -m pytest $R/tests -q -x -m gpu -p no:cacheprovider 2>&1 | tail -2 | tee $O/pytest.txt
+stage() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d.get('stages_ms_per_step',{})
+print('$1', 'fps', d['value'], 'ms_per_step', d['ms_per_step'], {k: round(v,1) for k,v in s.items()})"; }
+B="--no-cpu-baseline --no-extras --no-isolated"
+for rep in 1 2; do
+OLF_ONE_STREAM=1 timeout 300 python $R/bench.py $B --steps 4 --warmup 2 2>/dev/null | tail -1 | stage "one-stream"
+done | tee $O/stages.txt
+for rep in 1 2 3; do
+timeout 300 python $R/bench.py $B --steps 8 --warmup 2 2>/dev/null | tail -1 | stage "two-stream"
+done | tee -a $O/stages.txt
+rm -rf /tmp/ks1; OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o run -- python $R/bench.py $B --steps 3 --warmup 1 > /tmp/ks1.log 2>&1
+python - <<PY | tee $O/kstats.txt
+import csv, glob
+for r in list(csv.DictReader(open(glob.glob('/tmp/ks1/*kernel_stats.csv')[0])))[:30]:
+    print("%-60s calls %4s avg %9.3f ms  %5.1f%%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, float(r["Percentage"])))
+PY
