@@ -125,21 +125,24 @@ __global__ __launch_bounds__(256) void k_sep7(const uint8_t* __restrict__ src, s
 // BORDER_REFLECT_101 in y is an index computation per row; the strips whose window leaves the image in x (strip 0, strips beyond nsx) are a second, small
 // launch of the same kernel with a byte-wise row window (k_sep7_strip<true>).
 constexpr int SS_ROWS = 16;
+#ifndef OLF_SS_BROWS
+#define OLF_SS_BROWS 8
+#endif
+constexpr int SS_BROWS = OLF_SS_BROWS;       // rows per thread of the border strips (k_sep7_strip)
 
 __device__ __forceinline__ int ss_reflect(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * (n - 1) - p : p; }
 
 // BORDER: the strips whose window leaves the image -- strip 0 and the strips right of nsx -- with the row window assembled byte by byte under
 // BORDER_REFLECT_101 and the quad stored byte by byte; a separate small launch, so that no wave of the interior pays for it.
-template <bool BORDER>
-__global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, uint8_t* __restrict__ dst,
-                                                    size_t dstImgStride, int dstPitch, int W, int H, Taps7 taps, int nsx, int nsy)
+template <bool BORDER, int ROWS>
+__device__ __forceinline__ void sep7_strip_body(const int t, const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, uint8_t* __restrict__ dst,
+                                                size_t dstImgStride, int dstPitch, int W, int H, const Taps7& taps, int nsx, int nsy)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int nb = BORDER ? 1 + ((W + 3) / 4 - (nsx + 1)) : nsx;      // strips per strip row of this launch
+    const int nb = BORDER ? 1 + ((W + 3) / 4 - (nsx + 1)) : nsx;      // strips per strip row of this part
     if (t >= nb * nsy) return;
     const int sy = t / nb, si = t - sy * nb;
     const int sx = BORDER ? (si == 0 ? 0 : nsx + si) : si + 1;
-    const int x0 = 4 * sx, y0 = sy * SS_ROWS;
+    const int x0 = 4 * sx, y0 = sy * ROWS;
     const uint8_t* s = src + (size_t)blockIdx.y * srcImgStride + (x0 - 4);
     uint8_t* d = dst + (size_t)blockIdx.y * dstImgStride + x0;
     const uint32_t tlo = (uint32_t)taps.t[0] | ((uint32_t)taps.t[1] << 8) | ((uint32_t)taps.t[2] << 16) | ((uint32_t)taps.t[3] << 24);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 4; ++c) Pj[c] = a[c] | (b[c] << 16);
     };
-    uint32_t P[SS_ROWS / 2 + 3][4];
+    uint32_t P[ROWS / 2 + 3][4];
     Raw nx[4];      // the four input rows of the NEXT group of output rows: requested one group ahead, so that their latency (and the acknowledgement of the
                     // stores in between: one counter for both on this part) is covered by a group's arithmetic
     {
@@ -198,10 +201,10 @@ __global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ 
         pair(r0, r1, P[0]); pair(r2, r3, P[1]); pair(r4, r5, P[2]);
     }
 #pragma unroll
-    for (int g = 0; g < SS_ROWS / 4; ++g) {
+    for (int g = 0; g < ROWS / 4; ++g) {
         // output rows y0 + 4g .. y0 + 4g + 3 need image rows y0 + 4g - 3 .. y0 + 4g + 6 = pairs 2g .. 2g + 4
         const Raw c0 = nx[0], c1 = nx[1], c2 = nx[2], c3 = nx[3];
-        if (g + 1 < SS_ROWS / 4) {
+        if (g + 1 < ROWS / 4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) nx[k] = load_row(y0 + 4 * (g + 1) + 3 + k);
             __builtin_amdgcn_sched_barrier(0);      // (the requests stay in front of the arithmetic below)
@@ -234,6 +237,18 @@ __global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ 
     }
 }
 
+// The interior strips (16 rows per thread, 70 VGPRs) and the strips whose window leaves the image in x (a byte-wise row window; SS_BROWS = 8 rows per thread: twice
+// the threads and half the dependent chain of the 16-row form, which took 0.21 ms alone and up to 22 ms in the seed sort's shadow, where 72 threads per
+// image get no issue slots and everything behind them on the ORB stream waits; same-box step times 227.0 / 227.0 / 226.7 ms with 8 rows, 227.3 / 227.3 / 228.3
+// with 4, 227.5 / 227.7 / 227.6 with 16: profiles/r4ag_border_strip_rows_ab.txt).  Two launches: as two halves of one kernel the interior strips
+// inherit the border part's 145 VGPRs (two waves per SIMD).
+template <bool BORDER>
+__global__ __launch_bounds__(256) void k_sep7_strip(const uint8_t* __restrict__ src, size_t srcImgStride, int srcPitch, uint8_t* __restrict__ dst,
+                                                    size_t dstImgStride, int dstPitch, int W, int H, Taps7 taps, int nsx, int nsy)
+{
+    sep7_strip_body<BORDER, BORDER ? SS_BROWS : SS_ROWS>(blockIdx.x * 256 + threadIdx.x, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, taps, nsx, nsy);
+}
+
 int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* dst, size_t dstImgStride, int dstPitch, int W, int H,
                 const int* taps7, int n_images, hipStream_t s)
 {
@@ -251,8 +266,9 @@ int launch_sep7(const uint8_t* src, size_t srcImgStride, int srcPitch, uint8_t* 
     static const bool strips = [] { const char* e = getenv("OLF_SEP7"); return !e || atoi(e) != 0; }();
     if (strips && W >= 16 && H >= 8 && (dstPitch & 3) == 0 && (dstImgStride & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
         const int nsx = (W - 7) / 4, nsy = (H + SS_ROWS - 1) / SS_ROWS, nb = 1 + ((W + 3) / 4 - (nsx + 1));
+        const int nsyB = (H + SS_BROWS - 1) / SS_BROWS;
         hipLaunchKernelGGL(k_sep7_strip<false>, dim3((nsx * nsy + 255) / 256, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, t, nsx, nsy);
-        hipLaunchKernelGGL(k_sep7_strip<true>, dim3((nb * nsy + 255) / 256, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, t, nsx, nsy);
+        hipLaunchKernelGGL(k_sep7_strip<true>, dim3((nb * nsyB + 255) / 256, n_images), dim3(256), 0, s, src, srcImgStride, srcPitch, dst, dstImgStride, dstPitch, W, H, t, nsx, nsyB);
         OLF_HIP_CHECK(hipGetLastError());
         return OLF_OK;
     }
