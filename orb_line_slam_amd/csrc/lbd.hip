@@ -149,16 +149,24 @@ __global__ __launch_bounds__(64) void k_lbd_prep(const LineGeom* __restrict__ gp
     o[63] = make_float2(dL0, dL1);
 }
 
-// one thread per (line, support-region row): the four weighted row sums of computeLBD (:1143-1196)
+// one wave per line, one lane per support-region row: the four weighted row sums of computeLBD (:1143-1196).
+// The sums of a row are sequential float chains over its samples, so a lane walks its row; with the lanes of a wave being the 63 rows of a line, a sample
+// step of a mostly HORIZONTAL line touches 63 image rows -- 63 cache lines per load instruction, and the kernel ran at the texture path's rate of one line per
+// cycle (12 ms per 6144 x 500 lines, 24 GB of useful samples).  For such lines the 16 samples x 63 rows of a step are loaded TRANSPOSED: every lane writes its
+// row's 16 pixel offsets to LDS, the wave loads them as (4 rows x 16 consecutive samples) per instruction -- 4 to 8 cache lines -- and hands the values back
+// through the same LDS words.  Steep lines keep the direct form (their rows are horizontal: 63 neighbouring pixels per instruction as it is).
+constexpr int LR_U = 16, LR_P = LR_U + 1;      // samples per step; row pitch of the LDS tile in words (17: lanes = rows and lanes = samples both hit distinct banks)
 __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ dxdyAll,
                                                   const olf_keyline* __restrict__ kls, const int* __restrict__ counts,
-                                                  const float2* __restrict__ starts, float4* __restrict__ rowSums)
+                                                  const float2* __restrict__ starts, float4* __restrict__ rowSums, int transposeFlat)
 {
+    __shared__ uint32_t s_t[4][64 * LR_P];
     const LineGeom& g = *gp;
-    const int img = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int li = t / 63, hID = t - li * 63;
+    const int img = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = blockIdx.x * 4 + wv;
     if (li >= counts[img]) return;
+    const bool rowAct = lane < 63;
+    const int hID = rowAct ? lane : 62;          // (lane 63 shadows row 62: valid coordinates, nothing stored)
     const uint32_t* dxdy = dxdyAll + (size_t)img * g.pitchD * g.H;
     const short lengthOfLSP = (short)kls[(size_t)img * g.outCap + li].numOfPixels;
     const int realWidth = g.pitchD;      // row stride of the gradient image (the reference's realWidth, padded to a multiple of 4 pixels)
@@ -167,23 +175,43 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
     const float2 dL = st[63], s0 = st[hID];
     const float dL0 = dL.x, dL1 = dL.y;
     const float dO0 = -dL1, dO1 = dL0;
-    const float sCorX0 = s0.x, sCorY0 = s0.y;
-    float sCorX = sCorX0, sCorY = sCorY0;
+    float sCorX = s0.x, sCorY = s0.y;
     float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-    // the sample coordinates are a cheap sequential float chain, the sums a sequential one on the loaded values: 8 samples are
-    // addressed and loaded per step so that their loads are in flight together (the kernel is latency bound), then accumulated in order
-    constexpr int U = 16;
+    const bool flat = transposeFlat && fabsf(dL0) >= fabsf(dL1);      // (wave-uniform: one line per wave)
+    uint32_t* tb = s_t[wv];
+    // the sample coordinates are a cheap sequential float chain, the sums a sequential one on the loaded values: 16 samples are
+    // addressed and loaded per step so that their loads are in flight together, then accumulated in order
+    constexpr int U = LR_U;
     for (int w0 = 0; w0 < lengthOfLSP; w0 += U) {
         uint32_t p[U];
+        int off[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int tc = (int)(short)roundf(sCorX);
             const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
             tc = (int)(short)roundf(sCorY);
             const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
-            p[u] = dxdy[yCor * realWidth + xCor];           // (coordinates past the row end are clamped into the image, the value is unused)
+            off[u] = yCor * realWidth + xCor;           // (coordinates past the row end are clamped into the image, the value is unused)
             sCorX = f_add(sCorX, dL0);
             sCorY = f_add(sCorY, dL1);
+        }
+        if (flat) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) tb[lane * LR_P + u] = (uint32_t)off[u];
+            __builtin_amdgcn_wave_barrier();
+            const int a0 = (lane >> 4) * LR_P + (lane & 15);
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = dxdy[tb[a0 + 4 * k * LR_P]];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tb[a0 + 4 * k * LR_P] = v[k];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = tb[lane * LR_P + u];
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = dxdy[off[u]];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -197,8 +225,10 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
             }
         }
     }
-    const float cg = g.gaussCoefG[hID];
-    rowSums[((size_t)img * g.outCap + li) * 63 + hID] = make_float4(f_mul(cg, pgdL), f_mul(cg, ngdL), f_mul(cg, pgdO), f_mul(cg, ngdO));
+    if (rowAct) {
+        const float cg = g.gaussCoefG[hID];
+        rowSums[((size_t)img * g.outCap + li) * 63 + hID] = make_float4(f_mul(cg, pgdL), f_mul(cg, ngdL), f_mul(cg, pgdO), f_mul(cg, ngdO));
+    }
 }
 
 // one thread per line: 63 rows -> 9 bands (:1201-1240), means/stds (:1256-1280), normalise / clip / renormalise
@@ -304,6 +334,9 @@ __global__ __launch_bounds__(64) void k_lbd_desc(const LineGeom* __restrict__ gp
 
 // LBD gradient images: GaussianBlur(5x5, sigma 1) then Sobel (computeGaussianPyramid / computeSobel) -- they depend on the input images only, so the
 // fused entry runs them on the ORB stream in the shadow of the seed ordering (api.cpp, schedule 5)
+// OLF_LBD_T=0: every line through the direct loads (A/B)
+static int lbd_rows_transpose() { static const int v = !(getenv("OLF_LBD_T") && atoi(getenv("OLF_LBD_T")) == 0); return v; }
+
 int launch_lbd_dense(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
     OLF_TRY_RC(launch_gauss7_img(d_in, in_pitch, (size_t)in_pitch * g.H, b.lbdBlur, g.pitchW, (size_t)g.pitchW * g.H, g.W, g.H, g, 1, n_images, s));
@@ -323,8 +356,8 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
                        d_counts, reinterpret_cast<unsigned long long*>(b.keysA), (size_t)g.Ps / 2);
     if (!denseDone) OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
     hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
-    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums));
+    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());
@@ -337,8 +370,8 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
 {
     OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
     hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
-    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap * 63 + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums));
+    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());
