@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 // LSD_REFINE_ADV's rect_nfa read nothing of it, but olf_lsd_debug_scaled does) and never read back.  Saves k_lsd_grad's pass (its loads, unpacking and
 // index arithmetic: 0.49 M instructions per image) and a kernel boundary.  Only for the std::sort seed order, which does not need k_lsd_grad's per-chunk
 // counts of defined pixels.
-constexpr int UG_ROWS = 8;
+#ifndef OLF_UG_ROWS
+#define OLF_UG_ROWS 8
+#endif
+constexpr int UG_ROWS = OLF_UG_ROWS;
 __global__ __launch_bounds__(64) void k_lsd_upgrad(const uint8_t* __restrict__ src, uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
                                                    const LineGeom* __restrict__ gp, const ResizeCoef* __restrict__ rx, const ResizeCoef* __restrict__ ry,
                                                    int* __restrict__ maxN, int nsx)

@@ -59,11 +59,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
         if (tot > out_cap) { atomicOr(status, 4); tot = out_cap; }
         counts[img] = tot;
     }
-    // per-lane constants of the wave's key points
-    float4 pt[4];
-    uint32_t dw0[4], dw1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { pt[j] = s_patf[j * 64 + lane]; dw0[j] = s_w0[j * 64 + lane]; dw1[j] = s_w1[j * 64 + lane]; }
+    // (the per-lane constants -- 16 pattern floats, 8 disc weight words -- are read from LDS where they are used: held in registers across the key point they
+    // cost 24 VGPRs, i.e. two of the eight waves a SIMD can hold, and the kernel lives on its occupancy)
     const int r6 = lane / PDW, c10 = lane - r6 * PDW;      // staging: lanes 0 .. 59 take six rows of ten dwords per step
     uint32_t* patch = s_patch[wv];
 #pragma unroll 1
@@ -109,8 +106,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
             if (pass * 64 + lane < (2 * kHalfPatch + 1) * 8) {
                 uint32_t I;
                 __builtin_memcpy(&I, im + (icBase + (uint32_t)(pass * 8 * pitch)), 4);
-                const int rs = (int)__builtin_amdgcn_udot4(I, dw0[pass], 0u, false);
-                m10 = (int)__builtin_amdgcn_udot4(I, dw1[pass], (uint32_t)m10, false);
+                const int rs = (int)__builtin_amdgcn_udot4(I, s_w0[pass * 64 + lane], 0u, false);
+                m10 = (int)__builtin_amdgcn_udot4(I, s_w1[pass * 64 + lane], (uint32_t)m10, false);
                 sI += rs;
                 m01 += (pass * 8 + (lane >> 3) - kHalfPatch) * rs;
             }
@@ -133,10 +130,11 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
         unsigned long long bits[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt[j].x, b), __fmul_rn(pt[j].y, a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt[j].x, a), __fmul_rn(pt[j].y, b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt[j].z, b), __fmul_rn(pt[j].w, a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt[j].z, a), __fmul_rn(pt[j].w, b)));
+            const float4 pt = s_patf[j * 64 + lane];
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
             const int t0 = pb[r0 * (PDW * 4) + c0], t1 = pb[r1 * (PDW * 4) + c1];
             bits[j] = wave_vote(t0 < t1);
         }
