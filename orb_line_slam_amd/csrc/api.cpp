@@ -276,7 +276,17 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     rc = c->line.build(p->line, width, height, max_images);
     if (rc != OLF_OK) { set_error("olf_ctx_create: LSD parameters not supported"); return fail(rc); }
     const LineGeom& lg = c->line.geom;
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // The line stream gets a priority of its own.  The runtime multiplexes streams onto a few hardware queues, and two streams of the SAME priority can land on
+    // one queue: the line path and the caller's stream then run back to back (measured: the host-to-host pipeline at 330 ms per 3072-pair batch instead of 220
+    // whenever the caller's compute stream and this one aliased, profiles/r4aq_stream_queue_aliasing.txt).  Streams of different priorities never share a queue.
+    // OLF_S2_PRIO: 1 low (default: it leaves the high level to a caller's copy streams -- pipeline.py), -1 high, 0 the caller's level (the hazard, for A/B);
+    // the step time is the same for all three (226-231 ms on one box).
+    int s2prio = 1;
+    if (const char* e = getenv("OLF_S2_PRIO")) s2prio = atoi(e);
+    int prLeast = 0, prGreatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+    const int prio = s2prio < 0 ? prGreatest : s2prio > 0 ? prLeast : 0;
+    if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_sort, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_lbd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }

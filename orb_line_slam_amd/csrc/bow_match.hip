@@ -79,6 +79,11 @@ __global__ __launch_bounds__(256) void k_bow_sort_nodes(const int* __restrict__ 
     if (threadIdx.x == 0) mOut[f] = s_m;
 }
 
+#ifndef OLF_BM_WAVES
+#define OLF_BM_WAVES 16
+#endif
+constexpr int BM_WAVES = OLF_BM_WAVES;
+
 __device__ __forceinline__ int bm_lower_bound(const unsigned long long* a, int n, unsigned long long key)      // first position with a[p] >= key
 {
     int lo = 0, hi = n;
@@ -86,7 +91,9 @@ __device__ __forceinline__ int bm_lower_bound(const unsigned long long* a, int n
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_search_by_bow(const unsigned long long* __restrict__ sortedAll, const int* __restrict__ mAll, const olf_keypoint* __restrict__ kps,
+// (BM_WAVES waves per frame pair: the pair's ~100 shared nodes are claimed one at a time by whichever wave is free; the walk inside a node is serial, so the
+// kernel's time is the longest chain of nodes one wave ends up with -- 4 waves 3.6 ms per 3071 pairs, 16 waves see profiles/r4al_bow_waves_ab.txt)
+__global__ __launch_bounds__(64 * BM_WAVES) void k_search_by_bow(const unsigned long long* __restrict__ sortedAll, const int* __restrict__ mAll, const olf_keypoint* __restrict__ kps,
                                                        const uint4* __restrict__ desc, const int* __restrict__ counts, int cap, int img_stride,
                                                        const uint8_t* __restrict__ mpValid, const uint8_t* __restrict__ mpBad, float nnratio, int checkOri,
                                                        int* __restrict__ matches, int* __restrict__ nmatches)
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const unsigned long long*
     const olf_keypoint* kF = kps + (size_t)fF * img_stride * cap;
     const uint4* dK = desc + 2 * (size_t)fK * img_stride * cap;
     const uint4* dF = desc + 2 * (size_t)fF * img_stride * cap;
-    for (int i = threadIdx.x; i < cap; i += 256) { matched[i] = -1; binOf[i] = 0; }
+    for (int i = threadIdx.x; i < cap; i += 64 * BM_WAVES) { matched[i] = -1; binOf[i] = 0; }
     if (threadIdx.x < BM_HISTO) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_seg = 0; s_n = 0; }
     __syncthreads();
@@ -187,12 +194,12 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const unsigned long long*
         }
         __syncthreads();
         int dropped = 0;
-        for (int i = threadIdx.x; i < nF; i += 256)
+        for (int i = threadIdx.x; i < nF; i += 64 * BM_WAVES)
             if (matched[i] >= 0) { const int b = binOf[i]; if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) { matched[i] = -1; ++dropped; } }
         if (dropped) atomicSub(&s_n, dropped);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < cap; i += 256) matches[(size_t)p * cap + i] = i < nF ? matched[i] : -1;
+    for (int i = threadIdx.x; i < cap; i += 64 * BM_WAVES) matches[(size_t)p * cap + i] = i < nF ? matched[i] : -1;
     if (threadIdx.x == 0) nmatches[p] = s_n;
 }
 
@@ -208,7 +215,7 @@ int launch_search_by_bow_batch(const uint8_t* slotDesc, const int* childOff, con
     hipLaunchKernelGGL(k_bow_descend_nodes, dim3((cap + 255) / 256, n_frames), dim3(256), 0, s, reinterpret_cast<const uint4*>(slotDesc), childOff, slotNode,
                        nodeWeight, reinterpret_cast<const uint4*>(d_desc), d_counts, cap, img_stride, nid_level, d_nodes);
     hipLaunchKernelGGL(k_bow_sort_nodes, dim3(n_frames), dim3(256), (size_t)P * 8, s, d_nodes, cap, P, d_sorted, d_m);
-    hipLaunchKernelGGL(k_search_by_bow, dim3(n_frames - 1), dim3(256), (size_t)cap * 4 + ((cap + 3) & ~3), s, d_sorted, d_m, d_kps,
+    hipLaunchKernelGGL(k_search_by_bow, dim3(n_frames - 1), dim3(64 * BM_WAVES), (size_t)cap * 4 + ((cap + 3) & ~3), s, d_sorted, d_m, d_kps,
                        reinterpret_cast<const uint4*>(d_desc), d_counts, cap, img_stride, d_mp_valid, d_mp_bad, nnratio, check_ori, d_matches, d_nmatches);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;

@@ -16,12 +16,54 @@ from ._lib import DESC_BYTES, KEYLINE_DTYPE, KEYPOINT_DTYPE, FrameBuffers, check
 from .frame import StereoFrames
 
 
+def _gpu_local_cpus(torch, dev):
+    """CPUs of the NUMA node the GPU hangs off (sysfs), or None.  Pinned staging memory is placed by first touch: allocated from a CPU of another node, every
+    DMA of the pipeline crosses the socket interconnect -- measured on MI355X boxes as 330 ms per 3072-pair batch instead of 220 (profiles/r4am_pcie_numa.txt)."""
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        txt = open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        return cpus or None
+    except Exception:
+        return None
+
+
+class _LocalAffinity:
+    """with _LocalAffinity(torch, dev): the calling thread runs on the GPU's NUMA node (first-touch placement of what is allocated inside)"""
+    def __init__(self, torch, dev):
+        self.cpus = _gpu_local_cpus(torch, dev); self.old = None
+    def __enter__(self):
+        import os
+        try:
+            if self.cpus:
+                self.old = os.sched_getaffinity(0)
+                use = self.cpus & self.old
+                if use: os.sched_setaffinity(0, use)
+        except Exception:
+            self.old = None
+        return self
+    def __exit__(self, *a):
+        import os
+        try:
+            if self.old: os.sched_setaffinity(0, self.old)
+        except Exception:
+            pass
+
+
 class OfflinePipeline:
     def __init__(self, params=None, width=1242, height=375, pairs_per_batch=256, device=None):
         import torch
         self.torch = torch
         self.params = params or _lib.default_params()
         self.width, self.height, self.B = width, height, pairs_per_batch
+        import os
+        self.input_event = os.environ.get("OLF_PIPE_EVENT", "0") != "0"      # olf_ctx_set_input_event with each batch's upload event (A/B switch)
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         with torch.cuda.device(self.dev):
             self.ctx = _lib.Context(self.params, width, height, 2 * pairs_per_batch)
@@ -34,14 +76,19 @@ class OfflinePipeline:
             self.names = [s[0] for s in spec]
             self.slots = []
             for _ in range(2):
-                slot = {"host_in": torch.empty((2 * B, height, width), dtype=torch.uint8).pin_memory(),
+              with _LocalAffinity(torch, self.dev):      # (the staging buffers on the GPU's NUMA node)
+                slot = {"host_in": torch.zeros((2 * B, height, width), dtype=torch.uint8).pin_memory(),
                         "dev_in": torch.empty((2 * B, height, width), dtype=torch.uint8, device=self.dev),
                         "dev": {n: torch.zeros(sh, dtype=dt, device=self.dev) for n, sh, dt in spec},
                         "host": {n: torch.zeros(sh, dtype=dt).pin_memory() for n, sh, dt in spec},
                         "in_done": torch.cuda.Event(), "cmp_done": torch.cuda.Event(), "out_done": torch.cuda.Event(), "n": 0, "used": False}
                 slot["fb"] = FrameBuffers(*[slot["dev"][n].data_ptr() for n in self.names])
                 self.slots.append(slot)
-            self.s_in, self.s_cmp, self.s_out = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+            # three priority levels for three kinds of stream: the runtime multiplexes streams onto a few hardware queues and two streams of one priority can
+            # share a queue -- the copies then queue behind the batch's kernels (277 ms per batch instead of 222), or the context's line stream behind the ORB
+            # stream (330).  Copy streams high, the compute stream normal, the context's line stream low (api.cpp): streams of different levels never share.
+            self.s_in, self.s_out = torch.cuda.Stream(self.dev, priority=-1), torch.cuda.Stream(self.dev, priority=-1)
+            self.s_cmp = torch.cuda.Stream(self.dev)
 
     def input_buffer(self, i):
         """The pinned staging array batch i will be uploaded from ((2*pairs_per_batch, H, W) uint8).  A producer that writes its images
@@ -90,6 +137,8 @@ class OfflinePipeline:
                     self.s_cmp.wait_event(slot["in_done"])
                     if i >= 2:
                         self.s_cmp.wait_event(slot["out_done"])         # the results of batch i-2 have left the device buffers
+                    if self.input_event:
+                        self.ctx.set_input_event(slot["in_done"])         # the line stream waits for the upload only, not for the previous batch's tail
                     check(lib().olf_stereo_frames_dev(self.ctx.handle, C.c_void_p(slot["dev_in"].data_ptr()), n, C.byref(slot["fb"]),
                                                       C.c_void_p(self.s_cmp.cuda_stream)), "olf_stereo_frames_dev")
                     slot["cmp_done"].record(self.s_cmp)
