@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_bow_sort_nodes(const int* __restrict__ 
 }
 
 #ifndef OLF_BM_WAVES
-#define OLF_BM_WAVES 16
+#define OLF_BM_WAVES 8
 #endif
 constexpr int BM_WAVES = OLF_BM_WAVES;
 
@@ -92,7 +92,7 @@ __device__ __forceinline__ int bm_lower_bound(const unsigned long long* a, int n
 }
 
 // (BM_WAVES waves per frame pair: the pair's ~100 shared nodes are claimed one at a time by whichever wave is free; the walk inside a node is serial, so the
-// kernel's time is the longest chain of nodes one wave ends up with -- 4 waves 3.6 ms per 3071 pairs, 16 waves see profiles/r4al_bow_waves_ab.txt)
+// kernel's time is the longest chain of nodes one wave ends up with: 4 waves 3.60 ms per 3071 pairs, 8 waves 3.07, 16 waves 4.72 -- profiles/r4at_bow_waves_ab.txt)
 __global__ __launch_bounds__(64 * BM_WAVES) void k_search_by_bow(const unsigned long long* __restrict__ sortedAll, const int* __restrict__ mAll, const olf_keypoint* __restrict__ kps,
                                                        const uint4* __restrict__ desc, const int* __restrict__ counts, int cap, int img_stride,
                                                        const uint8_t* __restrict__ mpValid, const uint8_t* __restrict__ mpBad, float nnratio, int checkOri,
