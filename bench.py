@@ -384,7 +384,7 @@ def main():
         nbytes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
         ev = [torch.cuda.Event() for _ in range(2)]
         recv = [torch.empty(pk_bytes, dtype=torch.uint8, device=dev) if (rank == 0 and r != 0) else None for r in range(world)]
-        comm_stream = torch.cuda.Stream(device=dev) if args.gather == "overlap" else torch.cuda.current_stream()
+        comm_stream = torch.cuda.Stream(device=dev, priority=-1) if args.gather == "overlap" else torch.cuda.current_stream()      # (its own priority level: streams of one level can share a hardware queue, profiles/r4aq_stream_queue_aliasing.txt)
 
         def pack(k):
             s = torch.cuda.current_stream().cuda_stream
