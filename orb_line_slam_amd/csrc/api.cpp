@@ -418,8 +418,6 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
     c->last_n_images = n_images;
     // (the blur only needs the pyramid: with orb_wait_after >= 2 it runs ahead of FAST, beside the dense half of the LSD front)
     const int wa = c->orb_wait_after;
-    // wa == 5 (OLF_SCHED=6): the pyramid too waits for the dense half of the LSD front and runs in the seed sort's shadow (experiment: profiles/r4aw_sched6_ab.txt)
-    if (wa == 5) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_sort, 0));
     { StageScope t(c, s, ST_ORB_PYRAMID); OLF_TRY(launch_orb_pyramid(g, c->ob, d_images, n_images, s)); }
     if (wa == 1) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     // wa == 4 (OLF_SCHED=5): the blur in the shadow of the seed sort -- it waits for the dense half of the LSD front only (ev_sort), FAST for all of it
@@ -429,7 +427,7 @@ int olf_orb_extract_dev(olf_ctx* c, const uint8_t* d_images, int n_images, olf_k
         OLF_TRY(launch_lbd_dense(c->line.geom, c->lb, d_images, c->W, n_images, s));
         OLF_HIP_CHECK(hipEventRecord(c->ev_lbd, s));
     }
-    if (wa == 2 || wa == 4 || wa == 5) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
+    if (wa == 2 || wa == 4) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_FAST); OLF_TRY(launch_orb_fast(g, c->ob, n_images, s)); }
     if (wa == 3) OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_front, 0));
     { StageScope t(c, s, ST_ORB_OCTREE); OLF_TRY(launch_orb_octree(g, c->ob, n_images, s)); }
@@ -1049,7 +1047,7 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     // schedule 5 also moves the LBD gradient images (GaussianBlur + Sobel of the input, 6 ms of dense work) from the tail of the line stream into the
     // seed ordering's shadow on the ORB stream (OLF_LBD_PRE=0: off); the line stream's selection + LBD then wait for ev_lbd, so they are enqueued
     // behind the ORB extraction here (an event has to be recorded before the wait for it is enqueued)
-    static const bool lbd_pre = (sched == 5 || sched == 6) && !(getenv("OLF_LBD_PRE") && atoi(getenv("OLF_LBD_PRE")) == 0);
+    static const bool lbd_pre = sched == 5 && !(getenv("OLF_LBD_PRE") && atoi(getenv("OLF_LBD_PRE")) == 0);
     // Fork.  With the caller's input event (olf_ctx_set_input_event) the line stream does not wait for what is still queued on `s` -- the ORB / stereo /
     // matching tail of the previous batch -- and the LSD front of this batch runs beside it.  Safe with lbd_pre only: the LSD front, growth and rectangles
     // write line-path scratch that nothing on `s` reads, and selection / LBD / line stereo (which write the output buffers the previous batch's matchers
