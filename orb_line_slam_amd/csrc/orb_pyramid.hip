@@ -72,31 +72,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t* __restrict__ pyr, int p
 // FAST-9/16 score map (App. A.4).  score(p) = max over the sixteen 9-arcs of min|I(p)-I(ring)| - 1,
 // which is what cv::FAST's cornerScore returns for any threshold at which p is a corner; p is a
 // corner at threshold t  <=>  score >= t.  We store score where score >= minThFAST, else 0.
-__device__ __forceinline__ int arc9_maxmin(const int* d)
-{
-    int m2[16], m4[16], m8[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m2[i] = min(d[i], d[(i + 1) & 15]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 2) & 15]);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) m8[i] = min(m4[i], m4[(i + 4) & 15]);
-    int best = -1000;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) best = max(best, min(m8[i], d[(i + 8) & 15]));
-    return best;
-}
-
-__device__ __forceinline__ bool run9(uint32_t m)   // >= 9 contiguous set bits in a circular 16-bit mask
-{
-    uint32_t x = m | (m << 16);
-    uint32_t r = x & (x >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= x >> 8;
-    return (r & 0xffffu) != 0;
-}
-
 constexpr int FT_W = 128;                            // processed tile: 128 x FT_H pixels, FT_H = NT / 8 (32 rows for 256 threads); LDS holds bytes x0-4 .. x0+131 of rows y0-3 .. y0+FT_H+2
 constexpr int FT_EW = 124;                           // emitted part: columns 2 .. 125, rows 1 .. FT_H - 2 (the rest is the NMS halo of the neighbours)
 constexpr int FT_INW = (FT_W + 8) / 4;
@@ -195,54 +170,69 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     __syncthreads();
     const uint8_t* tb = reinterpret_cast<const uint8_t*>(tile);
     constexpr int P = FT_INW * 4;
-    // ---- phase A2: the full segment test of the survivors, one per lane (dense): 16 ring bytes from the LDS tile, brighter / darker
-    // masks, >= 9 contiguous.  Corners are queued for scoring.
+    // ---- phase A2 + B (round 4): the corner score of every survivor, one per lane (dense), in packed 16-bit arithmetic.  score = max over the sixteen 9-arcs of
+    // the arc's minimum of d (ring darker) or of -d (ring brighter), minus 1 -- cv::FAST's cornerScore -- and the survivor IS a corner at minThFAST iff that score
+    // reaches it, so the brighter / darker masks and the contiguity test of rounds 1-3 (190 instructions per survivor, then 182 more per corner for the score)
+    // are one computation: register i holds (d[i], d[i + 8]) as two int16, a rotation of the ring by one position is "next register" (the last one wraps into
+    // the first with its halves swapped), and min over 2, 4, 8 and 9 consecutive positions is four rounds of v_pk_min_i16.
     // (in place: a round's 256 entries are all read before any corner is appended, and the append position never passes the round's end)
+    typedef short s2v __attribute__((ext_vector_type(2)));
     const int nCand = s_nc;
     for (int i0 = 0; i0 < nCand; i0 += NT) {
         const int i = i0 + threadIdx.x;
-        bool corner = false;
-        int id = 0;
+        int sc = 0, id = 0;
         if (i < nCand) {
             id = s_cand[i];
             const int ty = id / FT_W, tx = id - ty * FT_W;
             const uint8_t* c = tb + (ty + 3) * P + tx + 4;
-            const int v = c[0], hiT = v + minTh, loT = v - minTh;
+            const int v = c[0];
             int ring[16];
             ring[0] = c[3 * P];   ring[1] = c[3 * P + 1];   ring[2] = c[2 * P + 2];   ring[3] = c[P + 3];
             ring[4] = c[3];       ring[5] = c[-P + 3];      ring[6] = c[-2 * P + 2];  ring[7] = c[-3 * P + 1];
             ring[8] = c[-3 * P];  ring[9] = c[-3 * P - 1];  ring[10] = c[-2 * P - 2]; ring[11] = c[-P - 3];
             ring[12] = c[-3];     ring[13] = c[P - 3];      ring[14] = c[2 * P - 2];  ring[15] = c[3 * P - 1];
-            uint32_t dark = 0, bright = 0;
+            const s2v vv = {(short)v, (short)v};
+            s2v R[8], a[8], b[8];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                dark |= (uint32_t)(ring[k] < loT) << k;
-                bright |= (uint32_t)(ring[k] > hiT) << k;
+            for (int k = 0; k < 8; ++k) {
+                const s2v rr = {(short)ring[k], (short)ring[k + 8]};
+                R[k] = vv - rr;
             }
-            corner = run9(dark) || run9(bright);
+            auto sw = [](s2v x) -> s2v { return __builtin_shufflevector(x, x, 1, 0); };
+            // darker ring: max over the arcs of the arc's minimum of d.  a = min over 2 consecutive positions, b = over 4, a = over 8; nine = position k with the
+            // eight that follow it (one half-swap per round: only the last register wraps into the first)
+            s2v bestD = {(short)-1000, (short)-1000};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_elementwise_min(R[k], k < 7 ? R[k + 1] : sw(R[0]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = __builtin_elementwise_min(a[k], k < 6 ? a[k + 2] : sw(a[k - 6]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_elementwise_min(b[k], k < 4 ? b[k + 4] : sw(b[k - 4]));
+            const s2v a0s = sw(a[0]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bestD = __builtin_elementwise_max(bestD, __builtin_elementwise_min(R[k], k < 7 ? a[k + 1] : a0s));
+            // brighter ring: max over the arcs of min(-d) = -(min over the arcs of max(d)): the same chain with the two operations exchanged
+            s2v bestB = {(short)1000, (short)1000};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_elementwise_max(R[k], k < 7 ? R[k + 1] : sw(R[0]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[k] = __builtin_elementwise_max(a[k], k < 6 ? a[k + 2] : sw(a[k - 6]));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = __builtin_elementwise_max(b[k], k < 4 ? b[k + 4] : sw(b[k - 4]));
+            const s2v a0b = sw(a[0]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bestB = __builtin_elementwise_min(bestB, __builtin_elementwise_max(R[k], k < 7 ? a[k + 1] : a0b));
+            const s2v best = __builtin_elementwise_max(bestD, -bestB);
+            sc = max((int)best.x, (int)best.y) - 1;
         }
         __syncthreads();
-        if (corner) s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
+        if (sc >= minTh) {
+            s_score[id] = (uint8_t)sc;
+            s_list[atomicAdd(&s_n, 1)] = (unsigned short)id;
+        }
     }
     __syncthreads();
-    // ---- phase B: scores of the queued corners into the LDS score tile, one corner per thread (dense lanes)
     const int nC = s_n;
-    for (int i = threadIdx.x; i < nC; i += NT) {
-        const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
-        const uint8_t* c = tb + (ty + 3) * P + tx + 4;
-        const int v = c[0];
-        int d[16], ndv[16];
-        d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-        d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-        d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-        d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) ndv[k] = -d[k];
-        int sc = max(arc9_maxmin(d), arc9_maxmin(ndv)) - 1;
-        if (sc < minTh) sc = 0;
-        s_score[id] = (uint8_t)sc;
-    }
-    __syncthreads();
     // ---- phase C: strict 3x3 non-maximum suppression inside the cell interior, survivors appended to their cell
     for (int i = threadIdx.x; i < nC; i += NT) {
         const int id = s_list[i], ty = id / FT_W, tx = id - ty * FT_W;
