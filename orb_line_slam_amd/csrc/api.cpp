@@ -1059,8 +1059,9 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     }
     c->mark_front = sched != 0;
     c->defer_lbd = lbd_pre;
+    c->lb.skipScaled = !(getenv("OLF_KEEP_SCALED") && atoi(getenv("OLF_KEEP_SCALED")) != 0);      // (nothing behind the fused kernel reads the working image)
     const int rcl = olf_line_extract_dev(c, d_images, n_images, o->kls, o->ldesc, o->lcounts, c->stream2);
-    c->mark_front = false; c->defer_lbd = false;
+    c->mark_front = false; c->defer_lbd = false; c->lb.skipScaled = false;
     OLF_TRY(rcl);
     if (!lbd_pre) {
         OLF_TRY(olf_stereo_lines_dev(c, n_pairs, o->kls, o->ldesc, o->lcounts, o->lmatches12, o->ldisp, o->lle, c->stream2));

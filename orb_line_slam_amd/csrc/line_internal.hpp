@@ -82,6 +82,7 @@ struct LineDeviceBufs {
     uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
     int* links = nullptr;          // [n][nChunks] next chunk of a region's pixel list (-1: last)
     int nChunks = 0;               // 32-pixel chunks per image in `region` (ids < 1024: the ROB slots' own chunks, then the pool)
+    bool skipScaled = false;         // fused stereo entry: the enlarged working image is consumed inside k_lsd_upgrad and not written (olf_lsd_debug_scaled needs the stand-alone entry)
     hipEvent_t sortEvent = nullptr;  // when set, launch_lsd_front records it in front of the seed ordering (the dense, bandwidth-bound part of the front is through)
     int* growFmt = nullptr;        // [n] after the multi-wave growth: 0 chunk chains, -1 given up (pool exhausted), 1 grown again by the one-wave agent (contiguous log)
     int poolChunks = 0;            // olf_debug_lsd_pool: > 0 caps the chunk pool the multi-wave kernel may use (tests of the fall-back)

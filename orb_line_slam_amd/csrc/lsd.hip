@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(const uint8_t* __restrict__ sc
 constexpr int UG_ROWS = OLF_UG_ROWS;
 __global__ __launch_bounds__(64) void k_lsd_upgrad(const uint8_t* __restrict__ src, uint8_t* __restrict__ scaled, uint32_t* __restrict__ grad,
                                                    const LineGeom* __restrict__ gp, const ResizeCoef* __restrict__ rx, const ResizeCoef* __restrict__ ry,
-                                                   int* __restrict__ maxN, int nsx)
+                                                   int* __restrict__ maxN, int nsx, int writeScaled)
 {
     const LineGeom& g = *gp;
     const int q = blockIdx.x * 64 + threadIdx.x;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_lsd_upgrad(const uint8_t* __restrict__ s
             int cur[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) cur[k] = (int)(((((b0 * h0[k]) >> 16) + ((b1 * h1[k]) >> 16) + 2u) >> 2) & 0xffu);
-            if (rr < UG_ROWS && dy < dh) {
+            if (writeScaled && rr < UG_ROWS && dy < dh) {
                 const uint32_t out = (uint32_t)cur[0] | ((uint32_t)cur[1] << 8) | ((uint32_t)cur[2] << 16) | ((uint32_t)cur[3] << 24);
                 __builtin_memcpy(d + (size_t)dy * g.pitchS, &out, 4);      // (columns beyond Ws inside the last quad are scratch bytes of the padded pitch)
             }
@@ -1539,7 +1539,7 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     if (fused) {
         const int nsx = (g.Ws + 3) / 4;
         hipLaunchKernelGGL(k_lsd_upgrad, dim3((nsx + 63) / 64, (g.Hs + UG_ROWS - 1) / UG_ROWS, n_images), dim3(64), 0, s, b.lsdBlur, b.scaled, b.grad, b.geom, b.rx, b.ry,
-                           b.maxN, nsx);
+                           b.maxN, nsx, b.skipScaled ? 0 : 1);
     } else if (g.resizeTiled) {
         int rc = launch_resize_tiled(b.lsdBlur, (size_t)g.pitchW * g.H, g.pitchW, g.W, g.H, b.scaled, (size_t)g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, b.rx,
                                      b.ry, n_images, s, (g.resizeTiled & 2) != 0);
