@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--scene", choices=("default", "long", "bars"), default="default", help="long: fewer, larger shapes; bars: long thin bars -> key lines of about 0.08*W pixels (SURVEY App. D model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bow", action="store_true", help="frame-to-frame ORB matching by the dense kNN stand-in of rounds 1-2 instead of SearchByBoW")
+    ap.add_argument("--no-deferred-join", action="store_true", help="join the two streams at the end of olf_stereo_frames_dev (the default of the C ABI) instead of behind the "
+                                                                    "point features' matcher (olf_ctx_set_deferred_join, include/orbline.h)")
     ap.add_argument("--pipeline", action="store_true", help="hand the context an input-ready event (olf_ctx_set_input_event, include/orbline.h): the line path of step k + 1 then starts "
                                                             "beside the tail of step k instead of behind it (measured: no gain, profiles/r4q_pipelined_steps_ab.txt)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the pass that runs every stage alone (counter collections that must see exactly the timed steps)")
@@ -332,6 +334,8 @@ def main():
     in_ev = torch.cuda.Event(); in_ev.record(); torch.cuda.synchronize()
     if args.pipeline:
         ctx.set_input_event(in_ev)
+    if not args.no_deferred_join:
+        check(lib().olf_ctx_set_deferred_join(ctx.handle, 1), "olf_ctx_set_deferred_join")
 
     def z(shape, dt):
         return torch.zeros(shape, dtype=dt, device=dev)
@@ -357,6 +361,17 @@ def main():
     def step(images):
         s = torch.cuda.current_stream().cuda_stream
         check(Lh.olf_stereo_frames_dev(ctx.handle, images.data_ptr(), B, C.byref(fb), s), "olf_stereo_frames_dev")
+        if B > 1 and voc is not None and not args.no_deferred_join:
+            # the tracker's order (src/Tracking.cc:963-970, then :1296-1308): the point features' matcher first -- it needs nothing of the line path, whose tail
+            # is still running on the context's line stream (olf_ctx_set_deferred_join) -- then the join, then the line matcher
+            check(Lh.olf_stereo_points_mask_dev(ctx.handle, dp.data_ptr(), B * cap, kf_valid.data_ptr(), s), "olf_stereo_points_mask_dev")
+            check(Lh.olf_search_by_bow_batch_dev(ctx.handle, voc._h, B, 2, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), kf_valid.data_ptr(), None,
+                                                 0.7, 1, 4, f2f_orb.data_ptr(), f2f_n.data_ptr(), s), "olf_search_by_bow_batch_dev")
+            check(Lh.olf_stereo_frames_join_dev(ctx.handle, s), "olf_stereo_frames_join_dev")
+            check(Lh.olf_match_bf_dev(ctx.handle, ldesc.data_ptr() + 2 * lcap * 32, lcounts.data_ptr() + 8, 2 * lcap, 2, ldesc.data_ptr(),
+                                      lcounts.data_ptr(), 2 * lcap, 2, B - 1, nnr_l, 1, f2f_lines.data_ptr(), s), "olf_match_bf_dev(lines)")
+            return
+        check(Lh.olf_stereo_frames_join_dev(ctx.handle, s), "olf_stereo_frames_join_dev")
         if B > 1:
             # frame i (left image 2i) against frame i-1: match(last.mDescriptors_Line, cur.mDescriptors_Line) (src/Tracking.cc:1308)
             check(Lh.olf_match_bf_dev(ctx.handle, ldesc.data_ptr() + 2 * lcap * 32, lcounts.data_ptr() + 8, 2 * lcap, 2, ldesc.data_ptr(),

@@ -54,6 +54,13 @@ int  olf_ctx_synchronize(olf_ctx* ctx);
  * everything of batch k + 1 that touches the output buffers or the shared LBD planes is ordered behind batch k's work on `stream` (api.cpp,
  * olf_stereo_frames_dev).  The caller still orders `stream` itself behind the production of d_images. */
 int  olf_ctx_set_input_event(olf_ctx* ctx, void* hip_event);
+/* Deferred join for olf_stereo_frames_dev.  By default the call ends with `stream` waiting for the line stream: every output is complete on `stream`.  The
+ * reference's tracker consumes the point features first (TrackReferenceKeyFrame: ComputeBoW + SearchByBoW, src/Tracking.cc:963-970) and the line features after
+ * them (:1296-1308); with the deferred join on, the call returns with the ORB-side outputs (key points, descriptors, counts, mvuRight, mvDepth) complete on
+ * `stream` and the line-side outputs (key lines, LBD descriptors, line matches) still being produced on the context's line stream --
+ * olf_stereo_frames_join_dev(ctx, stream) makes `stream` wait for them (the next olf_stereo_frames_dev call does it itself if the caller did not). */
+int  olf_ctx_set_deferred_join(olf_ctx* ctx, int on);
+int  olf_stereo_frames_join_dev(olf_ctx* ctx, void* stream);
 int  olf_ctx_poll_status(olf_ctx* ctx);
 
 /* Stage timing with HIP events recorded on the stream each stage is launched on (the reference's only

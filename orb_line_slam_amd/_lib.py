@@ -155,6 +155,8 @@ def lib():
         L.olf_frames_pack_bound.restype = C.c_size_t
         L.olf_frames_pack_dev.argtypes = [C.c_void_p, C.POINTER(FrameBuffers), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.olf_ctx_set_input_event.argtypes = [C.c_void_p, C.c_void_p]
+        L.olf_ctx_set_deferred_join.argtypes = [C.c_void_p, C.c_int]
+        L.olf_stereo_frames_join_dev.argtypes = [C.c_void_p, C.c_void_p]
         L.olf_stereo_points_mask_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.olf_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.olf_debug_fdiv_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]

@@ -53,6 +53,8 @@ struct olf_ctx {
     hipEvent_t ev_front = nullptr;
     hipEvent_t input_event = nullptr;  // olf_ctx_set_input_event: not owned; the fused entry's line stream waits for it instead of forking from the caller's stream
     hipEvent_t ev_lbd = nullptr;       // fused entry: the LBD gradient images are ready (computed on the ORB stream in the seed ordering's shadow)
+    bool deferred_join = false;        // olf_ctx_set_deferred_join: olf_stereo_frames_dev returns with the line path still running on the line stream
+    bool join_pending = false;         // ... and this call's line path has not been joined yet (olf_stereo_frames_join_dev, or the next call)
     bool defer_lbd = false;            // fused entry: olf_line_extract_dev stops behind the rectangles; selection + LBD are enqueued by the caller
     bool lbd_pre = false;              // fused entry: olf_orb_extract_dev computes the LBD gradient images behind its blur and records ev_lbd
     hipEvent_t ev_sort = nullptr;      // recorded in front of the seed ordering (the dense, bandwidth-bound half of the LSD front is through)
@@ -1027,6 +1029,7 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const int n_images = 2 * n_pairs;
+    if (c->join_pending) { OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0)); c->join_pending = false; }      // (a deferred join the caller never asked for)
     // The line path runs beside the ORB path on the second stream (the reference's 4 extraction threads, src/Frame.cc:164-171).  The ORB
     // stream builds its pyramid beside the dense half of the LSD front and then waits for the front's end: two dense pipelines at once only
     // slow each other down (OLF_SCHED=0: 290 ms per 3072-pair step), whereas FAST beside the latency-bound growth agents is hidden almost
@@ -1080,7 +1083,27 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
         OLF_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     }
     OLF_TRY(olf_stereo_points_dev(c, n_pairs, o->kps, o->desc, o->counts, o->uright, o->depth, s));
-    OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    // the join.  Deferred (olf_ctx_set_deferred_join): the caller's stream goes on with the ORB outputs -- key points, descriptors, stereo points are complete on
+    // it here -- while the line path's tail (selection, LBD, line stereo: 20 ms of a 3072-pair batch) still runs on the line stream; olf_stereo_frames_join_dev
+    // (or the next call) makes the stream wait for it
+    if (c->deferred_join) c->join_pending = true;
+    else OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    return OLF_OK;
+}
+
+int olf_ctx_set_deferred_join(olf_ctx* c, int on)
+{
+    if (!c) return OLF_ERR_INVALID;
+    c->deferred_join = on != 0;
+    return OLF_OK;
+}
+
+int olf_stereo_frames_join_dev(olf_ctx* c, void* stream)
+{
+    if (!c) return OLF_ERR_INVALID;
+    if (!c->join_pending) return OLF_OK;
+    OLF_HIP_CHECK(hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, c->ev_join, 0));
+    c->join_pending = false;
     return OLF_OK;
 }
 
@@ -1095,6 +1118,7 @@ int olf_stereo_frames(olf_ctx* c, const uint8_t* images, int n_pairs, const olf_
     d.kls = c->d_kls; d.ldesc = c->d_ldesc; d.lcounts = c->d_lcounts; d.lmatches12 = c->d_lm12; d.ldisp = c->d_ldisp; d.lle = c->d_lle;
     OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * ni, hipMemcpyHostToDevice, c->stream));
     OLF_TRY(olf_stereo_frames_dev(c, c->d_images, n_pairs, &d, c->stream));
+    OLF_TRY(olf_stereo_frames_join_dev(c, c->stream));      // (a context with the deferred join on: the copies below read the line outputs)
     hipStream_t s = c->stream;
     OLF_HIP_CHECK(hipMemcpyAsync(o->kps, d.kps, cap * ni * sizeof(olf_keypoint), hipMemcpyDeviceToHost, s));
     OLF_HIP_CHECK(hipMemcpyAsync(o->desc, d.desc, cap * ni * OLF_DESC_BYTES, hipMemcpyDeviceToHost, s));

@@ -493,3 +493,54 @@ def test_pipelined_batches_with_input_event(oracle):
     assert np.array_equal(ref[0][2], ref[2][2]) and np.array_equal(ref[0][7], ref[2][7])      # (counts; rows past a count keep the previous batch's bytes)
     assert np.array_equal(ref[1][2], ref[3][2]) and not np.array_equal(ref[0][2], ref[1][2])
     ctx.close()
+
+
+def test_deferred_join(oracle):
+    """olf_ctx_set_deferred_join: olf_stereo_frames_dev returns with the point-feature outputs complete on the caller's stream and the line path's tail still running
+    on the context's line stream; olf_stereo_frames_join_dev makes the stream wait for it.  Copies of the ORB outputs taken on the stream BEFORE the join and of the line
+    outputs taken behind it must equal what a joined call leaves; a second call without an explicit join in between joins by itself."""
+    import ctypes as C
+    import torch
+    from orb_line_slam_amd import _lib
+    from orb_line_slam_amd._lib import FrameBuffers, check as chk, lib
+    w, h, n = 1242, 375, 96
+    p = oracle.full_params(2000, 500, 718.856, 386.1448)
+    dev = torch.device("cuda", 0)
+    inputs = [torch.from_numpy(np.tile(synth.stereo_batch(7500 + 10 * k, 8, w, h), (n // 8, 1, 1))).to(dev) for k in range(2)]
+    ctx = _lib.Context(p, w, h, 2 * n)
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    spec = [((2 * n, cap, 28), torch.uint8), ((2 * n, cap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, cap), torch.float32), ((n, cap), torch.float32),
+            ((2 * n, lcap, 68), torch.uint8), ((2 * n, lcap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, lcap), torch.int32), ((n, lcap, 2), torch.float32),
+            ((n, lcap, 3), torch.float64)]
+    out = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in spec]
+    fb = FrameBuffers(*[t.data_ptr() for t in out])
+    st = torch.cuda.Stream(dev)
+
+    def run(deferred):
+        got = []
+        torch.cuda.synchronize()
+        chk(lib().olf_ctx_set_deferred_join(ctx.handle, 1 if deferred else 0), "olf_ctx_set_deferred_join")
+        with torch.cuda.stream(st):
+            for t in out:
+                t.zero_()
+            for k in (0, 1):
+                chk(lib().olf_stereo_frames_dev(ctx.handle, inputs[k].data_ptr(), n, C.byref(fb), st.cuda_stream), "olf_stereo_frames_dev")
+                orb = [t.clone() for t in out[:5]]                # before the join: the point features are complete on the stream
+                if k == 0:
+                    chk(lib().olf_stereo_frames_join_dev(ctx.handle, st.cuda_stream), "olf_stereo_frames_join_dev")
+                    got.append(orb + [t.clone() for t in out[5:]])
+                else:
+                    got.append(orb)                               # (no join: the next call, or the one below, does it)
+            chk(lib().olf_stereo_frames_join_dev(ctx.handle, st.cuda_stream), "olf_stereo_frames_join_dev")
+            got[1] = got[1] + [t.clone() for t in out[5:]]
+            torch.cuda.synchronize()
+        ctx.synchronize()
+        return [[t.cpu().numpy() for t in g] for g in got]
+
+    ref, dfd = run(False), run(True)
+    for i in range(2):
+        for a, b in zip(ref[i], dfd[i]):
+            assert a.tobytes() == b.tobytes(), i
+    assert ref[0][2].sum() > 1000 * n and ref[0][7].sum() > 100 * n
+    chk(lib().olf_ctx_set_deferred_join(ctx.handle, 0), "olf_ctx_set_deferred_join")
+    ctx.close()
