@@ -10,7 +10,9 @@ rows.sort()
 # the last COMPLETE step on both queues: a step ends with the batched SearchByBoW (bench.py runs it behind the fused entry), so the step is everything
 # that started after the previous step's k_search_by_bow ended -- the line stream's kernels start before the ORB stream's k_ingest, which is why the
 # ingest-anchored version of round 3 showed the ORB queue only
-bow = [i for i, r in enumerate(rows) if "k_search_by_bow" in r[2]]
+# (with the deferred join the step's last kernel is the line matcher's k_ratio_mutual, behind the point matcher's k_search_by_bow)
+last = [i for i, r in enumerate(rows) if "k_ratio_mutual" in r[2]] or [i for i, r in enumerate(rows) if "k_search_by_bow" in r[2]]
+bow = last
 if len(bow) >= 2:
     t_prev_end, t_last_end = rows[bow[-2]][1], rows[bow[-1]][1]
     sel = [r for r in rows if r[0] >= t_prev_end and r[0] <= t_last_end]
