@@ -67,15 +67,18 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
     for (int q = 0; q < DESC_KPW; ++q) {
         const int slot = (blockIdx.x * 4 + wv) * DESC_KPW + q;
         if (slot >= kpTotal) break;
-        int level = 0;
-        while (level + 1 < nlevels && slot >= g.lv[level + 1].kpBase) ++level;
-        const LevelGeom& L = g.lv[level];
-        const int i = slot - L.kpBase;
-        if (i >= lc[level]) continue;
-        int outIdx = i;
-        for (int l = 0; l < level; ++l) outIdx += lc[l];
-        if (outIdx >= out_cap) continue;
+        // which level the slot belongs to, its rank there and its place in the output: lane l holds level l's first slot and count (ONE round trip of two vector
+        // loads beside the key point word -- as loops over scalar loads, "while (slot >= lv[level + 1].kpBase)" and "outIdx += lc[l]", these were up to fourteen
+        // dependent memory round trips in front of everything else a wave does)
         const uint32_t p = lvlKp[(size_t)img * kpTotal + slot];
+        const bool lv_lane = lane < nlevels;
+        const int base_l = lv_lane ? g.lv[lane].kpBase : 0x7fffffff, cnt_l = lv_lane ? lc[lane] : 0;
+        const int level = (int)__popcll(wave_vote(lv_lane && lane > 0 && slot >= base_l));
+        const int i = slot - __builtin_amdgcn_readlane(base_l, level);
+        if (i >= __builtin_amdgcn_readlane(cnt_l, level)) continue;
+        const int outIdx = i + wave_sum_i32(lane < level ? cnt_l : 0);
+        if (outIdx >= out_cap) continue;
+        const LevelGeom& L = g.lv[level];
         const int cx = (int)(p >> 20) + kMinBorder, cy = (int)((p >> 8) & 0xfff) + kMinBorder, score = (int)(p & 0xff);
         const int pitch = L.pitch;
 
