@@ -148,20 +148,23 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
     const size_t oL = (size_t)(2 * pair) * cap, oR = (size_t)(2 * pair + 1) * cap;
     float outU = -1.0f, outD = -1.0f;
     int outS = -1;
+    // (what the tests below branch on is requested up front, in two rounds instead of five: the left key point and its best candidate; then the candidate's
+    // column and the level's geometry -- for a key point without a candidate from a clamped index, unused)
     const olf_keypoint kL = kps[oL + iL];
+    const unsigned best = bestKey[(size_t)pair * cap + iL];
     const int levelL = kL.octave;
     const float vL = kL.y, uL = kL.x;
+    asm volatile("" :: "v"(levelL), "v"(vL), "v"(uL), "v"(best));
+    const float uR0 = kps[oR + min((int)(best & 0xffffu), max(nR - 1, 0))].x;
+    const LevelGeom L = g.lv[min(max(levelL, 0), g.nlevels - 1)];
+    asm volatile("" :: "v"(uR0), "v"(L.inv_scale), "v"(L.scale), "v"(L.w), "v"(L.pitch), "v"(L.offset));
     const float mb = f_div(mbf, fx);
     const float maxD = f_div(mbf, mb);
     const float minU = f_sub(uL, maxD), maxU = uL;
     const int row = (int)vL;
-    const unsigned best = bestKey[(size_t)pair * cap + iL];
     const int bestDist = (int)(best >> 16);
     const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
     if (bestDist < thOrbDist && (best & 0xffffu) != 0xffffu && bestDist < TH_HIGH) {
-        const int bestIdxR = (int)(best & 0xffffu);
-        const float uR0 = kps[oR + bestIdxR].x;
-        const LevelGeom& L = g.lv[levelL];
         const float scaleFactor = L.inv_scale;
         const float scaleduL = roundf(f_mul(kL.x, scaleFactor));
         const float scaledvL = roundf(f_mul(kL.y, scaleFactor));
@@ -172,22 +175,29 @@ __global__ __launch_bounds__(256) void k_stereo_match(const OrbGeom* __restrict_
             const uint8_t* IL = pyr + (size_t)(2 * pair) * g.pyrBytes + L.offset;
             const uint8_t* IR = pyr + (size_t)(2 * pair + 1) * g.pyrBytes + L.offset;
             const int cxL = (int)scaleduL, cy = (int)scaledvL, cxR0 = (int)scaleduR0;
-            const int cL = IL[(size_t)cy * L.pitch + cxL];
             // the 11 shifted 11x11 windows of the right image overlap in a 21x11 strip: it is staged once in LDS (4 byte loads per lane
-            // instead of 33) and every shift reads its window and its centre pixel from there
+            // instead of 33) and every shift reads its window and its centre pixel from there.  All seven loads of a lane -- strip, patch, centre -- are
+            // requested before any is used: as a loop that stored each strip byte to LDS before loading the next they were six dependent round trips
             uint8_t* strip = s_strip[threadIdx.x >> 6];
-            for (int idx = lane; idx < 11 * 21; idx += 64) {
-                const int ry = idx / 21, rx = idx - ry * 21;
-                strip[idx] = IR[(size_t)(cy + ry - w) * L.pitch + cxR0 + rx - (w + Ls)];
+            int sv[4], araw[2], py[2], px[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k, ry = idx / 21, rx = idx - ry * 21;
+                sv[k] = idx < 11 * 21 ? (int)IR[(size_t)(cy + ry - w) * L.pitch + cxR0 + rx - (w + Ls)] : 0;
             }
             // each lane owns up to two of the 121 patch pixels
-            int a[2], py[2], px[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int idx = lane + 64 * k;
                 py[k] = idx / 11 - w; px[k] = idx % 11 - w;
-                a[k] = idx < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] - cL : 0;
+                araw[k] = idx < 121 ? (int)IL[(size_t)(cy + py[k]) * L.pitch + cxL + px[k]] : 0;
             }
+            const int cL = IL[(size_t)cy * L.pitch + cxL];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int idx = lane + 64 * k; if (idx < 11 * 21) strip[idx] = (uint8_t)sv[k]; }
+            int a[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a[k] = lane + 64 * k < 121 ? araw[k] - cL : 0;
             __builtin_amdgcn_wave_barrier();
             // the 11 sums of absolute differences: per lane two shifts' partial sums share a dword (a sum is below 121 * 255 < 2^15), six wave sums through
             // DPP instead of eleven butterflies through the LDS crossbar (66 dependent ds_bpermute per key point were most of the kernel's latency)
