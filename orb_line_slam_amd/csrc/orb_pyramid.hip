@@ -103,11 +103,19 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
     const int x0 = kMinBorder - 4 + blockIdx.x * FT_EW, y0 = kMinBorder + 2 + blockIdx.y * FT_EH;
     const int xBeg = kMinBorder + 3, yBeg = kMinBorder + 3, xEnd = L.maxBorderX - 3, yEnd = L.maxBorderY - 3;
     const uint8_t* src = pyr + (size_t)img * pyrBytes + L.offset;
-    for (int i = threadIdx.x; i < FT_INH * FT_INW; i += NT) {
-        const int r = i / FT_INW, j = i - r * FT_INW;
-        const int gy = min(y0 - 3 + r, L.h - 1);
-        const int xw = min(x0 - 4 + 4 * j, L.pitch - 4);          // rows are 64-byte aligned and padded to the pitch
-        tile[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw);
+    {   // (all of a thread's tile words are requested before the first is stored: as a loop of load -> LDS store the block started with six dependent round trips)
+        constexpr int NLD = (FT_INH * FT_INW + NT - 1) / NT;
+        uint32_t tv[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = threadIdx.x + k * NT;
+            const int r = i / FT_INW, j = i - r * FT_INW;
+            const int gy = min(y0 - 3 + r, L.h - 1);
+            const int xw = min(x0 - 4 + 4 * j, L.pitch - 4);          // rows are 64-byte aligned and padded to the pitch
+            tv[k] = i < FT_INH * FT_INW ? *reinterpret_cast<const uint32_t*>(src + (size_t)gy * L.pitch + xw) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int i = threadIdx.x + k * NT; if (i < FT_INH * FT_INW) tile[i] = tv[k]; }
     }
     reinterpret_cast<uint4*>(s_score)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);      // (FT_H * FT_W bytes = NT x 16)
     if (threadIdx.x == 0) { s_nc = 0; s_n = 0; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4ak; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 900 python -m pytest $R/tests/test_match_gpu.py $R/tests/test_line_gpu.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -1
+timeout 900 python -m pytest $R/tests/test_orb_gpu.py $R/tests/test_line_gpu.py -q -x -m gpu -p no:cacheprovider 2>&1 | tail -1
 stage() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d.get('stages_ms_per_step',{})
