@@ -7,6 +7,11 @@ olf_stereo_frames_dev (ExtractORB x2, ExtractLine x2, ComputeStereoMatches, Comp
 frame of the batch: ORBmatcher::SearchByBoW (src/ORBmatcher.cc:161-290) batched on the device, ComputeBoW included (BASELINE.json config 3;
 --no-bow: a dense kNN stand-in).  Workloads (--config): C2 640x480 1000+200, C3 KITTI 1242x375 2000+500 (default: the configuration
 the metric is quoted on), C4 EuRoC 752x480 1200+500, C5 1920x1080 4000+1000.
+The step issues the two matchers in the tracker's order (src/Tracking.cc:963-970 before :1296-1308): the fused call with the deferred join
+(olf_ctx_set_deferred_join: the point-side outputs are complete on the stream, the line path's tail still runs on the context's line stream),
+SearchByBoW on the point features, the join, the line matcher -- every kernel of a step is complete when its timed region ends
+(--no-deferred-join: the joined call of the C ABI's default).  The harness runs on a stream of its own (the default stream's handle is NULL,
+which the C ABI reads as "the context's stream").
 
 Multi-GPU: frames are independent -> every rank processes its own B pairs (weak scaling, no data-path collective).
 The design's one communication step runs INSIDE the timed region: after every step each rank packs the trimmed feature record of its
