@@ -18,6 +18,7 @@ The design's one communication step runs INSIDE the timed region: after every st
 batch (csrc/records.hip) and sends it to rank 0 (orb_line_slam_amd/distributed.py: one-word all_gather of the sizes + point-to-point
 sends, on a side stream, overlapped with the next step's kernels).  --verify: rank 0 re-runs every other rank's input (same seeds) and
 byte-compares the records it received with its own.
+--force-dist: the same N > 1 code path with ONE rank, so that the RCCL backend itself (bring-up, collectives on device tensors, barrier) runs on a 1-GPU box.
 
 The JSON line also carries: the roofline of the dominant stage (the one with the largest stand-alone time; algorithmic bytes / HIP-event
 duration of its launch inside the timed region; `traffic` = 2 x FETCH_SIZE + WRITE_SIZE and `valu_issue` = its vector instructions against the
@@ -208,6 +209,8 @@ def main():
     ap.add_argument("--gather", choices=("overlap", "sync", "off"), default="overlap", help="N>1: gather of the feature records to rank 0 (inside the timed region)")
     ap.add_argument("--seed-order", type=int, choices=(0, 1), default=None, help="convention C.9: order of the LSD seeds inside a gradient bin (default: the library's)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="N>1: nccl = RCCL over xGMI (device buffers); gloo = the same gather staged through host memory (lets 2 ranks share one GPU: the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group bring-up, batch-size agreement, pack, size exchange, gather, per-rank timing) "
+                    "even with one rank: on a 1-GPU box this is the only way the RCCL backend itself executes (no peer, so no point-to-point transfer)")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
     ap.add_argument("--images", default=None, help="recorded stereo sequence instead of synthetic input: a KITTI sequence directory (times.txt, image_0, image_1 -- "
                     "Examples/PL/PL_stereo_kitti.cc LoadImages), a EuRoC mav0 directory or any directory with left / right image folders (orb_line_slam_amd/sequence.py); "
@@ -224,16 +227,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
     dev_index = local_rank % torch.cuda.device_count()        # more ranks than GPUs only with --backend gloo (ranks then share a device)
-    if world > 1 and args.backend == "nccl" and local_rank >= torch.cuda.device_count():
+    if multi and args.backend == "nccl" and local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node (RCCL needs one device per rank; --backend gloo lets ranks share one)")
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # Bring-up under a deadline: a rendezvous that never completes (a rank that died, a wrong MASTER_PORT) or an RCCL that cannot build its rings
@@ -290,12 +297,12 @@ def main():
     # the batch lives in HBM (context buffers + outputs, about 62 MB per KITTI pair): shrink it if this GPU has less free memory than the
     # batch needs, and use the same size on every rank
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    per_pair = 62e6 * (W * H) / (1242 * 375) * (1.15 if world > 1 else 1.0)     # + packed records (double buffered) when they are gathered
+    per_pair = 62e6 * (W * H) / (1242 * 375) * (1.15 if multi else 1.0)     # + packed records (double buffered) when they are gathered
     fit = int((free_b - 6e9) / per_pair) // 64 * 64
     if fit < B:
         print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 64)}", file=sys.stderr, flush=True)
         B = max(fit, 64)
-    if world > 1:
+    if multi:
         tb = torch.tensor([B], dtype=torch.int64, device=cdev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)
         B = int(tb.item())
@@ -393,7 +400,7 @@ def main():
                                           counts.data_ptr(), 2 * cap, 2, B - 1, 0.7, 1, f2f_orb.data_ptr(), s), "olf_match_bf_dev(orb)")
 
     # ---- the gather of the feature records to rank 0 (N > 1) ---------------------------------------------------------------------
-    gather_on = world > 1 and args.gather != "off"
+    gather_on = multi and args.gather != "off"
     gstat = {"bytes": 0, "seconds": 0.0, "last": None}
     if gather_on:
         from orb_line_slam_amd.distributed import gather_records

@@ -55,3 +55,21 @@ def test_distributed_bring_up_fails_fast_with_a_message():
     out = subprocess.run(cmd + ["--backend", "gloo"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
     assert out.returncode != 0 and (b"timed out" in out.stderr or b"bring-up failed" in out.stderr), out.stderr.decode()[-1500:]
     assert b"rendezvous" in out.stderr and time.time() - t < 200
+
+
+def test_rccl_backend_single_rank():
+    """The RCCL backend itself on a 1-GPU box: bench.py --force-dist runs the N > 1 code path with one rank -- init_process_group("nccl", device_id=...),
+    the probe all_reduce, the one-device-per-rank check (all_gather_object), the batch-size agreement, pack, the size exchange (all_gather of device
+    tensors), the barrier and the per-rank / MAX timing reductions all execute in librccl; only the point-to-point transfer has no peer to go to."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "nccl", "--pairs", "64", "--distinct", "64", "--steps", "3", "--warmup", "1",
+           "--verify", "--no-cpu-baseline", "--no-extras", "--no-isolated"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["gather"]["verify"] == {"ranks": 1, "identical": True} and d["gather"]["bytes_per_step"] == 0
+    assert len(d["per_rank_ms_per_step"]["ranks"]) == 1
