@@ -73,3 +73,15 @@ def test_rccl_backend_single_rank():
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["gather"]["verify"] == {"ranks": 1, "identical": True} and d["gather"]["bytes_per_step"] == 0
     assert len(d["per_rank_ms_per_step"]["ranks"]) == 1
+
+
+def test_rccl_point_to_point_on_device_buffers_self_loop():
+    """gather_records' transfer primitive -- batch_isend_irecv of device uint8 tensors on a side stream -- through RCCL with the only peer a 1-GPU box has:
+    the rank itself (tools/rccl_self_p2p_probe.py).  Group semantics, stream ordering and the work handles run as on a node; the xGMI link does not."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_self_p2p_probe.py"), str(8 << 20)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    d = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["identical"] is True and d["bytes"] == 8 << 20 and len(d["seconds"]) == 4
