@@ -85,3 +85,4 @@ def test_rccl_point_to_point_on_device_buffers_self_loop():
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     d = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["identical"] is True and d["bytes"] == 8 << 20 and len(d["seconds"]) == 4
+
