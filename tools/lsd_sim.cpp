@@ -295,8 +295,7 @@ int main(int argc, char** argv)
     const int Karg = argc > 5 ? atoi(argv[5]) : 7;
     const int nwArg = argc > 6 ? atoi(argv[6]) : 0;
     for (int K : {Karg}) {
-        for (int nw : {1, 4, 16, 64}) {
-            if (nwArg && nw != nwArg) continue;
+        for (int nw : (nwArg ? std::vector<int>{nwArg} : std::vector<int>{1, 4, 16, 64})) {
             for (int cap : {capArg}) {
                 Sim S(F, nw, K, cap, true);
                 S.run();
