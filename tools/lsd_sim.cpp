@@ -128,6 +128,7 @@ enum St { GROWING, DONE, PARKED };
 struct Entry {
     St st; std::vector<int> px; size_t i = 0; double reg_angle = 0; float sdx = 0, sdy = 0; int blocker = -1; bool invalid = false; int worker = -1;
     int runs = 0;
+    int delay = 0;      // per-run overhead still to be served (dispatch / pick / prologue / finish of the kernel, in iterations)
 };
 
 struct Sim {
@@ -142,6 +143,7 @@ struct Sim {
     std::vector<Region> committed;
     int robCap;
     bool alignedOnly;
+    int OV = 0;                     // iterations of overhead charged to every (re-)run of a region
     Sim(const Field& f, int nw, int k, int cap, bool ao) : F(f), NW(nw), K(k), owner((size_t)f.W * f.H, -1), wrank(nw, -1), robCap(cap), alignedOnly(ao) {}
 
     bool is_final(int o) const { return o >= 0 && o < watermark; }
@@ -151,7 +153,7 @@ struct Sim {
     void start(int rank, Entry& e, int w)
     {
         const int a0 = F.order[rank];
-        e.st = GROWING; e.px.clear(); e.px.push_back(a0); e.i = 0; e.invalid = false; e.worker = w; ++e.runs;
+        e.st = GROWING; e.px.clear(); e.px.push_back(a0); e.i = 0; e.invalid = false; e.worker = w; ++e.runs; e.delay = OV;
         e.reg_angle = F.ang[a0]; e.sdx = float(std::cos(e.reg_angle)); e.sdy = float(std::sin(e.reg_angle));
         owner[a0] = rank;
         wrank[w] = rank;
@@ -168,6 +170,7 @@ struct Sim {
     {
         const int W = F.W, H = F.H;
         ++work;
+        if (e.delay > 0) { --e.delay; return; }
         const size_t end = std::min(e.px.size(), e.i + (size_t)K);
         for (; e.i < end; ++e.i) {
             const int rx = e.px[e.i] % W, ry = e.px[e.i] / W;
@@ -294,10 +297,12 @@ int main(int argc, char** argv)
     const int capArg = argc > 4 ? atoi(argv[4]) : 256;
     const int Karg = argc > 5 ? atoi(argv[5]) : 7;
     const int nwArg = argc > 6 ? atoi(argv[6]) : 0;
+    const int ovArg = argc > 7 ? atoi(argv[7]) : 0;
     for (int K : {Karg}) {
         for (int nw : (nwArg ? std::vector<int>{nwArg} : std::vector<int>{1, 4, 16, 64})) {
             for (int cap : {capArg}) {
                 Sim S(F, nw, K, cap, true);
+                S.OV = ovArg;
                 S.run();
                 bool ok = true;
                 size_t ci = 0;
