@@ -13,6 +13,8 @@
 #include <map>
 #include <set>
 #include <queue>
+#include <deque>
+#include <algorithm>
 #include <cassert>
 
 extern "C" int olf_synth_stereo(uint64_t seed, int W, int H, uint8_t* left, uint8_t* right);
@@ -144,7 +146,9 @@ struct Sim {
     int robCap;
     bool alignedOnly;
     int OV = 0;                     // iterations of overhead charged to every (re-)run of a region
-    Sim(const Field& f, int nw, int k, int cap, bool ao) : F(f), NW(nw), K(k), owner((size_t)f.W * f.H, -1), wrank(nw, -1), robCap(cap), alignedOnly(ao) {}
+    int OVp = 0, B = 1;             // ... and to every pick; a pick claims up to B runnable seeds, which the worker then grows one after the other
+    std::vector<std::deque<int>> wq;    // worker -> claimed ranks (front = the one being grown)
+    Sim(const Field& f, int nw, int k, int cap, bool ao) : F(f), NW(nw), K(k), owner((size_t)f.W * f.H, -1), wrank(nw, -1), robCap(cap), alignedOnly(ao), wq(nw) {}
 
     bool is_final(int o) const { return o >= 0 && o < watermark; }
 
@@ -153,16 +157,22 @@ struct Sim {
     void start(int rank, Entry& e, int w)
     {
         const int a0 = F.order[rank];
-        e.st = GROWING; e.px.clear(); e.px.push_back(a0); e.i = 0; e.invalid = false; e.worker = w; ++e.runs; e.delay = OV;
+        e.st = GROWING; e.px.clear(); e.px.push_back(a0); e.i = 0; e.invalid = false; e.worker = w; ++e.runs; e.delay = OV + (wq[w].empty() ? OVp : 0);
         e.reg_angle = F.ang[a0]; e.sdx = float(std::cos(e.reg_angle)); e.sdy = float(std::sin(e.reg_angle));
         owner[a0] = rank;
-        wrank[w] = rank;
+        wq[w].push_back(rank); wrank[w] = wq[w].front();
+    }
+    void drop(int w, int rank)
+    {
+        auto& q = wq[w];
+        q.erase(std::remove(q.begin(), q.end(), rank), q.end());
+        wrank[w] = q.empty() ? -1 : q.front();
     }
     void park(int rank, Entry& e, int blocker)
     {
         release(e, rank); wasted += e.px.size(); e.px.clear();
         e.st = PARKED; e.blocker = blocker; e.invalid = false;
-        if (e.worker >= 0) { wrank[e.worker] = -1; e.worker = -1; }
+        if (e.worker >= 0) { drop(e.worker, rank); e.worker = -1; }
         ++parks;
     }
     // one agent iteration of the region of `rank`; returns false when the region is complete
@@ -198,7 +208,7 @@ struct Sim {
                     e.reg_angle = fastAtan2(e.sdy, e.sdx) * DEG_TO_RADS;
                 }
         }
-        if (e.i >= e.px.size()) { e.st = DONE; wrank[e.worker] = -1; e.worker = -1; }
+        if (e.i >= e.px.size()) { e.st = DONE; drop(e.worker, rank); e.worker = -1; }
     }
 
     void advance_watermark()
@@ -224,6 +234,7 @@ struct Sim {
             // hand work to idle workers: first re-runnable parked seeds (lowest rank first), then new seeds
             for (int w = 0; w < NW; ++w) {
                 if (wrank[w] >= 0) continue;
+                for (int b = 0; b < B; ++b) {
                 bool got = false;
                 for (auto& kv : rob) {
                     Entry& e = kv.second;
@@ -242,7 +253,7 @@ struct Sim {
                     if (F.iso[a0]) { e.st = DONE; e.px.assign(1, a0); owner[a0] = rank; continue; }
                     start(rank, e, w); got = true; break;
                 }
-                if (got) continue;
+                if (got) continue;      // (next seed of this worker's batch)
                 while (next < nk && (int)rob.size() < robCap) {
                     const int rank = next++;
                     const int a0 = F.order[rank];
@@ -254,6 +265,8 @@ struct Sim {
                     Entry& e = rob[rank];
                     if (F.iso[a0]) { e.st = DONE; e.px.assign(1, a0); owner[a0] = rank; continue; }
                     start(rank, e, w); got = true; break;
+                }
+                if (!got) break;
                 }
             }
             bool any = false;
@@ -298,11 +311,12 @@ int main(int argc, char** argv)
     const int Karg = argc > 5 ? atoi(argv[5]) : 7;
     const int nwArg = argc > 6 ? atoi(argv[6]) : 0;
     const int ovArg = argc > 7 ? atoi(argv[7]) : 0;
+    const int ovpArg = argc > 8 ? atoi(argv[8]) : 0, bArg = argc > 9 ? atoi(argv[9]) : 1;
     for (int K : {Karg}) {
         for (int nw : (nwArg ? std::vector<int>{nwArg} : std::vector<int>{1, 4, 16, 64})) {
             for (int cap : {capArg}) {
                 Sim S(F, nw, K, cap, true);
-                S.OV = ovArg;
+                S.OV = ovArg; S.OVp = ovpArg; S.B = bArg;
                 S.run();
                 bool ok = true;
                 size_t ci = 0;
