@@ -290,6 +290,160 @@ struct Sim {
     }
 };
 
+// ---- the same policy on G workgroups --------------------------------------------------------------------------------------------------------
+// Seeds are dealt to the groups by rank-interleaved windows of WS seeds; every group has its OWN reorder buffer (robCap entries, what fits a workgroup's LDS),
+// its own workers and a local watermark (rank of its oldest unresolved seed).  The global watermark is the minimum of the local ones, and a group sees the
+// other groups' watermarks D ticks late (they travel through memory).  A group's head entry commits when it is older than everything the group can see
+// unresolved elsewhere.  Pixel claims (owner words) and steal notices are immediate (L2 atomics).  Same check as above: committed regions == sequential ones.
+struct Sim2 {
+    const Field& F;
+    int NW, K, G, WS, D, robCap, OV;
+    std::vector<int> owner;
+    std::vector<std::map<int, Entry>> rob;      // per group
+    std::vector<int> gnext;                     // per group: next rank of its windows to dispatch
+    std::vector<std::deque<int>> hist;          // per group: published local watermarks, newest at the back
+    std::vector<int> wrank;
+    long long ticks = 0, work = 0, wasted = 0, aborts = 0, steals = 0, parks = 0, idle = 0;
+    std::vector<Region> committed;
+    int nk;
+    Sim2(const Field& f, int nw, int k, int g, int ws, int d, int cap, int ov)
+        : F(f), NW(nw), K(k), G(g), WS(ws), D(d), robCap(cap), OV(ov), owner((size_t)f.W * f.H, -1), rob(g), gnext(g), hist(g), wrank(nw, -1), nk((int)f.order.size())
+    {
+        for (int q = 0; q < G; ++q) gnext[q] = std::min(q * WS, nk);
+    }
+    int grp(int rank) const { return (rank / WS) % G; }
+    int wgrp(int w) const { return w % G; }
+    int advance(int r) const { ++r; if (r % WS == 0) r += (G - 1) * WS; return std::min(r, nk); }
+    int local_wm(int g) const { return rob[g].empty() ? gnext[g] : rob[g].begin()->first; }
+    int seen_wm(int g, int h) const                 // group h's watermark as group g sees it
+    {
+        if (h == g || D == 0 || hist[h].empty()) return local_wm(h);
+        const int n = (int)hist[h].size();
+        return hist[h][std::max(0, n - 1 - D)];
+    }
+    int global_seen(int g) const { int m = nk; for (int h = 0; h < G; ++h) m = std::min(m, seen_wm(g, h)); return m; }
+    int others_seen(int g) const { int m = nk; for (int h = 0; h < G; ++h) if (h != g) m = std::min(m, seen_wm(g, h)); return m; }
+    Entry* find(int rank) { auto& r = rob[grp(rank)]; auto it = r.find(rank); return it == r.end() ? nullptr : &it->second; }
+
+    void release(Entry& e, int rank) { for (int p : e.px) if (owner[p] == rank) owner[p] = -1; }
+    void start(int rank, Entry& e, int w)
+    {
+        const int a0 = F.order[rank];
+        e.st = GROWING; e.px.clear(); e.px.push_back(a0); e.i = 0; e.invalid = false; e.worker = w; ++e.runs; e.delay = OV;
+        e.reg_angle = F.ang[a0]; e.sdx = float(std::cos(e.reg_angle)); e.sdy = float(std::sin(e.reg_angle));
+        owner[a0] = rank; wrank[w] = rank;
+    }
+    void park(int rank, Entry& e, int blocker)
+    {
+        release(e, rank); wasted += e.px.size(); e.px.clear();
+        e.st = PARKED; e.blocker = blocker; e.invalid = false;
+        if (e.worker >= 0) { wrank[e.worker] = -1; e.worker = -1; }
+        ++parks;
+    }
+    void take_from(int victim, int thief)
+    {
+        ++steals;
+        Entry* v = find(victim);
+        assert(v);
+        if (v->st == GROWING) v->invalid = true; else if (v->st == DONE) park(victim, *v, thief);
+    }
+    void step(int rank, Entry& e)
+    {
+        const int W = F.W, H = F.H, g = grp(rank);
+        ++work;
+        if (e.delay > 0) { --e.delay; return; }
+        const int wm = global_seen(g);
+        const size_t end = std::min(e.px.size(), e.i + (size_t)K);
+        for (; e.i < end; ++e.i) {
+            const int rx = e.px[e.i] % W, ry = e.px[e.i] / W;
+            for (int yy = std::max(ry - 1, 0); yy <= std::min(ry + 1, H - 1); ++yy)
+                for (int xx = std::max(rx - 1, 0); xx <= std::min(rx + 1, W - 1); ++xx) {
+                    const int c = yy * W + xx;
+                    if (F.ang[c] == NOTDEF) continue;
+                    const int o = owner[c];
+                    if (o == rank) continue;
+                    if (o >= 0 && o < rank) {
+                        if (o < wm) continue;                                        // used by a region this group knows to be final
+                        if (aligned(F, c, e.reg_angle)) { ++aborts; park(rank, e, o); return; }
+                        continue;
+                    }
+                    if (!aligned(F, c, e.reg_angle)) continue;
+                    if (o > rank) take_from(o, rank);
+                    owner[c] = rank; e.px.push_back(c);
+                    e.sdx += std::cos((double)float(F.ang[c])); e.sdy += std::sin((double)float(F.ang[c]));
+                    e.reg_angle = fastAtan2(e.sdy, e.sdx) * DEG_TO_RADS;
+                }
+        }
+        if (e.i >= e.px.size()) { e.st = DONE; wrank[e.worker] = -1; e.worker = -1; }
+    }
+    void commit(int g)
+    {
+        const int lim = others_seen(g);
+        while (!rob[g].empty()) {
+            auto it = rob[g].begin();
+            if (it->first >= lim || it->second.st != DONE) return;
+            Region R; R.rank = it->first; R.px = std::move(it->second.px); R.iters = 0;
+            committed.push_back(std::move(R));
+            rob[g].erase(it);
+        }
+    }
+    // a runnable seed for worker w of group g: parked entries of the group whose blocker is resolved (or that are the globally oldest), then new seeds
+    bool hand(int w)
+    {
+        const int g = wgrp(w);
+        const int wm = global_seen(g);
+        for (auto& kv : rob[g]) {
+            Entry& e = kv.second;
+            if (e.st != PARKED) continue;
+            const int rank = kv.first, a0 = F.order[rank], o = owner[a0];
+            if (o >= 0 && o < rank) {
+                if (o < wm) { e.st = DONE; e.px.clear(); e.px.push_back(-1); }       // consumed by a final region: dead
+                continue;
+            }
+            if (!(e.blocker < wm || rank == wm)) continue;
+            if (o > rank) take_from(o, rank);
+            if (F.iso[a0]) { e.st = DONE; e.px.assign(1, a0); owner[a0] = rank; continue; }
+            start(rank, e, w);
+            return true;
+        }
+        while (gnext[g] < nk && (int)rob[g].size() < robCap) {
+            const int rank = gnext[g]; gnext[g] = advance(rank);
+            const int a0 = F.order[rank], o = owner[a0];
+            if (o >= 0 && o < rank) {
+                if (o < wm) continue;                                                // dead seed
+                Entry& e = rob[g][rank]; e.st = PARKED; e.blocker = o; ++parks; continue;
+            }
+            Entry& e = rob[g][rank];
+            if (o > rank) take_from(o, rank);                                        // a younger region of another group's later window was quicker
+            if (F.iso[a0]) { e.st = DONE; e.px.assign(1, a0); owner[a0] = rank; continue; }
+            start(rank, e, w);
+            return true;
+        }
+        return false;
+    }
+    void run()
+    {
+        for (;;) {
+            for (int g = 0; g < G; ++g) commit(g);
+            for (int g = 0; g < G; ++g) { hist[g].push_back(local_wm(g)); if ((int)hist[g].size() > D + 2) hist[g].pop_front(); }
+            for (int w = 0; w < NW; ++w) if (wrank[w] < 0) hand(w);
+            bool any = false;
+            for (int w = 0; w < NW; ++w) {
+                const int rank = wrank[w];
+                if (rank < 0) { ++idle; continue; }
+                any = true;
+                Entry& e = *find(rank);
+                if (e.invalid) { park(rank, e, e.blocker); continue; }
+                step(rank, e);
+            }
+            bool left = false;
+            for (int g = 0; g < G; ++g) if (gnext[g] < nk || !rob[g].empty()) left = true;
+            if (!any && !left) break;
+            if (++ticks > 4000000) { fprintf(stderr, "no progress\n"); exit(1); }
+        }
+    }
+};
+
 int main(int argc, char** argv)
 {
     const int W = argc > 1 ? atoi(argv[1]) : 1242, H = argc > 2 ? atoi(argv[2]) : 375;
@@ -312,6 +466,23 @@ int main(int argc, char** argv)
     const int nwArg = argc > 6 ? atoi(argv[6]) : 0;
     const int ovArg = argc > 7 ? atoi(argv[7]) : 0;
     const int ovpArg = argc > 8 ? atoi(argv[8]) : 0, bArg = argc > 9 ? atoi(argv[9]) : 1;
+    const int gArg = argc > 10 ? atoi(argv[10]) : 0, dArg = argc > 11 ? atoi(argv[11]) : 1, wsArg = argc > 12 ? atoi(argv[12]) : 64;
+    if (gArg > 0) {
+        // lsd_sim W H seed robCapPerGroup K NW OV - - G D WS
+        Sim2 S(F, nwArg ? nwArg : 32, Karg, gArg, wsArg, dArg, capArg, ovArg);
+        S.run();
+        std::sort(S.committed.begin(), S.committed.end(), [](const Region& a, const Region& b) { return a.rank < b.rank; });
+        bool ok = true;
+        size_t ci = 0;
+        for (auto& r : seq) {
+            while (ci < S.committed.size() && S.committed[ci].px.size() == 1 && S.committed[ci].px[0] == -1) ++ci;
+            if (ci >= S.committed.size() || S.committed[ci].rank != r.rank || S.committed[ci].px != r.px) { ok = false; break; }
+            ++ci;
+        }
+        printf("G=%d groups x %d workers, %d entries per group, windows of %d seeds, watermark delay %d, OV=%d: ticks %8lld  work %8lld  idle %8lld aborts %6lld steals %6lld parks %6lld  %s\n",
+               gArg, S.NW / gArg, capArg, wsArg, dArg, ovArg, S.ticks, S.work, S.idle, S.aborts, S.steals, S.parks, ok ? "EXACT" : "MISMATCH");
+        return 0;
+    }
     for (int K : {Karg}) {
         for (int nw : (nwArg ? std::vector<int>{nwArg} : std::vector<int>{1, 4, 16, 64})) {
             for (int cap : {capArg}) {
