@@ -340,12 +340,19 @@ struct Sim2 {
         if (e.worker >= 0) { wrank[e.worker] = -1; e.worker = -1; }
         ++parks;
     }
+    struct Notice { long long due; int victim, thief; };
+    std::vector<Notice> notices;                // steal notices on their way to another group (that group's entries live in ITS LDS: the notice goes through memory)
+    void deliver(int victim, int thief)
+    {
+        Entry* v = find(victim);
+        if (!v) { fprintf(stderr, "notice for a committed region\n"); exit(1); }      // (cannot happen: the thief is older and its group's watermark travels behind the notice)
+        if (v->st == GROWING) v->invalid = true; else if (v->st == DONE) park(victim, *v, thief);
+    }
     void take_from(int victim, int thief)
     {
         ++steals;
-        Entry* v = find(victim);
-        assert(v);
-        if (v->st == GROWING) v->invalid = true; else if (v->st == DONE) park(victim, *v, thief);
+        if (D > 0 && grp(victim) != grp(thief)) { notices.push_back({ticks + D, victim, thief}); return; }
+        deliver(victim, thief);
     }
     void step(int rank, Entry& e)
     {
@@ -424,6 +431,9 @@ struct Sim2 {
     void run()
     {
         for (;;) {
+            for (size_t q = 0; q < notices.size();) {
+                if (notices[q].due <= ticks) { deliver(notices[q].victim, notices[q].thief); notices[q] = notices.back(); notices.pop_back(); } else ++q;
+            }
             for (int g = 0; g < G; ++g) commit(g);
             for (int g = 0; g < G; ++g) { hist[g].push_back(local_wm(g)); if ((int)hist[g].size() > D + 2) hist[g].pop_front(); }
             for (int w = 0; w < NW; ++w) if (wrank[w] < 0) hand(w);
