@@ -183,6 +183,9 @@ int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* ang
 /* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
  * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
+/* debug/test: workgroups (CUs) that grow ONE image together when the kernel runs 16 waves per image (1, 2 or 4; 0 = automatic from the batch
+ * size: the one-pair-per-call shape of Frame::Frame, src/Frame.cc:164-171, takes 4).  Results do not depend on it. */
+int olf_debug_lsd_groups(olf_ctx* ctx, int groups);
 /* debug / tests: the kernel that replays libstdc++'s std::sort for the LSD seed order (convention C.9 variant 1, csrc/lsd_seedsort.hip) on a
  * caller-supplied array of n <= Ws*Hs keys, (field << 22) | payload with a 10-bit field: out receives the keys whose field is <= kthr in the
  * order std::sort(keys, keys + n, field ascending) leaves them; depth_limit < 0 = introsort's own 2 * floor(log2 n), a small value forces

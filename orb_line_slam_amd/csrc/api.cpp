@@ -302,6 +302,8 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     l.nChunks = lg.regionStride / 32;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     A(l.region, n * (size_t)lg.regionStride); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    l.mgImages = (int)std::min<size_t>(n, kMgMaxImages); l.mgStride = lsd_grow_mg_stride(lg.maxRegions);
+    A(l.mg, (size_t)l.mgImages * l.mgStride);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
     A(l.rowSums, n * lg.outCap * 63 * 4); A(l.lbdStarts, n * lg.outCap * 64 * 2); A(l.rx, c->line.rx.size()); A(l.ry, c->line.ry.size()); A(l.geom, 1);
     A(c->d_kls, n * lg.outCap); A(c->d_ldesc, n * lg.outCap * OLF_DESC_BYTES); A(c->d_lcounts, n);
@@ -552,6 +554,14 @@ int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
     }
     c->lb.forceNW = waves_per_image;
     c->lb.forceE = rob_entries;
+    return OLF_OK;
+}
+
+// debug / tests: workgroups per image of the multi-wave growth (1, 2 or 4; 0: chosen from the batch size)
+int olf_debug_lsd_groups(olf_ctx* c, int groups)
+{
+    if (!c || !(groups == 0 || groups == 1 || groups == 2 || groups == 4)) { set_error("olf_debug_lsd_groups: bad argument"); return OLF_ERR_INVALID; }
+    c->lb.forceG = groups > 0 ? groups : -1;
     return OLF_OK;
 }
 

@@ -89,6 +89,10 @@ struct LineDeviceBufs {
     int* topBuf = nullptr;         // [n][SS_TOP_WORDS] job lists / counters / final ranges of the seed sort's grid-wide top levels (lsd_seedsort.hip)
     int forceSortMode = -1;        // olf_debug_seed_sort_mode: 0 one wave per image, 1 / 2 the 4- / 8-wave kernel of lsd_seedsort.hip; -1: by batch size
     int forceNW = -1, forceE = 0;  // olf_debug_lsd_waves: waves per image (0: the one-wave agent) and ROB entries of the growth kernel; -1 / 0: automatic
+    unsigned char* mg = nullptr;   // [mgImages][mgStride] several workgroups per image (lsd_grow.hip, MG): control words, steal-notice words, the groups' staging lists of logged regions
+    size_t mgStride = 0;
+    int mgImages = 0;              // images `mg` is sized for (small batches only: the latency path)
+    int forceG = -1;               // olf_debug_lsd_groups: workgroups per image of the multi-wave growth (1, 2, 4); -1: by batch size
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
 };
 
@@ -112,6 +116,8 @@ int launch_lsd_angle_table(LineDeviceBufs& b, int libmFloat, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
+size_t lsd_grow_mg_stride(int maxRegions);   // bytes per image of LineDeviceBufs::mg
+constexpr int kMgMaxImages = 64;             // images grown by several workgroups each in one call, at most
 int lsd_seedsort_top_words();      // ints per image of LineDeviceBufs::topBuf
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
 

@@ -1576,7 +1576,19 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
     return OLF_OK;
 }
 
-int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s);
+int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, int G, hipStream_t s);
+
+// workgroups (CUs) per image of the multi-wave growth: the drop-in's online shape -- one stereo pair per call -- leaves 254 CUs idle with one workgroup per image
+// (OLF_LSD_GROUPS forces 1 / 2 / 4 for A/B runs)
+int lsd_grow_groups(int n_images, int nw)
+{
+    static const int forced = [] { const char* e = getenv("OLF_LSD_GROUPS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    if (nw < 16) return 1;
+    if (forced) return n_images * forced <= 256 && n_images <= kMgMaxImages ? forced : 1;
+    if (n_images <= 16) return 4;
+    if (n_images <= 64) return 2;
+    return 1;
+}
 
 // waves per image of the multi-wave growth: as many as keep the chip full (8 waves per SIMD x 1024 SIMDs) without leaving a small batch
 // to a handful of waves; 0 selects the one-wave agent of round 1 (kept for A/B measurements, OLF_LSD_NW=0)
@@ -1600,7 +1612,10 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
         static const int envE = [] { const char* e = getenv("OLF_LSD_ROB"); const int v = e ? atoi(e) : 0; return (v == 128 || v == 256 || v == 512) ? v : 0; }();
         const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
-        const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, s);
+        int G = b.forceG > 0 ? b.forceG : lsd_grow_groups(n_images, nw);
+        const int pool = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
+        while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > 256 || E > 512 || pool / G < E + 64)) G >>= 1;      // (every group of an image has to be resident: one workgroup per CU)
+        const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, G, s);
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
         // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once

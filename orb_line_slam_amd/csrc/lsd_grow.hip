@@ -16,6 +16,14 @@
 //   The oldest unresolved seed never waits for anything, so there is always progress; the committed regions are exactly the sequential ones.
 // Inside a region the growth step is the wave agent of round 1 (up to 7 FIFO entries x 8 neighbours per iteration, speculative accept
 // rounds that verify every decision against the exact running angle).
+// SEVERAL WORKGROUPS PER IMAGE (MG, round 5 -- the drop-in's one-pair shape, src/Frame.cc:164-171): G workgroups (one CU each) grow one image.  Seeds are dealt to
+// the groups in rank-interleaved windows of 1024 seeds; every group has its OWN reorder buffer in LDS over its own windows and a local watermark (rank of its oldest
+// unresolved seed) that it publishes in global memory.  What crosses a CU boundary is relaxed AGENT-scope traffic only -- owner words (atomicMin / compare-and-swap /
+// sc1 loads, which bypass the CU's L1), the published watermarks, and steal notices for regions of another group (one word per reorder-buffer slot in global memory) --
+// ordered by s_waitcnt vmcnt(0) on the issuing wave; no cache write-back or invalidate is ever needed because no plain store is read by another group before the
+// kernel ends.  A group's head entry commits when it is DONE, older than every other group's watermark AS READ AT THE PREVIOUS COMMIT, and its notice word read NOW
+// is clear: a region that stole from it finished -- notice performed -- before its group's watermark passed it, so a notice can never arrive behind the commit.
+// Logged regions go to a per-group staging list with their rank and are merged by rank behind the kernel (k_mg_merge).  tools/lsd_sim.cpp Sim2 is the model.
 // Region pixel lists live in 32-pixel chunks (chunk id < E: the dedicated first chunk of a ROB slot; else from a per-image pool) chained
 // through links[]; k_lsd_rect walks the chains.
 #include "lsd_device.hpp"
@@ -27,7 +35,7 @@ constexpr uint32_t MW_FREE = 0xffffffffu;
 constexpr int MW_RING = 256;          // FIFO window of a growing region kept in LDS, per wave
 constexpr int MW_DIR = 128;           // chunk directory per wave (ordinal -> chunk id) for reading the FIFO from memory
 enum { ST_EMPTY = 0, ST_READY = 1, ST_PARKED = 2, ST_GROWING = 3, ST_DONE = 4, ST_DEAD = 5 };
-enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_FREEHEAD, C_N };
+enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_FREEHEAD, C_OMIN, C_WML, C_N };
 
 #define WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -36,6 +44,34 @@ enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALL
 // XCDs' L2s", i.e. every load / atomic goes out to the fabric and every release fence writes the L2 back (measured: 16x slower in batch).
 #define AG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define AG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+// MG (several workgroups per image): what another CU reads or writes goes through agent-scope relaxed atomics (loads carry sc1 and bypass the L1)
+template <bool MG> __device__ __forceinline__ uint32_t own_load(const uint32_t* p)
+{
+    return MG ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool MG> __device__ __forceinline__ uint32_t own_min(uint32_t* p, uint32_t v)
+{
+    return MG ? __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// owner T -> FREE (only if the region still holds the pixel)
+template <bool MG> __device__ __forceinline__ void own_unclaim(uint32_t* p, uint32_t T)
+{
+    uint32_t exp = T;
+    if (MG) __hip_atomic_compare_exchange_strong(p, &exp, 0xffffffffu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_compare_exchange_strong(p, &exp, 0xffffffffu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t ag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// release towards the other waves of the workgroup; MG: towards other CUs as well -- every memory operation of this wave has been performed (the compiler's
+// workgroup fence does not wait for the vector-memory counter when the workgroup sits on one CU)
+template <bool MG> __device__ __forceinline__ void rel_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (MG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // wave-uniform read of an LDS word (every lane reads the same address)
@@ -88,7 +124,27 @@ struct MwCtx {
     // global, per image
     uint32_t* owner; const uint32_t* grad; const uint32_t* keys; uint32_t* chunks; int* links; RegionRec* recs; int* status;
     int E, mask, nkeys, nChunks, Ws, Hs, minRegSize, maxRegions, lane;
+    // several workgroups per image (MG): this group, the group count, the first chunk id of this group's share of the pool (slot chunks cb .. cb + E, pool behind),
+    // the image's control words / notice words [G][E] in global memory and this group's staging list of logged regions
+    int G, grp, cb;
+    int* gctl; uint32_t* gInvalAll; int* sRank; RegionRec* sRec;
 };
+
+// global control words of an image grown by several workgroups (ints): the groups' published watermarks on lines of their own, the abort flag, regions logged per group
+constexpr int MG_MAX_G = 4, MG_MAX_E = 512, MG_WS_BITS = 10;
+constexpr int MGC_WM = 0, MGC_ABORT = 16 * MG_MAX_G, MGC_NREG = MGC_ABORT + 16, MGC_WORDS = MGC_NREG + 16;
+constexpr int MG_INF = 0x7fffffff;
+constexpr size_t MG_INVAL_OFF = 1024, MG_RANK_OFF = MG_INVAL_OFF + (size_t)MG_MAX_G * MG_MAX_E * 4;
+static_assert(MGC_WORDS * 4 <= (int)MG_INVAL_OFF, "control words");
+__host__ __device__ inline size_t mg_rec_off(int maxRegions) { return (MG_RANK_OFF + (size_t)MG_MAX_G * maxRegions * 4 + 15) & ~(size_t)15; }
+size_t lsd_grow_mg_stride(int maxRegions) { return (mg_rec_off(maxRegions) + (size_t)MG_MAX_G * maxRegions * sizeof(RegionRec) + 255) & ~(size_t)255; }
+// group of the seed of rank r
+__device__ __forceinline__ int mg_group(uint32_t rank, int G) { return (int)((rank >> MG_WS_BITS) % (uint32_t)G); }
+
+template <bool MG> __device__ __forceinline__ void mw_abort(const MwCtx& c)
+{
+    if (c.lane == 0) { WG_STORE(c.ctl + C_ABORT, 1); if (MG) ag_store(c.gctl + MGC_ABORT, 1); }
+}
 
 // chunk from the pool: never-used ones by a bump counter; recycled ones (given back by regions that were given up) from a free list that is
 // threaded through links[] itself (head and count in LDS, under a lock), so recycling never loses a chunk however many are given back.
@@ -130,38 +186,41 @@ __device__ __forceinline__ void mw_free(const MwCtx& c, int id)
 }
 
 // un-claim the n pixels of the list of `slot` (pixel 0 is the seed; 1.. from the chunk chain) and give its pool chunks back
+template <bool MG>
 __device__ __forceinline__ void mw_release(const MwCtx& c, int slot, int n, uint32_t T)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the list may have been written by this wave a moment ago
-    if (c.lane == 0) {
-        uint32_t exp = T;
-        __hip_atomic_compare_exchange_strong(c.owner + (WG_LOAD(c.eSeed + slot) & 0x3fffffu), &exp, MW_FREE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    int cid = slot;
+    if (c.lane == 0) own_unclaim<MG>(c.owner + (WG_LOAD(c.eSeed + slot) & 0x3fffffu), T);
+    int cid = c.cb + slot;
     for (int q0 = 0; q0 < n && cid >= 0; q0 += 32) {
         const int q = q0 + c.lane;
         if (c.lane < 32 && q >= 1 && q < n) {
             const uint32_t xy = AG_LOAD(c.chunks + (size_t)cid * 32 + c.lane);
             const int a = (int)(xy >> 16) * c.Ws + (int)(xy & 0xffffu);
-            uint32_t exp = T;
-            __hip_atomic_compare_exchange_strong(c.owner + a, &exp, MW_FREE, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            own_unclaim<MG>(c.owner + a, T);
         }
         const int nx = (q0 + 32 < n) ? uni(AG_LOAD(c.links + cid)) : -1;
-        if (cid >= c.E) mw_free(c, cid);
+        if (cid >= c.cb + c.E) mw_free(c, cid);
         cid = nx;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the pixels are free before the entry changes state
+    rel_fence<MG>();      // the pixels are free before the entry changes state
 }
 
 // commit DONE / DEAD entries at the head of the ROB, in rank order, up to 64 per call; logs the regions that are large enough.
 // `ctl` is the caller's snapshot (the cheap test whether the head entry can go at all is made on it, without the lock).
-__device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
+// MG: the call also refreshes this group's view of the other groups (their watermarks, the abort flag, steal notices from their regions) and publishes the
+// group's own watermark; `force` skips the cheap test (empty buffer whose dispatcher has moved on, idle waves waiting for another group).
+template <bool MG>
+__device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool force)
 {
-    if (cv.head >= cv.tail) return;
-    {
+    if (!MG || !force) {
+        if (cv.head >= cv.tail) return;
         const int st0 = WG_LOAD(c.eState + (cv.head & c.mask));
         const uint32_t iv0 = WG_LOAD(c.eInval + (cv.head & c.mask));
-        if (!(uni(st0) == ST_DEAD || (uni(st0) == ST_DONE && (uint32_t)uni((int)iv0) == MW_FREE))) return;
+        if (MG) {
+            // a head that somebody is growing (or is about to) needs nothing from here; a parked or stolen-from head may be waiting for another group's watermark
+            if (uni(st0) == ST_GROWING || uni(st0) == ST_READY) return;
+        } else if (!(uni(st0) == ST_DEAD || (uni(st0) == ST_DONE && (uint32_t)uni((int)iv0) == MW_FREE))) return;
     }
     if (!try_lock(c.ctl + C_LOCKCOMMIT, c.lane)) return;
     const MwCtl cl = mw_ctl(c.ctl);
@@ -169,10 +228,33 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
     {
         const int i = h + c.lane, slot = i & c.mask;
         const bool in = i < cl.tail;
+        uint32_t omin = (uint32_t)MG_INF, ominNew = (uint32_t)MG_INF, giv = MW_FREE;
+        if (MG) {
+            // one round trip: the other groups' watermarks, the abort flag, the notice words of every entry in the buffer.  The decision below pairs the notice words
+            // read NOW with the watermarks read at the PREVIOUS call (C_OMIN): a thief's notice is performed before its group's watermark passes it.
+            int wmo = MG_INF, ab = 0;
+            if (c.lane < c.G && c.lane != c.grp) wmo = ag_load(c.gctl + MGC_WM + 16 * c.lane);
+            if (c.lane == 0) ab = ag_load(c.gctl + MGC_ABORT);
+            uint32_t* gi = c.gInvalAll + (size_t)c.grp * c.E;
+            if (in) giv = ag_load(gi + slot);
+            for (int k = 64; k < cl.tail - h; k += 64) {
+                const int i2 = i + k, s2 = i2 & c.mask;
+                if (i2 < cl.tail) {
+                    const uint32_t v = ag_load(gi + s2);
+                    if (v != MW_FREE) __hip_atomic_fetch_min(c.eInval + s2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (giv != MW_FREE) __hip_atomic_fetch_min(c.eInval + slot, giv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            omin = lds_u(reinterpret_cast<uint32_t*>(c.ctl) + C_OMIN);
+            for (int g2 = 0; g2 < c.G; ++g2) ominNew = min(ominNew, (uint32_t)rlane(wmo, g2));
+            if (uni(ab) && c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1);
+        }
         const int st = in ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
         const uint32_t iv = in ? WG_LOAD(c.eInval + slot) : 0u;
         const int n = in ? WG_LOAD(c.eN + slot) : 0;
-        const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE);       // DONE with a steal noted: has to be re-run first
+        const uint32_t rk = (MG && in) ? (uint32_t)WG_LOAD(c.eRank + slot) : 0u;
+        // DONE with a steal noted: has to be re-run first.  MG: a finished region is final only when every older seed of the other groups is
+        const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE && (!MG || (giv == MW_FREE && rk < omin)));
         const unsigned long long cm = wave_vote(can);
         const int run = cm == ~0ull ? 64 : __builtin_ctzll(~cm);
         const unsigned long long low = run >= 64 ? ~0ull : ((1ull << run) - 1ull);
@@ -183,13 +265,14 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
             big &= big - 1ull;
             const int sl = (h + l) & c.mask;
             const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
-            if (nc < 0) { if (c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1); break; }       // pool or region log exhausted: the image is grown again by the one-wave agent
+            if (nc < 0) { mw_abort<MG>(c); break; }       // pool or region log exhausted: the image is grown again by the one-wave agent
             // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
-            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)sl * 32 + c.lane);
+            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)(c.cb + sl) * 32 + c.lane);
             if (c.lane == 0) {
-                c.links[nc] = AG_LOAD(c.links + sl);
+                c.links[nc] = AG_LOAD(c.links + c.cb + sl);
                 RegionRec rr; rr.start = nc; rr.n = rlane(n, l); rr.angle = c.eAng[sl];
-                c.recs[nr] = rr;
+                if (MG) { c.sRec[nr] = rr; c.sRank[nr] = rlane((int)rk, l); }
+                else c.recs[nr] = rr;
             }
             ++nr;
         }
@@ -198,21 +281,36 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
         // watermark: rank of the oldest unresolved seed.  The dispatcher publishes tail before dispNext and the snapshot `cl` is older than
         // the tail read here, so an empty ROB with a stale dispNext can only give a watermark that is too low, which is safe.
         const int t2 = lds_u(c.ctl + C_TAIL);
-        const int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
+        int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
+        if (MG) {
+            if (wm >= c.nkeys) wm = MG_INF;              // this group has nothing left
+            if (wm != lds_u(c.ctl + C_WML) && c.lane == 0) { ag_store(c.gctl + MGC_WM + 16 * c.grp, wm); WG_STORE(c.ctl + C_WML, wm); }
+            if (c.lane == 0) WG_STORE(c.ctl + C_OMIN, (int)ominNew);
+            wm = min(wm, (int)ominNew);                  // what this group may treat as final: below every group's watermark
+        }
         if (c.lane == 0) { WG_STORE(c.ctl + C_NREG, nr); WG_STORE(c.ctl + C_HEAD, h); WG_STORE(c.ctl + C_WM, wm); }
     }
     unlock(c.ctl + C_LOCKCOMMIT, c.lane);
 }
 
-// tell the region whose tag is `victim` that the region of `rank` took one of its pixels
+// tell the region whose tag is `victim` that the region of `rank` took one of its pixels (MG: a region of another group is told through its notice word in
+// global memory, which that group's commit sweeps into its LDS entry)
+template <bool MG>
 __device__ __forceinline__ void mw_notify(const MwCtx& c, uint32_t victim, uint32_t rank)
 {
-    __hip_atomic_fetch_min(c.eInval + (victim & ((1u << MW_SLOT_BITS) - 1u)), rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t vs = victim & ((1u << MW_SLOT_BITS) - 1u);
+    if (MG) {
+        const int vg = mg_group(victim >> MW_SLOT_BITS, c.G);
+        if (vg != c.grp) { __hip_atomic_fetch_min(c.gInvalAll + (size_t)vg * c.E + vs, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    }
+    __hip_atomic_fetch_min(c.eInval + vs, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do.
 // The loads (keys, seed words, owners, the seeds' table entries) are done before the lock is taken, the lock only covers the insertion;
 // isolated seeds (k_lsd_iso) are claimed right here, 64 at a time, and enter the ROB as finished one-pixel regions.
+// MG: the group's seeds are the windows of 1024 ranks w with w % G == grp; a 64-seed step never straddles a window.
+template <bool MG>
 __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, const float* __restrict__ angDeg, const AngEnt* __restrict__ ent)
 {
     const int dn0 = cv.dispNext;
@@ -221,7 +319,7 @@ __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, cons
     const int rank = dn0 + c.lane;
     const bool valid = rank < c.nkeys;
     const int addr = valid ? (int)(c.keys[rank] & 0x3fffffu) : 0;
-    const uint32_t o = valid ? AG_LOAD(c.owner + addr) : 0u;
+    const uint32_t o = valid ? own_load<MG>(c.owner + addr) : 0u;
     const uint32_t w = valid ? c.grad[addr] : 0u;
     const bool iso = (w & kIso) != 0;
     float deg = 0.f;
@@ -235,35 +333,41 @@ __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, cons
     if (dn == dn0 && t - h <= c.E - 64) {
         const uint32_t wm = cl.wm;
         // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; they are never seeds)
-        const bool live = valid && !(w & kNotDef) && !(o != MW_FREE && (o >> MW_SLOT_BITS) < wm);
+        // (MG: a region of another group's LATER window may hold the seed already -- a younger owner counts as free here; the claim takes the pixel from it and tells it)
+        const bool older = o != MW_FREE && (o >> MW_SLOT_BITS) < (uint32_t)rank;
+        const bool live = valid && !(w & kNotDef) && !(older && (o >> MW_SLOT_BITS) < wm);
         const unsigned long long m = wave_vote(live);
         if (live) {
             s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
-            claim = iso && o == MW_FREE;
+            claim = iso && !older;
             c.eRank[s] = rank;
             c.eSeed[s] = (uint32_t)addr | (iso ? 0x80000000u : 0u);
             c.eInval[s] = MW_FREE;
+            if (MG) ag_store(c.gInvalAll + (size_t)c.grp * c.E + s, MW_FREE);      // (performed before the tag of this entry can be in any owner word: rel_fence below)
             c.eN[s] = 0;
             c.eDeg[s] = deg; c.eSx[s] = ss.x; c.eSy[s] = ss.y;
-            c.eBlock[s] = o != MW_FREE ? (o >> MW_SLOT_BITS) : 0u;
-            c.eState[s] = o != MW_FREE ? (int)ST_PARKED : claim ? (int)ST_GROWING : (int)ST_READY;
+            c.eBlock[s] = older ? (o >> MW_SLOT_BITS) : 0u;
+            c.eState[s] = older ? (int)ST_PARKED : claim ? (int)ST_GROWING : (int)ST_READY;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        rel_fence<MG>();
         if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + (int)__popcll(m)); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(dn + 64, c.nkeys)); }
+        int nx = dn + 64;
+        if (MG && (nx & ((1 << MG_WS_BITS) - 1)) == 0) nx += (c.G - 1) << MG_WS_BITS;
+        if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(nx, c.nkeys)); }
         did = true;
     }
     unlock(c.ctl + C_LOCKDISP, c.lane);
     if (did && claim) {
         const uint32_t T = ((uint32_t)rank << MW_SLOT_BITS) | (uint32_t)s;
-        const uint32_t old = __hip_atomic_fetch_min(c.owner + addr, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t old = own_min<MG>(c.owner + addr, T);
         if (old < T) {          // an older region took it in the meantime: consumed or to be re-examined once that region is final
             c.eBlock[s] = old >> MW_SLOT_BITS;
             __hip_atomic_store(c.eState + s, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            if (old != MW_FREE) mw_notify(c, old, (uint32_t)rank);     // a younger seed of a later window was quicker: the pixel is ours now
+            if (old != MW_FREE) mw_notify<MG>(c, old, (uint32_t)rank);     // a younger seed of a later window was quicker: the pixel is ours now
             c.eN[s] = 1;
+            if (MG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the notice is performed before the entry can commit and the watermark pass it
             __hip_atomic_store(c.eState + s, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
@@ -303,6 +407,7 @@ __device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* pre
 #define RUN_PROF_ARGS
 #define RUN_PROF_PASS
 #endif
+template <bool MG>
 __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int wv, double prec, double precWrap, const AngEnt* __restrict__ ent RUN_PROF_ARGS)
 {
     PROF_CNT(PF_NRUN);
@@ -322,11 +427,11 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
     if (prev != ST_READY) {
         // re-run: the seed may have been consumed in the meantime, and a finished region that was stolen from still holds its claims
         const int nOld = lds_u(c.eN + slot);
-        if (nOld > 0) { mw_release(c, slot, nOld, T); if (lane == 0) WG_STORE(c.eN + slot, 0); }
-        if (lane == 0) WG_STORE(c.eInval + slot, MW_FREE);      // steals from here on concern this run
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (nOld > 0) { mw_release<MG>(c, slot, nOld, T); if (lane == 0) WG_STORE(c.eN + slot, 0); }
+        if (lane == 0) { WG_STORE(c.eInval + slot, MW_FREE); if (MG) ag_store(c.gInvalAll + (size_t)c.grp * c.E + slot, MW_FREE); }      // steals from here on concern this run
+        rel_fence<MG>();
         uint32_t old0 = 0;
-        if (lane == 0) old0 = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) old0 = own_min<MG>(c.owner + seed, T);
         old0 = (uint32_t)uni((int)old0);
         if (old0 < T) {
             // claimed by an older region: consumed if that one is final, else wait for it
@@ -337,23 +442,25 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             }
             return;
         }
-        if (old0 != MW_FREE && lane == 0) mw_notify(c, old0, rank);
+        if (old0 != MW_FREE && lane == 0) mw_notify<MG>(c, old0, rank);
         if (sw & 0x80000000u) {
             // no neighbour is aligned with the seed's own angle (k_lsd_iso): the region is the seed alone, whatever is used around it
+            if (MG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) { WG_STORE(c.eN + slot, 1); __hip_atomic_store(c.eState + slot, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
             return;
         }
     } else if (lane == 0) {
         // first run of a seed that was free when it was dispatched: claim it and look at the answer with the first iteration's loads
-        pOld = __hip_atomic_fetch_min(c.owner + seed, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pOld = own_min<MG>(c.owner + seed, T);
         pMine = true;
     }
+    const int own = c.cb + slot;        // the slot's own chunk
     const uint32_t seedXY = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16);
     double reg_angle = d_mul((double)deg_v, kDegToRads);
     float sumdx = sx_v, sumdy = sy_v;
-    if (lane == 0) { ring[0] = seedXY; c.chunks[(size_t)slot * 32] = seedXY; c.links[slot] = -1; dir[0] = slot; }
+    if (lane == 0) { ring[0] = seedXY; c.chunks[(size_t)own * 32] = seedXY; c.links[own] = -1; dir[0] = own; }
     __builtin_amdgcn_wave_barrier();
-    int n = 1, i = 0, cur = slot;
+    int n = 1, i = 0, cur = own;
     uint32_t blocker = MW_FREE;
     bool fail = false, seedLost = false;      // seedLost: the seed itself had been taken by an older region when this run claimed it
     // results of the claims issued one iteration ago: a pixel an older region had taken between this region's test and its claim means the
@@ -361,7 +468,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
     // followed it and the pixel was added twice -- not observed, but detected rather than assumed away); a younger region's pixel is
     // ours now and that region is told
 #define MW_PENDING() do { \
-        if (pMine && pOld != MW_FREE && pOld > T) mw_notify(c, pOld, rank); \
+        if (pMine && pOld != MW_FREE && pOld > T) mw_notify<MG>(c, pOld, rank); \
         const unsigned long long _bad = wave_vote(pMine && pOld <= T); \
         pMine = false; \
         if (_bad) { const uint32_t _o = (uint32_t)rlane((int)pOld, __builtin_ctzll(_bad)); blocker = _o == T ? 0u : (_o >> MW_SLOT_BITS); fail = true; \
@@ -396,7 +503,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
         const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
         const uint32_t pw = c.grad[a];
-        const uint32_t o = AG_LOAD(c.owner + a);
+        const uint32_t o = own_load<MG>(c.owner + a);
         const int xy = xx | (yy << 16);
         // not mine, not used by a final region; an older, unfinished claim stays a candidate ("contested")
         const unsigned long long olderM = wave_vote(o < T);
@@ -486,7 +593,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
                 new1 = mw_alloc(c);
                 if (lastOrd > curOrd + 1 && new1 >= 0) new2 = mw_alloc(c);
                 if (new1 < 0 || (lastOrd > curOrd + 1 && new2 < 0)) {
-                    if (lane == 0) WG_STORE(c.ctl + C_ABORT, 1);
+                    mw_abort<MG>(c);
                     n = n0; blocker = 0; fail = true; break;
                 }
                 if (lane == 0) {
@@ -500,7 +607,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
             const bool mine = wave_bit(acc);
             if (mine) {
                 const int idx = n0 + wave_rank_below(acc);
-                pOld = __hip_atomic_fetch_min(c.owner + a, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pOld = own_min<MG>(c.owner + a, T);
                 pMine = true;
                 ring[idx & (MW_RING - 1)] = (uint32_t)xy;
                 const int ord = idx >> 5;
@@ -519,7 +626,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         PROF_CNT(PF_NFAIL);
         // the seed consumed by a region that is final already: resolved for good; anything else waits for the region it ran into
         const bool dead = seedLost && blocker < (uint32_t)lds_u(c.ctl + C_WM);
-        if (!seedLost) mw_release(c, slot, n, T);
+        if (!seedLost) mw_release<MG>(c, slot, n, T);
         if (lane == 0) {
             WG_STORE(c.eN + slot, 0);
             WG_STORE(c.eBlock + slot, blocker);
@@ -528,7 +635,7 @@ __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int w
         PROF(PF_FINISH);
         return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // list + links are in memory before the entry says DONE
+    rel_fence<MG>();          // list + links are in memory (MG: claims and steal notices performed) before the entry says DONE
     if (lane == 0) {
         WG_STORE(c.eN + slot, n);
         c.eAng[slot] = reg_angle;
@@ -542,15 +649,26 @@ size_t lsd_grow_mw_lds_bytes(int nw, int E)
     return (size_t)(C_N + 1) * 4 + (size_t)E * (9 * 4 + 8) + 8 + (size_t)nw * (MW_RING + MW_DIR) * 4;
 }
 
+// MG = false: one workgroup per image (blockIdx.x = image).  MG = true: G workgroups per image; block b serves image (b / 8 / G) * 8 + b % 8 as group (b / 8) % G, so that
+// the groups of an image land on ONE XCD under the observed round-robin placement (block b -> XCD b % 8) and meet in that XCD's L2 -- a speed matter only: every
+// cross-group access is an agent-scope atomic, correct under any placement.
+template <bool MG>
 __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll, uint32_t* __restrict__ ownerAll,
                                                       const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
-                                                      const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt)
+                                                      const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt,
+                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
-    const int img = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int img = blockIdx.x, grp = 0;
+    if (MG) {
+        const int k = blockIdx.x >> 3;
+        img = (k / G) * 8 + (blockIdx.x & 7); grp = k % G;
+        if (img >= n_images) return;
+    }
     MwCtx c;
     {
         unsigned char* p = smem;
@@ -575,27 +693,48 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     c.links = linksAll + (size_t)img * nChunks;
     c.recs = recsAll + (size_t)img * g.maxRegions;
     c.status = status;
-    c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32]; c.nChunks = poolLimit;      // (the bound of mw_alloc only: the per-image stride of chunks / links is nChunks)
+    c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32];
     c.Ws = g.Ws; c.Hs = g.Hs;
     c.minRegSize = g.minRegSize; c.maxRegions = g.maxRegions; c.lane = lane;
+    c.G = 1; c.grp = 0; c.cb = 0; c.gctl = nullptr; c.gInvalAll = nullptr; c.sRank = nullptr; c.sRec = nullptr;
+    c.nChunks = poolLimit;      // (the bound of mw_alloc only: the per-image stride of chunks / links is nChunks)
+    if (MG) {
+        unsigned char* mg = mgAll + (size_t)img * mgStride;
+        c.G = G; c.grp = grp;
+        const int share = poolLimit / G;            // every group allocates from its own part of the image's chunk pool (ids stay image-wide: k_lsd_rect walks them)
+        c.cb = grp * share; c.nChunks = c.cb + share;
+        c.gctl = reinterpret_cast<int*>(mg);
+        c.gInvalAll = reinterpret_cast<uint32_t*>(mg + MG_INVAL_OFF);
+        c.sRank = reinterpret_cast<int*>(mg + MG_RANK_OFF) + (size_t)grp * g.maxRegions;
+        c.sRec = reinterpret_cast<RegionRec*>(mg + mg_rec_off(g.maxRegions)) + (size_t)grp * g.maxRegions;
+    }
     for (int q = threadIdx.x; q < E; q += blockDim.x) c.eState[q] = ST_EMPTY;
     if (threadIdx.x < C_N + 1) c.ctl[threadIdx.x] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) c.ctl[C_POOLTOP] = E;              // chunk ids below E are the ROB slots' own chunks
+    if (threadIdx.x == 0) {
+        c.ctl[C_POOLTOP] = c.cb + E;              // chunk ids cb .. cb + E are the ROB slots' own chunks
+        if (MG) { c.ctl[C_DISPNEXT] = min(grp << MG_WS_BITS, c.nkeys); c.ctl[C_WML] = -1; }
+    }
     __syncthreads();
     const double prec = g.prec, precWrap = g.precWrap;
     int idle = 0;
     PROF_DECL;
     for (;;) {
-        const MwCtl cv = mw_ctl(c.ctl);
+        MwCtl cv = mw_ctl(c.ctl);
         if (lds_u(c.ctl + C_ABORT)) break;
-        mw_commit(c, cv);
+        mw_commit<MG>(c, cv, MG && cv.head >= cv.tail);
         PROF(PF_COMMIT);
+        // supply ahead of demand: any wave tops the reorder buffer up BEFORE it looks for a region whenever the buffer is less than half full, so that the waves do
+        // not run dry together and spin through commit / pick / dispatch while one of them waits for the dispatcher's loads (profiles/r4zz_mw_dispatch_ahead_ab.txt)
+        if (nw > 1 && cv.dispNext < c.nkeys && cv.tail - cv.head < (E >> 1) && lds_u(c.ctl + C_LOCKDISP) == 0) {
+            if (mw_dispatch<MG>(c, cv, angDeg, ent)) cv = mw_ctl(c.ctl);
+            PROF(PF_DISPATCH);
+        }
         int prev = ST_READY;
         const int slot = mw_pick(c, cv, &prev);
         PROF(PF_PICK);
-        if (slot >= 0) { idle = 0; mw_run(c, slot, prev, wv, prec, precWrap, ent RUN_PROF_PASS); continue; }
-        const int dsp = mw_dispatch(c, cv, angDeg, ent);
+        if (slot >= 0) { idle = 0; mw_run<MG>(c, slot, prev, wv, prec, precWrap, ent RUN_PROF_PASS); continue; }
+        const int dsp = mw_dispatch<MG>(c, cv, angDeg, ent);
         PROF(PF_DISPATCH);
         if (dsp) continue;
         // nothing to run, nothing to dispatch: finished, or waiting for other waves' regions
@@ -604,9 +743,23 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
             const MwCtl c2 = mw_ctl(c.ctl);
             if (c2.dispNext >= c.nkeys && c2.head == c2.tail) break;
         }
+        if (MG) mw_commit<MG>(c, cv, true);      // waiting for another group: look at its watermark again
         __builtin_amdgcn_s_sleep(8);
         PROF(PF_IDLE);
-        if (++idle > (1 << 21)) { if (lane == 0) { atomicOr(status, 16); WG_STORE(c.ctl + C_ABORT, 1); } break; }
+        if (++idle > (MG ? (1 << 18) : (1 << 21))) {
+            // the guard: what the first wave to give up saw goes to status[32..] (olf_debug_status)
+            if (lane == 0 && img == 0 && atomicCAS(status + 28 + grp, 0, 1) == 0) {
+                int* d = status + 64 + grp * 24;
+                const int hs = cv.head & c.mask;
+                d[0] = img; d[1] = grp; d[2] = cv.head; d[3] = cv.tail; d[4] = cv.dispNext; d[5] = (int)cv.wm;
+                d[6] = c.ctl[C_OMIN]; d[7] = c.ctl[C_WML]; d[8] = c.eState[hs]; d[9] = c.eRank[hs]; d[10] = (int)c.eInval[hs];
+                d[11] = (int)c.eBlock[hs]; d[12] = c.nkeys; d[13] = c.eN[hs];
+                if (MG) { for (int q = 0; q < c.G; ++q) d[14 + q] = ag_load(c.gctl + MGC_WM + 16 * q); d[18] = (int)ag_load(c.gInvalAll + (size_t)grp * E + hs); d[19] = ag_load(c.gctl + MGC_ABORT); }
+                d[20] = c.ctl[C_LOCKCOMMIT]; d[21] = c.ctl[C_LOCKDISP]; d[22] = (int)ag_load(c.owner + (c.eSeed[hs] & 0x3fffffu)); d[23] = (int)c.eSeed[hs];
+            }
+            if (lane == 0) atomicOr(status, 16);
+            mw_abort<MG>(c); break;
+        }
     }
 #ifdef OLF_MW_PROF
     if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)pf_acc[q]);
@@ -614,18 +767,72 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     __syncthreads();
     // growFmt: 0 = this image's regions are chunk chains; -1 = given up (chunk pool or region log exhausted, or the idle guard): nothing of
     // the image's gradient words was modified (claims live in the owner words), so k_lsd_grow replays it from the start (launch_lsd_grow)
-    if (threadIdx.x == 0) { const bool ab = c.ctl[C_ABORT] != 0; regCount[img] = ab ? 0 : c.ctl[C_NREG]; growFmt[img] = ab ? -1 : 0; }
+    if (threadIdx.x == 0) {
+        const bool ab = c.ctl[C_ABORT] != 0;
+        if (MG) {
+            // this group is through: nothing of it is unresolved any more (the other groups may still be waiting for exactly that); k_mg_merge writes regCount / growFmt
+            ag_store(c.gctl + MGC_WM + 16 * grp, MG_INF);
+            c.gctl[MGC_NREG + grp] = c.ctl[C_NREG];
+            if (ab) ag_store(c.gctl + MGC_ABORT, 1);
+        } else { regCount[img] = ab ? 0 : c.ctl[C_NREG]; growFmt[img] = ab ? -1 : 0; }
+    }
 }
 
-int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, hipStream_t s)
+// the groups' staging lists (each in rank order) -> the image's region log in rank order = the order the sequential loop logs them in
+__global__ __launch_bounds__(256) void k_mg_merge(const LineGeom* __restrict__ gp, unsigned char* __restrict__ mgAll, size_t mgStride, int G, RegionRec* __restrict__ recsAll,
+                                                  int* __restrict__ regCount, int* __restrict__ growFmt)
+{
+    const LineGeom& g = *gp;
+    const int img = blockIdx.x;
+    unsigned char* mg = mgAll + (size_t)img * mgStride;
+    const int* gctl = reinterpret_cast<const int*>(mg);
+    const int* ranks = reinterpret_cast<const int*>(mg + MG_RANK_OFF);
+    const RegionRec* srec = reinterpret_cast<const RegionRec*>(mg + mg_rec_off(g.maxRegions));
+    int cnt[MG_MAX_G], total = 0;
+    for (int q = 0; q < MG_MAX_G; ++q) { cnt[q] = q < G ? gctl[MGC_NREG + q] : 0; total += cnt[q]; }
+    if (gctl[MGC_ABORT] != 0 || total > g.maxRegions) {
+        if (threadIdx.x == 0) { regCount[img] = 0; growFmt[img] = -1; }
+        return;
+    }
+    RegionRec* out = recsAll + (size_t)img * g.maxRegions;
+    for (int q = 0; q < G; ++q) {
+        const int* rq = ranks + (size_t)q * g.maxRegions;
+        for (int j = threadIdx.x; j < cnt[q]; j += blockDim.x) {
+            const int r = rq[j];
+            int pos = j;
+            for (int o = 0; o < G; ++o) {
+                if (o == q) continue;
+                const int* ro = ranks + (size_t)o * g.maxRegions;
+                int lo = 0, hi = cnt[o];
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (ro[mid] < r) lo = mid + 1; else hi = mid; }
+                pos += lo;
+            }
+            out[pos] = srec[(size_t)q * g.maxRegions + j];
+        }
+    }
+    if (threadIdx.x == 0) { regCount[img] = total; growFmt[img] = 0; }
+}
+
+int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, int G, hipStream_t s)
 {
     const size_t lds = lsd_grow_mw_lds_bytes(nw, E);
     // at most 46 KB (16 waves, 512 entries): below the 64 KB a launch may ask for without a function attribute (which would have to be set per
     // device -- a process-wide "already set" flag is wrong with several GPUs in one process)
     if (lds > 64 * 1024) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
-    hipLaunchKernelGGL(k_lsd_grow_mw, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
-                       reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                       b.nChunks, b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks, b.growFmt);
+    const int poolLimit = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
+    if (G > 1) {
+        if (G > MG_MAX_G || E > MG_MAX_E || !b.mg || n_images > b.mgImages || poolLimit / G < E + 64) { set_error("launch_lsd_grow_mw: groups"); return OLF_ERR_INVALID; }
+        // the control words of every image start at zero (watermarks 0 = nothing final yet; the notice words are set when a slot is filled)
+        OLF_HIP_CHECK(hipMemset2DAsync(b.mg, b.mgStride, 0, MG_INVAL_OFF, (size_t)n_images, s));
+        const int blocks = ((n_images + 7) / 8) * 8 * G;
+        hipLaunchKernelGGL(k_lsd_grow_mw<true>, dim3(blocks), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
+                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images);
+        hipLaunchKernelGGL(k_mg_merge, dim3(n_images), dim3(256), 0, s, b.geom, b.mg, b.mgStride, G, reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.growFmt);
+    } else
+        hipLaunchKernelGGL(k_lsd_grow_mw<false>, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
+                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

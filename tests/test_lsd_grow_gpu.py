@@ -8,9 +8,10 @@ from orb_line_slam_amd import synth, _lib
 pytestmark = pytest.mark.gpu
 
 
-def _set(ex, w, h, n, waves, rob):
+def _set(ex, w, h, n, waves, rob, groups=1):
     ctx = ex._context(w, h, n)
     _lib.check(_lib.lib().olf_debug_lsd_waves(ctx.handle, waves, rob), "olf_debug_lsd_waves")
+    _lib.check(_lib.lib().olf_debug_lsd_groups(ctx.handle, groups), "olf_debug_lsd_groups")
 
 
 def _status(ex):
@@ -25,15 +26,20 @@ def test_growth_is_independent_of_wave_count(oracle, w, h):
     imgs = synth.stereo_batch(71, 2, w, h)            # 4 images
     want = [oracle.line_extract(im, p.line) for im in imgs]
     ex = ola.Lineextractor(0, 0.025, max_images=4)
-    for waves, rob in [(0, 0), (1, 128), (2, 128), (2, 256), (4, 256), (8, 512), (16, 512), (16, 128), (3, 256), (-1, 0)]:
-        _set(ex, w, h, 4, waves, rob)
-        kls, desc, counts = ex.extract_batch(imgs)
-        assert (_status(ex)[0] & (8 | 16)) == 0, (waves, rob, "capacity / watchdog flag")
-        for i in range(4):
-            n = int(counts[i])
-            assert n == len(want[i]["kls"]), (waves, rob, i, n, len(want[i]["kls"]))
-            assert np.array_equal(kls[i, :n], want[i]["kls"]), (waves, rob, i)
-            assert np.array_equal(desc[i, :n], want[i]["desc"]), (waves, rob, i)
+    # workgroups per image {1, 2, 4} (several CUs on one image: per-group reorder buffers over rank-interleaved 1024-seed windows) x the ten settings;
+    # groups = 0 is the automatic choice (4 for a batch this small)
+    for groups in (1, 2, 4, 0):
+        for waves, rob in [(0, 0), (1, 128), (2, 128), (2, 256), (4, 256), (8, 512), (16, 512), (16, 128), (3, 256), (-1, 0)]:
+            if groups != 1 and waves == 0:
+                continue                                  # (the one-wave agent has no groups)
+            _set(ex, w, h, 4, waves, rob, groups)
+            kls, desc, counts = ex.extract_batch(imgs)
+            assert (_status(ex)[0] & (8 | 16)) == 0, (groups, waves, rob, "capacity / watchdog flag")
+            for i in range(4):
+                n = int(counts[i])
+                assert n == len(want[i]["kls"]), (groups, waves, rob, i, n, len(want[i]["kls"]))
+                assert np.array_equal(kls[i, :n], want[i]["kls"]), (groups, waves, rob, i)
+                assert np.array_equal(desc[i, :n], want[i]["desc"]), (groups, waves, rob, i)
 
 
 def test_growth_noise_and_flat_images(oracle):
@@ -44,12 +50,40 @@ def test_growth_noise_and_flat_images(oracle):
     flat = np.full((h, w), 77, np.uint8)
     p = oracle.full_params(1000, 0)
     ex = ola.Lineextractor(0, 0.025, max_images=2)
-    for waves in (16, 4, 1):
-        _set(ex, w, h, 2, waves, 0)
-        for img in (noise, flat):
-            gk, gd = ex(img)
-            o = oracle.line_extract(img, p.line)
-            assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), waves
+    want = {id(img): oracle.line_extract(img, p.line) for img in (noise, flat)}
+    for groups in (1, 2, 4):
+        for waves in (16, 4, 1):
+            _set(ex, w, h, 2, waves, 0, groups)
+            for img in (noise, flat):
+                gk, gd = ex(img)
+                o = want[id(img)]
+                assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), (groups, waves)
+
+
+def test_growth_structured_images_across_workgroups(oracle):
+    """Images whose regions are long and collide across the 1024-seed windows the groups deal out: a fan of lines through one point, a checkerboard
+    (every edge has the same gradient magnitude: thousands of equal keys, regions of different windows meeting at every corner) and concentric rings."""
+    w, h = 480, 360
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    fan = np.full((h, w), 40, np.uint8)
+    ang = np.arctan2(yy - h / 2, xx - w / 2)
+    fan[(np.floor(ang / (np.pi / 12)) % 2) == 0] = 210
+    checker = (((xx // 24) + (yy // 24)) % 2 * 170 + 40).astype(np.uint8)
+    rings = (np.sin(np.hypot(xx - w / 2, yy - h / 2) / 6.0) * 100 + 128).astype(np.uint8)
+    p = oracle.full_params(1000, 0)
+    ex = ola.Lineextractor(0, 0.025, max_images=3)
+    imgs = np.stack([fan, checker, rings])
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    assert all(len(o["kls"]) > 8 for o in want)
+    for groups in (1, 2, 4):
+        for waves, rob in [(16, 512), (8, 256), (16, 128)]:
+            _set(ex, w, h, 3, waves, rob, groups)
+            kls, desc, counts = ex.extract_batch(imgs)
+            assert (_status(ex)[0] & (8 | 16)) == 0, (groups, waves, rob)
+            for i in range(3):
+                n = int(counts[i])
+                assert n == len(want[i]["kls"]), (groups, waves, rob, i, n, len(want[i]["kls"]))
+                assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (groups, waves, rob, i)
 
 
 def test_pool_exhaustion_falls_back_to_the_one_wave_agent(oracle):
