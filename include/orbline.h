@@ -181,7 +181,7 @@ int olf_debug_status_n(olf_ctx* ctx, int32_t* out, int n);
 int olf_debug_lsd_owner(olf_ctx* ctx, int image, uint32_t* out);      /* debug: owner words of the last growth, Ws*Hs */
 int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* angle, int cap, int32_t* count);     /* the first n (<= 256) words */
 /* debug/test: waves per image of the LSD region-growing kernel (1..16; 0 = the one-wave sequential agent; -1 = automatic from the batch
- * size) and entries of its reorder buffer (128, 256 or 512; 0 = automatic).  Results do not depend on either. */
+ * size) and entries of its reorder buffer (128, 256, 512, or 1024 with several workgroups per image; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
 /* debug/test: workgroups (CUs) that grow ONE image together when the kernel runs 16 waves per image (1, 2 or 4; 0 = automatic from the batch
  * size: the one-pair-per-call shape of Frame::Frame, src/Frame.cc:164-171, takes 4).  Results do not depend on it. */

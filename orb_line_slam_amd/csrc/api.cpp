@@ -549,7 +549,7 @@ int olf_debug_copy_bandwidth(olf_ctx* c, size_t bytes, int reps, double* gbytes_
 int olf_debug_lsd_waves(olf_ctx* c, int waves_per_image, int rob_entries)
 {
     const bool pow2 = rob_entries > 0 && (rob_entries & (rob_entries - 1)) == 0;
-    if (!c || waves_per_image > 16 || waves_per_image < -1 || (rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 512))) {
+    if (!c || waves_per_image > 16 || waves_per_image < -1 || (rob_entries != 0 && (!pow2 || rob_entries < 128 || rob_entries > 1024))) {
         set_error("olf_debug_lsd_waves: bad argument"); return OLF_ERR_INVALID;
     }
     c->lb.forceNW = waves_per_image;

@@ -1610,11 +1610,12 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     b.chained = nw != 0;
     if (nw > 0) {
         // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
-        static const int envE = [] { const char* e = getenv("OLF_LSD_ROB"); const int v = e ? atoi(e) : 0; return (v == 128 || v == 256 || v == 512) ? v : 0; }();
-        const int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
+        static const int envE = [] { const char* e = getenv("OLF_LSD_ROB"); const int v = e ? atoi(e) : 0; return (v == 128 || v == 256 || v == 512 || v == 1024) ? v : 0; }();
+        int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
         int G = b.forceG > 0 ? b.forceG : lsd_grow_groups(n_images, nw);
         const int pool = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
-        while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > 256 || E > 512 || pool / G < E + 64)) G >>= 1;      // (every group of an image has to be resident: one workgroup per CU)
+        while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > 256 || pool / G < E + 64)) G >>= 1;      // (every group of an image has to be resident: one workgroup per CU)
+        if (G == 1 && E > 512) E = 512;                                                                          // (the 1024-entry buffer is the groups' only)
         const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, G, s);
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the

@@ -35,7 +35,7 @@ constexpr uint32_t MW_FREE = 0xffffffffu;
 constexpr int MW_RING = 256;          // FIFO window of a growing region kept in LDS, per wave
 constexpr int MW_DIR = 128;           // chunk directory per wave (ordinal -> chunk id) for reading the FIFO from memory
 enum { ST_EMPTY = 0, ST_READY = 1, ST_PARKED = 2, ST_GROWING = 3, ST_DONE = 4, ST_DEAD = 5 };
-enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_FREEHEAD, C_OMIN, C_WML, C_N };
+enum { C_HEAD = 0, C_TAIL, C_DISPNEXT, C_WM, C_LOCKDISP, C_LOCKCOMMIT, C_LOCKALLOC, C_FREETOP, C_POOLTOP, C_NREG, C_ABORT, C_FREEHEAD, C_OMIN, C_WML, C_SCAN, C_SCANVER, C_N };
 
 #define WG_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define WG_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -126,12 +126,13 @@ struct MwCtx {
     int E, mask, nkeys, nChunks, Ws, Hs, minRegSize, maxRegions, lane;
     // several workgroups per image (MG): this group, the group count, the first chunk id of this group's share of the pool (slot chunks cb .. cb + E, pool behind),
     // the image's control words / notice words [G][E] in global memory and this group's staging list of logged regions
-    int G, grp, cb;
+    int G, grp, cb, ws;         // ws: log2 of the seed window (64 .. 1024 seeds)
     int* gctl; uint32_t* gInvalAll; int* sRank; RegionRec* sRec;
+    const unsigned long long* tl0;      // (-DOLF_MW_PROF) start of the launch, image 0 only
 };
 
 // global control words of an image grown by several workgroups (ints): the groups' published watermarks on lines of their own, the abort flag, regions logged per group
-constexpr int MG_MAX_G = 4, MG_MAX_E = 512, MG_WS_BITS = 10;
+constexpr int MG_MAX_G = 4, MG_MAX_E = 1024;
 constexpr int MGC_WM = 0, MGC_ABORT = 16 * MG_MAX_G, MGC_NREG = MGC_ABORT + 16, MGC_WORDS = MGC_NREG + 16;
 constexpr int MG_INF = 0x7fffffff;
 constexpr size_t MG_INVAL_OFF = 1024, MG_RANK_OFF = MG_INVAL_OFF + (size_t)MG_MAX_G * MG_MAX_E * 4;
@@ -139,7 +140,7 @@ static_assert(MGC_WORDS * 4 <= (int)MG_INVAL_OFF, "control words");
 __host__ __device__ inline size_t mg_rec_off(int maxRegions) { return (MG_RANK_OFF + (size_t)MG_MAX_G * maxRegions * 4 + 15) & ~(size_t)15; }
 size_t lsd_grow_mg_stride(int maxRegions) { return (mg_rec_off(maxRegions) + (size_t)MG_MAX_G * maxRegions * sizeof(RegionRec) + 255) & ~(size_t)255; }
 // group of the seed of rank r
-__device__ __forceinline__ int mg_group(uint32_t rank, int G) { return (int)((rank >> MG_WS_BITS) % (uint32_t)G); }
+__device__ __forceinline__ int mg_group(uint32_t rank, int G, int ws) { return (int)((rank >> ws) % (uint32_t)G); }
 
 template <bool MG> __device__ __forceinline__ void mw_abort(const MwCtx& c)
 {
@@ -206,6 +207,16 @@ __device__ __forceinline__ void mw_release(const MwCtx& c, int slot, int n, uint
     rel_fence<MG>();      // the pixels are free before the entry changes state
 }
 
+// The scan hint of mw_pick (C_SCAN): every entry below it is settled -- DEAD, or DONE with no steal noted -- and a settled entry only ever changes when a steal
+// is noted for it.  Whoever notes a steal (after setting the entry's notice word) bumps C_SCANVER and pulls the hint back to that entry; a pick that raised the
+// hint from a scan made before the notice sees the new version and pulls the hint back to the head.
+__device__ __forceinline__ void mw_unsettle(const MwCtx& c, int slot)
+{
+    __hip_atomic_fetch_add(c.ctl + C_SCANVER, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int h = WG_LOAD(c.ctl + C_HEAD);
+    __hip_atomic_fetch_min(c.ctl + C_SCAN, h + ((slot - h) & c.mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // commit DONE / DEAD entries at the head of the ROB, in rank order, up to 64 per call; logs the regions that are large enough.
 // `ctl` is the caller's snapshot (the cheap test whether the head entry can go at all is made on it, without the lock).
 // MG: the call also refreshes this group's view of the other groups (their watermarks, the abort flag, steal notices from their regions) and publishes the
@@ -241,10 +252,10 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool 
                 const int i2 = i + k, s2 = i2 & c.mask;
                 if (i2 < cl.tail) {
                     const uint32_t v = ag_load(gi + s2);
-                    if (v != MW_FREE) __hip_atomic_fetch_min(c.eInval + s2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (v != MW_FREE) { __hip_atomic_fetch_min(c.eInval + s2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, s2); }
                 }
             }
-            if (giv != MW_FREE) __hip_atomic_fetch_min(c.eInval + slot, giv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (giv != MW_FREE) { __hip_atomic_fetch_min(c.eInval + slot, giv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, slot); }
             omin = lds_u(reinterpret_cast<uint32_t*>(c.ctl) + C_OMIN);
             for (int g2 = 0; g2 < c.G; ++g2) ominNew = min(ominNew, (uint32_t)rlane(wmo, g2));
             if (uni(ab) && c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1);
@@ -300,90 +311,175 @@ __device__ __forceinline__ void mw_notify(const MwCtx& c, uint32_t victim, uint3
 {
     const uint32_t vs = victim & ((1u << MW_SLOT_BITS) - 1u);
     if (MG) {
-        const int vg = mg_group(victim >> MW_SLOT_BITS, c.G);
+        const int vg = mg_group(victim >> MW_SLOT_BITS, c.G, c.ws);
         if (vg != c.grp) { __hip_atomic_fetch_min(c.gInvalAll + (size_t)vg * c.E + vs, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     }
     __hip_atomic_fetch_min(c.eInval + vs, rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    mw_unsettle(c, (int)vs);
 }
 
-// next 64 keys -> ROB entries for the seeds that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do.
-// The loads (keys, seed words, owners, the seeds' table entries) are done before the lock is taken, the lock only covers the insertion;
-// isolated seeds (k_lsd_iso) are claimed right here, 64 at a time, and enter the ROB as finished one-pixel regions.
-// MG: the group's seeds are the windows of 1024 ranks w with w % G == grp; a 64-seed step never straddles a window.
+// the next seeds -> ROB entries for those that are not already consumed by a final region.  1: progress (or somebody else is at it), 0: nothing to do.
+// A call looks at up to MW_DK steps of 64 seeds at once -- every load of every step in flight together -- and inserts as many WHOLE steps as the buffer has room
+// for: behind the first ten thousand seeds nearly every seed of a step has been consumed already, and a dispatcher that takes one step per dependent round of
+// loads (keys -> owner word + gradient word -> table entry, 2.2 us) is what the rest of the image then waits for (profiles/r5a_growth_timeline.txt).
+// The loads are done before the lock is taken, the lock only covers the insertion; isolated seeds (k_lsd_iso) are claimed right here and enter the ROB as
+// finished one-pixel regions.  MG: the group's seeds are the windows w of 2^ws ranks with w % G == grp; a call never straddles a window.
+#ifndef MW_DK
+#define MW_DK 1
+#endif
 template <bool MG>
 __device__ __forceinline__ int mw_dispatch(const MwCtx& c, const MwCtl& cv, const float* __restrict__ angDeg, const AngEnt* __restrict__ ent)
 {
     const int dn0 = cv.dispNext;
     if (dn0 >= c.nkeys) return 0;
     if (cv.tail - cv.head > c.E - 64) return 0;
-    const int rank = dn0 + c.lane;
-    const bool valid = rank < c.nkeys;
-    const int addr = valid ? (int)(c.keys[rank] & 0x3fffffu) : 0;
-    const uint32_t o = valid ? own_load<MG>(c.owner + addr) : 0u;
-    const uint32_t w = valid ? c.grad[addr] : 0u;
-    const bool iso = (w & kIso) != 0;
-    float deg = 0.f;
-    float2 ss = make_float2(0.f, 0.f);
-    if (valid && !iso) { deg = angDeg[w & 0x3fffffu]; ss = ent[w & 0x3fffffu].seed; }    // region_grow starts at the seed's angle and at (cos, sin) of it
+    int K = min(MW_DK, (c.nkeys - dn0 + 63) >> 6);
+    if (MG) K = min(K, ((1 << c.ws) - (dn0 & ((1 << c.ws) - 1))) >> 6);
+    int addr[MW_DK]; uint32_t o[MW_DK], w[MW_DK]; float deg[MW_DK]; float2 ss[MW_DK];
+#pragma unroll
+    for (int k = 0; k < MW_DK; ++k) {
+        const int rank = dn0 + 64 * k + c.lane;
+        addr[k] = (k < K && rank < c.nkeys) ? (int)(c.keys[rank] & 0x3fffffu) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < MW_DK; ++k) {
+        o[k] = addr[k] >= 0 ? own_load<MG>(c.owner + addr[k]) : 0u;
+        w[k] = addr[k] >= 0 ? c.grad[addr[k]] : (uint32_t)kNotDef;
+    }
+#pragma unroll
+    for (int k = 0; k < MW_DK; ++k) {
+        deg[k] = 0.f; ss[k] = make_float2(0.f, 0.f);
+        // region_grow starts at the seed's angle and at (cos, sin) of it (not needed for a seed that the snapshot's watermark already shows consumed)
+        const bool gone = o[k] != MW_FREE && (o[k] >> MW_SLOT_BITS) < cv.wm;
+        if (addr[k] >= 0 && !(w[k] & (kIso | kNotDef)) && !gone) { deg[k] = angDeg[w[k] & 0x3fffffu]; ss[k] = ent[w[k] & 0x3fffffu].seed; }
+    }
     if (!try_lock(c.ctl + C_LOCKDISP, c.lane)) return 1;
     const MwCtl cl = mw_ctl(c.ctl);
     const int dn = cl.dispNext, t = cl.tail, h = cl.head;
-    bool did = false, claim = false;
-    int s = 0;
+    int done = 0, total = 0;                    // steps inserted, entries inserted
+    bool claim[MW_DK]; int sl[MW_DK];
     if (dn == dn0 && t - h <= c.E - 64) {
         const uint32_t wm = cl.wm;
-        // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; they are never seeds)
-        // (MG: a region of another group's LATER window may hold the seed already -- a younger owner counts as free here; the claim takes the pixel from it and tells it)
-        const bool older = o != MW_FREE && (o >> MW_SLOT_BITS) < (uint32_t)rank;
-        const bool live = valid && !(w & kNotDef) && !(older && (o >> MW_SLOT_BITS) < wm);
-        const unsigned long long m = wave_vote(live);
-        if (live) {
-            s = (t + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
-            claim = iso && !older;
-            c.eRank[s] = rank;
-            c.eSeed[s] = (uint32_t)addr | (iso ? 0x80000000u : 0u);
-            c.eInval[s] = MW_FREE;
-            if (MG) ag_store(c.gInvalAll + (size_t)c.grp * c.E + s, MW_FREE);      // (performed before the tag of this entry can be in any owner word: rel_fence below)
-            c.eN[s] = 0;
-            c.eDeg[s] = deg; c.eSx[s] = ss.x; c.eSy[s] = ss.y;
-            c.eBlock[s] = older ? (o >> MW_SLOT_BITS) : 0u;
-            c.eState[s] = older ? (int)ST_PARKED : claim ? (int)ST_GROWING : (int)ST_READY;
+        const int room = c.E - (t - h);
+#pragma unroll
+        for (int k = 0; k < MW_DK; ++k) {
+            claim[k] = false; sl[k] = 0;
+            if (k < K && done == k) {
+                const int rank = dn0 + 64 * k + c.lane;
+                const bool iso = (w[k] & kIso) != 0;
+                // (kNotDef: the std::sort seed list also holds the undefined pixels of the smallest defined bin; they are never seeds)
+                // (MG: a region of another group's LATER window may hold the seed already -- a younger owner counts as free here; the claim takes the pixel from it and tells it)
+                const bool older = o[k] != MW_FREE && (o[k] >> MW_SLOT_BITS) < (uint32_t)rank;
+                const bool gone = older && (o[k] >> MW_SLOT_BITS) < wm;
+                // (a seed whose table entry was skipped because the older snapshot showed it consumed is consumed under the newer watermark too)
+                const bool live = addr[k] >= 0 && !(w[k] & kNotDef) && !gone;
+                const unsigned long long m = wave_vote(live);
+                const int cnt = (int)__popcll(m);
+                if (total + cnt <= room) {
+                    if (live) {
+                        const int s = (t + total + __popcll(m & ((1ull << c.lane) - 1ull))) & c.mask;
+                        sl[k] = s;
+                        claim[k] = iso && !older;
+                        c.eRank[s] = rank;
+                        c.eSeed[s] = (uint32_t)addr[k] | (iso ? 0x80000000u : 0u);
+                        c.eInval[s] = MW_FREE;
+                        if (MG) ag_store(c.gInvalAll + (size_t)c.grp * c.E + s, MW_FREE);      // (performed before the tag of this entry can be in any owner word: rel_fence below)
+                        c.eN[s] = 0;
+                        c.eDeg[s] = deg[k]; c.eSx[s] = ss[k].x; c.eSy[s] = ss[k].y;
+                        c.eBlock[s] = older ? (o[k] >> MW_SLOT_BITS) : 0u;
+                        c.eState[s] = older ? (int)ST_PARKED : claim[k] ? (int)ST_GROWING : (int)ST_READY;
+                    }
+                    total += cnt;
+                    done = k + 1;
+                }
+            }
         }
         rel_fence<MG>();
-        if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + (int)__popcll(m)); }
+        if (c.lane == 0) { WG_STORE(c.ctl + C_TAIL, t + total); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        int nx = dn + 64;
-        if (MG && (nx & ((1 << MG_WS_BITS) - 1)) == 0) nx += (c.G - 1) << MG_WS_BITS;
+        int nx = dn + 64 * done;
+        if (MG && (nx & ((1 << c.ws) - 1)) == 0) nx += (c.G - 1) << c.ws;
         if (c.lane == 0) { WG_STORE(c.ctl + C_DISPNEXT, min(nx, c.nkeys)); }
-        did = true;
+#ifdef OLF_MW_PROF
+        // when (10 ns ticks since the first block of the launch started) the dispatcher of image 0 crosses every 4096th rank: status[160 + rank / 4096]
+        if (c.lane == 0 && c.tl0) {
+            atomicAdd(c.status + 158, total);
+            const int kb = ((dn + 64 * done) >> 12) - 1;
+            if (((dn >> 12) != ((dn + 64 * done) >> 12)) && kb < 30) {
+                c.status[160 + kb] = (int)(__builtin_amdgcn_s_memrealtime() - *c.tl0);
+                c.status[190 + kb] = atomicAdd(c.status + 158, 0); c.status[220 + kb] = atomicAdd(c.status + 159, 0);
+            }
+        }
+#endif
     }
     unlock(c.ctl + C_LOCKDISP, c.lane);
-    if (did && claim) {
-        const uint32_t T = ((uint32_t)rank << MW_SLOT_BITS) | (uint32_t)s;
-        const uint32_t old = own_min<MG>(c.owner + addr, T);
-        if (old < T) {          // an older region took it in the meantime: consumed or to be re-examined once that region is final
-            c.eBlock[s] = old >> MW_SLOT_BITS;
-            __hip_atomic_store(c.eState + s, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            if (old != MW_FREE) mw_notify<MG>(c, old, (uint32_t)rank);     // a younger seed of a later window was quicker: the pixel is ours now
-            c.eN[s] = 1;
-            if (MG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the notice is performed before the entry can commit and the watermark pass it
-            __hip_atomic_store(c.eState + s, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int k = 0; k < MW_DK; ++k) {
+        if (k < done && claim[k]) {
+            const int rank = dn0 + 64 * k + c.lane, s = sl[k];
+            const uint32_t T = ((uint32_t)rank << MW_SLOT_BITS) | (uint32_t)s;
+            const uint32_t old = own_min<MG>(c.owner + addr[k], T);
+            if (old < T) {          // an older region took it in the meantime: consumed or to be re-examined once that region is final
+                c.eBlock[s] = old >> MW_SLOT_BITS;
+                __hip_atomic_store(c.eState + s, (int)ST_PARKED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (old != MW_FREE) mw_notify<MG>(c, old, (uint32_t)rank);     // a younger seed of a later window was quicker: the pixel is ours now
+                c.eN[s] = 1;
+                if (MG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the notice is performed before the entry can commit and the watermark pass it
+                __hip_atomic_store(c.eState + s, (int)ST_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     return 1;
 }
 
-// lowest-rank entry that can be (re-)run now; returns its slot with the entry in state GROWING (its previous state in *prev), or -1
+// lowest-rank entry that can be (re-)run now; returns its slot with the entry in state GROWING (its previous state in *prev), or -1.
+// The scan starts at the hint (see mw_unsettle): with several workgroups per image a buffer is mostly finished regions waiting for another group's watermark.
+template <bool MG>
 __device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* prev)
 {
-    const int h = cv.head, t = cv.tail;
+    const int t = cv.tail;
     const uint32_t wm = cv.wm;
-    for (int base = h; base < t; base += 64) {
+    const int ver0 = lds_u(c.ctl + C_SCANVER);
+    const int hint0 = lds_u(c.ctl + C_SCAN);
+    const int h = max(cv.head, hint0);
+    int settledTo = h;              // every entry in [h, settledTo) was seen settled
+    bool open = true;               // ... and nothing unsettled has been seen yet
+    int found = -1;
+    for (int base = h; base < t && found < 0; base += 64) {
         const int i = base + c.lane;
         const int slot = i & c.mask;
-        const int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
-        const uint32_t bl = WG_LOAD(c.eBlock + slot), iv = WG_LOAD(c.eInval + slot);
+        int st = i < t ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
+        uint32_t bl = WG_LOAD(c.eBlock + slot);
+        const uint32_t iv = WG_LOAD(c.eInval + slot);
+#ifndef OLF_MW_NO_BULK
+        {
+            // seeds parked on a region that is final now -- all of this step at once: one look at the seed's owner word decides "consumed for good" (DEAD, the
+            // common case behind the first few thousand seeds) without a region run of its own (pick, prologue, claim, finish: 6-7 k cycles each); a seed that
+            // turns out free goes back with blocker 0, which the ordinary path below takes; one that another unfinished region holds waits for that one
+            const bool pk = st == ST_PARKED && bl != 0u && bl < wm;
+            if (wave_vote(pk)) {
+                bool mine = false;
+                if (pk) { int exp = ST_PARKED; mine = __hip_atomic_compare_exchange_strong(c.eState + slot, &exp, (int)ST_GROWING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                if (mine) {
+                    const uint32_t rk = (uint32_t)WG_LOAD(c.eRank + slot);
+                    const uint32_t o = own_load<MG>(c.owner + (WG_LOAD(c.eSeed + slot) & 0x3fffffu));
+                    const bool older = o != MW_FREE && (o >> MW_SLOT_BITS) < rk;
+                    const bool gone = older && (o >> MW_SLOT_BITS) < wm;
+                    bl = older ? (o >> MW_SLOT_BITS) : 0u;
+                    st = gone ? (int)ST_DEAD : (int)ST_PARKED;
+                    if (!gone) WG_STORE(c.eBlock + slot, bl);
+                    __hip_atomic_store(c.eState + slot, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+#endif
+        if (open) {
+            const unsigned long long sm = wave_vote(st == ST_DEAD || (st == ST_DONE && iv == MW_FREE));
+            const int run = sm == ~0ull ? 64 : __builtin_ctzll(~sm);
+            settledTo = min(base + run, t);
+            open = run == 64;
+        }
         const bool el = st == ST_READY || (st == ST_PARKED && bl < wm) || (st == ST_DONE && iv != MW_FREE && iv < wm);
         unsigned long long m = wave_vote(el);
         while (m) {
@@ -392,11 +488,19 @@ __device__ __forceinline__ int mw_pick(const MwCtx& c, const MwCtl& cv, int* pre
             int exp = rlane(st, l);
             int ok = 0;
             if (c.lane == 0) ok = __hip_atomic_compare_exchange_strong(c.eState + s, &exp, (int)ST_GROWING, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1 : 0;
-            if (uni(ok)) { *prev = rlane(st, l); return s; }
+            if (uni(ok)) { *prev = rlane(st, l); found = s; break; }
             m &= m - 1ull;
         }
     }
-    return -1;
+    if (settledTo > hint0) {
+        if (c.lane == 0) {
+            int exp = hint0;
+            if (__hip_atomic_compare_exchange_strong(c.ctl + C_SCAN, &exp, settledTo, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) &&
+                WG_LOAD(c.ctl + C_SCANVER) != ver0)
+                __hip_atomic_fetch_min(c.ctl + C_SCAN, WG_LOAD(c.ctl + C_HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    return found;
 }
 
 // grow (or re-grow) the region of ROB entry `slot`, which this wave holds in state GROWING
@@ -411,6 +515,9 @@ template <bool MG>
 __device__ __forceinline__ void mw_run(const MwCtx& c, int slot, int prev, int wv, double prec, double precWrap, const AngEnt* __restrict__ ent RUN_PROF_ARGS)
 {
     PROF_CNT(PF_NRUN);
+#ifdef OLF_MW_PROF
+    if (c.tl0 && c.lane == 0) atomicAdd(c.status + 159, 1);
+#endif
     const int lane = c.lane, Ws = c.Ws, Hs = c.Hs;
     const int rank_v = WG_LOAD(c.eRank + slot);
     const uint32_t sw_v = WG_LOAD(c.eSeed + slot);
@@ -658,7 +765,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
                                                       const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt,
-                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images)
+                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images, int wsBits)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -696,11 +803,11 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     c.E = E; c.mask = E - 1; c.nkeys = keyCount[img * 32];
     c.Ws = g.Ws; c.Hs = g.Hs;
     c.minRegSize = g.minRegSize; c.maxRegions = g.maxRegions; c.lane = lane;
-    c.G = 1; c.grp = 0; c.cb = 0; c.gctl = nullptr; c.gInvalAll = nullptr; c.sRank = nullptr; c.sRec = nullptr;
+    c.G = 1; c.grp = 0; c.cb = 0; c.ws = 10; c.gctl = nullptr; c.gInvalAll = nullptr; c.sRank = nullptr; c.sRec = nullptr;
     c.nChunks = poolLimit;      // (the bound of mw_alloc only: the per-image stride of chunks / links is nChunks)
     if (MG) {
         unsigned char* mg = mgAll + (size_t)img * mgStride;
-        c.G = G; c.grp = grp;
+        c.G = G; c.grp = grp; c.ws = wsBits;
         const int share = poolLimit / G;            // every group allocates from its own part of the image's chunk pool (ids stay image-wide: k_lsd_rect walks them)
         c.cb = grp * share; c.nChunks = c.cb + share;
         c.gctl = reinterpret_cast<int*>(mg);
@@ -708,12 +815,20 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         c.sRank = reinterpret_cast<int*>(mg + MG_RANK_OFF) + (size_t)grp * g.maxRegions;
         c.sRec = reinterpret_cast<RegionRec*>(mg + mg_rec_off(g.maxRegions)) + (size_t)grp * g.maxRegions;
     }
+    c.tl0 = nullptr;
+#ifdef OLF_MW_PROF
+    if (img == 0) {
+        unsigned long long* t0 = reinterpret_cast<unsigned long long*>(status + 156);
+        if (threadIdx.x == 0) atomicCAS(t0, 0ull, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        c.tl0 = t0;
+    }
+#endif
     for (int q = threadIdx.x; q < E; q += blockDim.x) c.eState[q] = ST_EMPTY;
     if (threadIdx.x < C_N + 1) c.ctl[threadIdx.x] = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         c.ctl[C_POOLTOP] = c.cb + E;              // chunk ids cb .. cb + E are the ROB slots' own chunks
-        if (MG) { c.ctl[C_DISPNEXT] = min(grp << MG_WS_BITS, c.nkeys); c.ctl[C_WML] = -1; }
+        if (MG) { c.ctl[C_DISPNEXT] = min(grp << wsBits, c.nkeys); c.ctl[C_WML] = -1; }
     }
     __syncthreads();
     const double prec = g.prec, precWrap = g.precWrap;
@@ -731,7 +846,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
             PROF(PF_DISPATCH);
         }
         int prev = ST_READY;
-        const int slot = mw_pick(c, cv, &prev);
+        const int slot = mw_pick<MG>(c, cv, &prev);
         PROF(PF_PICK);
         if (slot >= 0) { idle = 0; mw_run<MG>(c, slot, prev, wv, prec, precWrap, ent RUN_PROF_PASS); continue; }
         const int dsp = mw_dispatch<MG>(c, cv, angDeg, ent);
@@ -762,6 +877,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         }
     }
 #ifdef OLF_MW_PROF
+    if (img == 0 && threadIdx.x == 0) status[250 + grp] = (int)(__builtin_amdgcn_s_memrealtime() - *c.tl0);
     if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)pf_acc[q]);
 #endif
     __syncthreads();
@@ -816,23 +932,35 @@ __global__ __launch_bounds__(256) void k_mg_merge(const LineGeom* __restrict__ g
 int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int nw, int E, int G, hipStream_t s)
 {
     const size_t lds = lsd_grow_mw_lds_bytes(nw, E);
-    // at most 46 KB (16 waves, 512 entries): below the 64 KB a launch may ask for without a function attribute (which would have to be set per
-    // device -- a process-wide "already set" flag is wrong with several GPUs in one process)
-    if (lds > 64 * 1024) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
+    // up to 46 KB (16 waves, 512 entries) fits the 64 KB a launch may ask for without a function attribute; a 1024-entry buffer (70 KB) needs the attribute,
+    // which is a property of the function ON THE CURRENT DEVICE: set per device, remembered per device
+    if (lds > 64 * 1024) {
+        static bool done[64] = {};
+        int dev = 0;
+        OLF_HIP_CHECK(hipGetDevice(&dev));
+        if (lds > 100 * 1024 || G < 2 || dev < 0 || dev >= 64) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
+        if (!done[dev]) {
+            OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_grow_mw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            done[dev] = true;
+        }
+    }
     const int poolLimit = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
     if (G > 1) {
+        // OLF_LSD_WS: log2 of the seed window the groups are dealt (6 .. 10), for A/B runs
+        static const int envWs = [] { const char* e = getenv("OLF_LSD_WS"); const int v = e ? atoi(e) : 0; return (v >= 6 && v <= 10) ? v : 0; }();
+        const int wsBits = envWs ? envWs : 10;
         if (G > MG_MAX_G || E > MG_MAX_E || !b.mg || n_images > b.mgImages || poolLimit / G < E + 64) { set_error("launch_lsd_grow_mw: groups"); return OLF_ERR_INVALID; }
         // the control words of every image start at zero (watermarks 0 = nothing final yet; the notice words are set when a slot is filled)
         OLF_HIP_CHECK(hipMemset2DAsync(b.mg, b.mgStride, 0, MG_INVAL_OFF, (size_t)n_images, s));
         const int blocks = ((n_images + 7) / 8) * 8 * G;
         hipLaunchKernelGGL(k_lsd_grow_mw<true>, dim3(blocks), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images);
+                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images, wsBits);
         hipLaunchKernelGGL(k_mg_merge, dim3(n_images), dim3(256), 0, s, b.geom, b.mg, b.mgStride, G, reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.growFmt);
     } else
         hipLaunchKernelGGL(k_lsd_grow_mw<false>, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images);
+                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images, 10);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
