@@ -117,6 +117,58 @@ __global__ __launch_bounds__(64) void k_lines_dist(const LinePrep* __restrict__ 
     m21[(size_t)pair * cap + i2] = who;
 }
 
+// The same matrix with ONE WAVE per right line (few pairs per call -- the drop-in's online shape, where one thread per right line leaves a pair to eight
+// waves walking 500 left lines each): the lanes take 64 consecutive left lines, the strict running minimum becomes an exclusive prefix minimum over the lanes
+// seeded with the carry of the earlier steps -- left line i1 is a new record iff its distance is below everything before it, exactly the sequential scan.
+__device__ __forceinline__ bool in_window_g(const LinePrep* __restrict__ R, int cx, int cy, int ws)
+{
+    if (cy < 0 || cy >= GR) return false;
+    const int lo = max(0, cx - ws), hi = min(GC, cx + 1) - 1;
+    if (lo > hi) return false;
+    return (int)R->lo[cy] <= hi && (int)R->hi[cy] >= lo;
+}
+__global__ __launch_bounds__(256) void k_lines_dist_w(const LinePrep* __restrict__ prep, const uint8_t* __restrict__ desc,
+                                                     const int* __restrict__ counts, int cap, int ws, double sim_th, int best_lr,
+                                                     uint16_t* __restrict__ dist, int* __restrict__ m21)
+{
+    const int pair = blockIdx.y, i2 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nL = counts[2 * pair], nR = counts[2 * pair + 1];
+    if (i2 >= nR) return;
+    const LinePrep* Rp = prep + (size_t)(2 * pair + 1) * cap + i2;
+    const double Rvx = Rp->vx, Rvy = Rp->vy;
+    const uint4* dR = reinterpret_cast<const uint4*>(desc + ((size_t)(2 * pair + 1) * cap + i2) * OLF_DESC_BYTES);
+    const int INF = 0x7fffffff;
+    int running = INF, who = -1;
+    uint16_t* col = dist + (size_t)pair * cap * cap + i2;
+    for (int base = 0; base < nL; base += 64) {
+        const int i1 = base + lane;
+        int d = INF;
+        if (i1 < nL) {
+            const LinePrep* Lp = prep + (size_t)(2 * pair) * cap + i1;
+            const int spx = Lp->spx, spy = Lp->spy, epx = Lp->epx, epy = Lp->epy;
+            if (in_window_g(Rp, spx, spy, ws) || in_window_g(Rp, epx, epy, ws)) {
+                const double dt = d_add(d_mul(Lp->vx, Rvx), d_mul(Lp->vy, Rvy));
+                if (!(fabs(dt) < sim_th)) d = ham256_u4(reinterpret_cast<const uint4*>(desc + ((size_t)(2 * pair) * cap + i1) * OLF_DESC_BYTES), dR);
+            }
+        }
+        uint16_t outv = 0xffff;
+        if (best_lr) {
+            int e = d;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(e, o); if (lane >= o) e = min(e, t); }
+            int excl = __shfl_up(e, 1);
+            if (lane == 0) excl = INF;
+            excl = min(excl, running);
+            const bool rec = d != INF && d < excl;
+            if (rec) outv = (uint16_t)d;
+            const unsigned long long rm = __ballot(rec);
+            if (rm) { const int l = 63 - __builtin_clzll(rm); running = __shfl(d, l); who = base + l; }
+        } else if (d != INF) outv = (uint16_t)d;
+        if (i1 < nL) col[(size_t)i1 * cap] = outv;
+    }
+    if (lane == 0) m21[(size_t)pair * cap + i2] = who;
+}
+
 // one wave per left line: best / second best over the considered candidates (the row of the distance matrix is read coalesced, lanes
 // stride over the right lines; first index wins a tie, the second best is the second smallest value of the multiset -- what the
 // reference's sequential scan produces), ratio + mutual test, then the end-point disparities of src/Frame.cc:930-960 on lane 0
@@ -205,8 +257,14 @@ int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, c
 {
     LinePrep* prep = reinterpret_cast<LinePrep*>(d_prep);
     hipLaunchKernelGGL(k_lines_prep, dim3((cap + 63) / 64, 2 * n_pairs), dim3(64), 0, s, d_kls, d_counts, cap, W, H, prep);
-    hipLaunchKernelGGL(k_lines_dist, dim3((cap + 63) / 64, n_pairs), dim3(64), 0, s, prep, d_desc, d_counts, cap, P.matching_s_ws, P.line_sim_th,
-                       P.best_lr_matches, d_dist, d_m21);
+    // OLF_LINES_DIST_W: pairs per call up to which a wave (not a thread) takes a right line
+    static const int wMax = [] { const char* e = getenv("OLF_LINES_DIST_W"); return e ? atoi(e) : 256; }();
+    if (n_pairs <= wMax)
+        hipLaunchKernelGGL(k_lines_dist_w, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, prep, d_desc, d_counts, cap, P.matching_s_ws, P.line_sim_th,
+                           P.best_lr_matches, d_dist, d_m21);
+    else
+        hipLaunchKernelGGL(k_lines_dist, dim3((cap + 63) / 64, n_pairs), dim3(64), 0, s, prep, d_desc, d_counts, cap, P.matching_s_ws, P.line_sim_th,
+                           P.best_lr_matches, d_dist, d_m21);
     hipLaunchKernelGGL(k_lines_resolve, dim3((cap + 3) / 4, n_pairs), dim3(256), 0, s, d_kls, d_counts, cap, d_dist, d_m21, P, d_m12, d_disp, d_le);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;

@@ -1615,7 +1615,6 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         int G = b.forceG > 0 ? b.forceG : lsd_grow_groups(n_images, nw);
         const int pool = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
         while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > 256 || pool / G < E + 64)) G >>= 1;      // (every group of an image has to be resident: one workgroup per CU)
-        if (G == 1 && E > 512) E = 512;                                                                          // (the 1024-entry buffer is the groups' only)
         const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, G, s);
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the

@@ -106,7 +106,7 @@ __device__ __forceinline__ void unlock(int* l, int lane)
 
 // -DOLF_MW_PROF: cycle counters per phase, summed over the waves of image 0 into status[16..] (tools/prof_mw.py)
 #ifdef OLF_MW_PROF
-#define PROF_DECL long long pf_t = __builtin_readcyclecounter(), pf_acc[PF_N] = {0}
+#define PROF_DECL long long pf_t = __builtin_readcyclecounter(), pf_all[2 * PF_N] = {0}; long long* pf_acc = pf_all
 #define PROF(i) do { const long long _t = __builtin_readcyclecounter(); pf_acc[i] += _t - pf_t; pf_t = _t; } while (0)
 #define PROF_CNT(i) (++pf_acc[i])
 #else
@@ -836,6 +836,12 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     PROF_DECL;
     for (;;) {
         MwCtl cv = mw_ctl(c.ctl);
+#ifdef OLF_MW_PROF
+#ifndef OLF_MW_PROF_LATE
+#define OLF_MW_PROF_LATE 40960
+#endif
+        pf_acc = pf_all + (cv.dispNext >= OLF_MW_PROF_LATE ? PF_N : 0);
+#endif
         if (lds_u(c.ctl + C_ABORT)) break;
         mw_commit<MG>(c, cv, MG && cv.head >= cv.tail);
         PROF(PF_COMMIT);
@@ -878,7 +884,11 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     }
 #ifdef OLF_MW_PROF
     if (img == 0 && threadIdx.x == 0) status[250 + grp] = (int)(__builtin_amdgcn_s_memrealtime() - *c.tl0);
-    if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)pf_acc[q]);
+    // (two sets: the whole launch at status[16..], the part behind seed rank OLF_MW_PROF_LATE at status[100..])
+    if (img == 0 && lane == 0) for (int q = 0; q < PF_N; ++q) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(status + 16) + q, (unsigned long long)(pf_all[q] + pf_all[PF_N + q]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(status + 100) + q, (unsigned long long)pf_all[PF_N + q]);
+    }
 #endif
     __syncthreads();
     // growFmt: 0 = this image's regions are chunk chains; -1 = given up (chunk pool or region log exhausted, or the idle guard): nothing of
@@ -938,9 +948,10 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
         static bool done[64] = {};
         int dev = 0;
         OLF_HIP_CHECK(hipGetDevice(&dev));
-        if (lds > 100 * 1024 || G < 2 || dev < 0 || dev >= 64) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
+        if (lds > 100 * 1024 || dev < 0 || dev >= 64) { set_error("launch_lsd_grow_mw: LDS"); return OLF_ERR_INVALID; }
         if (!done[dev]) {
             OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_grow_mw<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_grow_mw<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
             done[dev] = true;
         }
     }

@@ -398,8 +398,10 @@ enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OT
 template <int NW, int NEM, int NI = 1>
 __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_images, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                               const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                              uint32_t* s_buf, uint32_t* s_x, int* ctl, const int* topImg = nullptr)
+                                              uint32_t* s_buf, uint32_t* s_x, int* ctl, const int* topImg = nullptr, int grp = 0, int Gs = 1)
 {
+    // (grp, Gs: NI == 1 behind the grid-wide top levels only -- Gs workgroups share one image: each starts from every Gs-th range the top levels left; the ranges
+    // are disjoint in the key array and in the seed list, so nothing but the seed count is shared)
     static_assert(NI == 1 || NI == NW, "one wave per image of the group");
 #ifdef OLF_SS_PROF
     long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
@@ -430,7 +432,8 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
             Kthr = (uint32_t)(g.nBins - 1 - binT);
         }
     }
-    if (NI == 1 && empty) { if (threadIdx.x == 0) keyCount[img * 32] = 0; return; }
+    if (NI == 1 && empty) { if (threadIdx.x == 0 && grp == 0) keyCount[img * 32] = 0; return; }
+    if (NI == 1 && Gs > 1 && !topImg && grp != 0) return;      // (no ranges to share: the first workgroup sorts the image)
     const int depth0 = depthOverride >= 0 ? depthOverride : 2 * (31 - __builtin_clz((unsigned)n));
     // the ranges still to do (right siblings on the path), one per lane: at most depth0 + 1 <= 43 of them
     int stF = 0, stL = 0, stD = 0;
@@ -452,8 +455,9 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
                 // the top levels have been partitioned by the grid-wide kernels (launch_seedsort_top): start from the ranges they left
                 const int nf = min(topImg[2], SHCAP);
                 const int* f = topImg + 8 + 2 * SS_TOP_JOBS * SS_JW;
-                for (int q = 0; q < nf; ++q) { shF[q] = f[5 * q]; shL[q] = f[5 * q + 1]; shD[q] = f[5 * q + 2]; shLb[q] = f[5 * q + 3]; shUb[q] = f[5 * q + 4]; }
-                ctl[1] = nf;
+                int e = 0;
+                for (int q = grp; q < nf; q += Gs, ++e) { shF[e] = f[5 * q]; shL[e] = f[5 * q + 1]; shD[e] = f[5 * q + 2]; shLb[e] = f[5 * q + 3]; shUb[e] = f[5 * q + 4]; }
+                ctl[1] = e;
             } else { ctl[1] = 1; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
         }
         __syncthreads();
@@ -611,7 +615,7 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
     } else {
         if (lane == 0) atomicMax(&ctl[3], listedEnd);
         __syncthreads();
-        if (threadIdx.x == 0) keyCount[img * 32] = ctl[3];
+        if (threadIdx.x == 0) { if (Gs > 1 && topImg) atomicMax(&keyCount[img * 32], ctl[3]); else keyCount[img * 32] = ctl[3]; }
     }
 }
 
@@ -628,10 +632,11 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
 template <int NW, int NEM, int NI>
 __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                                             const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                                            int n_images, const int* __restrict__ topAll)
+                                                            int n_images, const int* __restrict__ topAll, int Gs)
 {
     extern __shared__ __align__(8) uint32_t s_dyn[];
     constexpr int BUFW = 4 * 64 * NEM, XW = 2 * 64 * NEM;
+    const int blk = NI == 1 ? (int)blockIdx.x / Gs : (int)blockIdx.x, grp = NI == 1 ? (int)blockIdx.x % Gs : 0;
     static_assert(XW >= 4 * 64 * SS_NE_LDS, "the LDS path's queues fit the staging area");
     const int wv = threadIdx.x >> 6;
     // the staging areas first: global_load_lds takes its LDS base from 16 bits of M0, so a staged block must lie in the first 64 KB of the
@@ -640,8 +645,8 @@ __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __r
     uint32_t* s_buf = s_dyn + (size_t)NW * XW + (size_t)wv * BUFW;
     int* ctl = reinterpret_cast<int*>(s_dyn + (size_t)NW * (BUFW + XW));
     static_assert((size_t)NW * XW * 4 <= 65536, "staged blocks within reach of M0");
-    ss_sort_image<NW, NEM, NI>(*gp, blockIdx.x * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl,
-                               NI == 1 && topAll ? topAll + (size_t)blockIdx.x * SS_TOP_WORDS : nullptr);
+    ss_sort_image<NW, NEM, NI>(*gp, blk * NI, n_images, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, ctl,
+                               NI == 1 && topAll ? topAll + (size_t)blk * SS_TOP_WORDS : nullptr, grp, NI == 1 ? Gs : 1);
 }
 
 // the batch in image groups: NI waves, NI images, the one-wave kernel's block size and LDS per wave -- and its six waves per SIMD
@@ -960,8 +965,13 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
     // grid-wide one loses 104 against 73 ms, on a 1080p batch 330 against 102)
     const bool useTop = top && NI == 1 && b.topBuf && n_images <= 64;
     if (useTop) { const int rc = launch_seedsort_top(g, b, n_images, s, nOverride, kthrOverride, depthOverride); if (rc != OLF_OK) return rc; }
-    hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3((n_images + NI - 1) / NI), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
-                       nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (const int*)nullptr);
+    // behind the top levels a few images leave most of the chip idle: Gs workgroups (CUs) per image, each starting from every Gs-th of the ranges the top levels
+    // left (OLF_SS_GROUPS forces 1 .. 8)
+    static const int envG = [] { const char* e = getenv("OLF_SS_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
+    const int Gs = !useTop ? 1 : envG ? envG : n_images <= 4 ? 8 : n_images <= 16 ? 4 : n_images <= 32 ? 2 : 1;
+    if (Gs > 1) OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));      // (the groups' seed counts meet in an atomicMax)
+    hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3(((n_images + NI - 1) / NI) * Gs), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
+                       nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (const int*)nullptr, Gs);
     return OLF_OK;
 }
 

@@ -11,4 +11,4 @@ imgs = synth.stereo_batch(11, 1, 1242, 375)
 for _ in range(3): fe.frames(imgs)
 PY
 rm -rf /tmp/pt; rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/pt -o run -- python /tmp/pair1.py > /tmp/pt.log 2>&1
-python $R/tools/timeline_tail.py /tmp/pt 16 0.08
+python $R/tools/timeline_tail.py /tmp/pt ${1:-14} ${2:-0.02}
