@@ -218,20 +218,14 @@ __device__ __forceinline__ void mw_unsettle(const MwCtx& c, int slot)
 }
 
 // commit DONE / DEAD entries at the head of the ROB, in rank order, up to 64 per call; logs the regions that are large enough.
-// `ctl` is the caller's snapshot (the cheap test whether the head entry can go at all is made on it, without the lock).
-// MG: the call also refreshes this group's view of the other groups (their watermarks, the abort flag, steal notices from their regions) and publishes the
-// group's own watermark; `force` skips the cheap test (empty buffer whose dispatcher has moved on, idle waves waiting for another group).
-template <bool MG>
-__device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool force)
+// `ctl` is the caller's snapshot (the cheap test whether the head entry can go at all is made on it, without the lock).  One workgroup per image.
+__device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv)
 {
-    if (!MG || !force) {
-        if (cv.head >= cv.tail) return;
+    if (cv.head >= cv.tail) return;
+    {
         const int st0 = WG_LOAD(c.eState + (cv.head & c.mask));
         const uint32_t iv0 = WG_LOAD(c.eInval + (cv.head & c.mask));
-        if (MG) {
-            // a head that somebody is growing (or is about to) needs nothing from here; a parked or stolen-from head may be waiting for another group's watermark
-            if (uni(st0) == ST_GROWING || uni(st0) == ST_READY) return;
-        } else if (!(uni(st0) == ST_DEAD || (uni(st0) == ST_DONE && (uint32_t)uni((int)iv0) == MW_FREE))) return;
+        if (!(uni(st0) == ST_DEAD || (uni(st0) == ST_DONE && (uint32_t)uni((int)iv0) == MW_FREE))) return;
     }
     if (!try_lock(c.ctl + C_LOCKCOMMIT, c.lane)) return;
     const MwCtl cl = mw_ctl(c.ctl);
@@ -239,33 +233,10 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool 
     {
         const int i = h + c.lane, slot = i & c.mask;
         const bool in = i < cl.tail;
-        uint32_t omin = (uint32_t)MG_INF, ominNew = (uint32_t)MG_INF, giv = MW_FREE;
-        if (MG) {
-            // one round trip: the other groups' watermarks, the abort flag, the notice words of every entry in the buffer.  The decision below pairs the notice words
-            // read NOW with the watermarks read at the PREVIOUS call (C_OMIN): a thief's notice is performed before its group's watermark passes it.
-            int wmo = MG_INF, ab = 0;
-            if (c.lane < c.G && c.lane != c.grp) wmo = ag_load(c.gctl + MGC_WM + 16 * c.lane);
-            if (c.lane == 0) ab = ag_load(c.gctl + MGC_ABORT);
-            uint32_t* gi = c.gInvalAll + (size_t)c.grp * c.E;
-            if (in) giv = ag_load(gi + slot);
-            for (int k = 64; k < cl.tail - h; k += 64) {
-                const int i2 = i + k, s2 = i2 & c.mask;
-                if (i2 < cl.tail) {
-                    const uint32_t v = ag_load(gi + s2);
-                    if (v != MW_FREE) { __hip_atomic_fetch_min(c.eInval + s2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, s2); }
-                }
-            }
-            if (giv != MW_FREE) { __hip_atomic_fetch_min(c.eInval + slot, giv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, slot); }
-            omin = lds_u(reinterpret_cast<uint32_t*>(c.ctl) + C_OMIN);
-            for (int g2 = 0; g2 < c.G; ++g2) ominNew = min(ominNew, (uint32_t)rlane(wmo, g2));
-            if (uni(ab) && c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1);
-        }
         const int st = in ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
         const uint32_t iv = in ? WG_LOAD(c.eInval + slot) : 0u;
         const int n = in ? WG_LOAD(c.eN + slot) : 0;
-        const uint32_t rk = (MG && in) ? (uint32_t)WG_LOAD(c.eRank + slot) : 0u;
-        // DONE with a steal noted: has to be re-run first.  MG: a finished region is final only when every older seed of the other groups is
-        const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE && (!MG || (giv == MW_FREE && rk < omin)));
+        const bool can = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE);       // DONE with a steal noted: has to be re-run first
         const unsigned long long cm = wave_vote(can);
         const int run = cm == ~0ull ? 64 : __builtin_ctzll(~cm);
         const unsigned long long low = run >= 64 ? ~0ull : ((1ull << run) - 1ull);
@@ -276,14 +247,13 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool 
             big &= big - 1ull;
             const int sl = (h + l) & c.mask;
             const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
-            if (nc < 0) { mw_abort<MG>(c); break; }       // pool or region log exhausted: the image is grown again by the one-wave agent
+            if (nc < 0) { mw_abort<false>(c); break; }       // pool or region log exhausted: the image is grown again by the one-wave agent
             // the first 32 pixels sit in the slot's own chunk, which the next seed in this slot will overwrite: move them to a pool chunk
-            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)(c.cb + sl) * 32 + c.lane);
+            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)sl * 32 + c.lane);
             if (c.lane == 0) {
-                c.links[nc] = AG_LOAD(c.links + c.cb + sl);
+                c.links[nc] = AG_LOAD(c.links + sl);
                 RegionRec rr; rr.start = nc; rr.n = rlane(n, l); rr.angle = c.eAng[sl];
-                if (MG) { c.sRec[nr] = rr; c.sRank[nr] = rlane((int)rk, l); }
-                else c.recs[nr] = rr;
+                c.recs[nr] = rr;
             }
             ++nr;
         }
@@ -292,15 +262,83 @@ __device__ __forceinline__ void mw_commit(const MwCtx& c, const MwCtl& cv, bool 
         // watermark: rank of the oldest unresolved seed.  The dispatcher publishes tail before dispNext and the snapshot `cl` is older than
         // the tail read here, so an empty ROB with a stale dispNext can only give a watermark that is too low, which is safe.
         const int t2 = lds_u(c.ctl + C_TAIL);
-        int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
-        if (MG) {
-            if (wm >= c.nkeys) wm = MG_INF;              // this group has nothing left
-            if (wm != lds_u(c.ctl + C_WML) && c.lane == 0) { ag_store(c.gctl + MGC_WM + 16 * c.grp, wm); WG_STORE(c.ctl + C_WML, wm); }
-            if (c.lane == 0) WG_STORE(c.ctl + C_OMIN, (int)ominNew);
-            wm = min(wm, (int)ominNew);                  // what this group may treat as final: below every group's watermark
-        }
+        const int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
         if (c.lane == 0) { WG_STORE(c.ctl + C_NREG, nr); WG_STORE(c.ctl + C_HEAD, h); WG_STORE(c.ctl + C_WM, wm); }
     }
+    unlock(c.ctl + C_LOCKCOMMIT, c.lane);
+}
+
+// Several workgroups per image: one call = one look at the other groups (their watermarks, the abort flag), every entry at the head of this group's buffer that
+// has become final committed (any number of 64-entry steps), the steal notices of the rest of the buffer swept into LDS, the group's own watermark published.
+// A finished region is final when every older seed of the other groups is (its rank below their watermarks) and nobody stole from it: the notice words are
+// loaded AFTER the watermarks have arrived -- a thief's notice is performed before its group's watermark passes the thief, so a notice cannot arrive behind the
+// commit.  With four or more waves the group's wave 0 does nothing else (k_lsd_grow_mw): the hand-over of the commit order at a window boundary is then two
+// memory round trips behind the other group's publish, not several passes of busy waves through their loop (profiles/r5a_commit_trace.txt: 40-60 us per window).
+__device__ __forceinline__ void mw_commit_mg(const MwCtx& c)
+{
+    if (!try_lock(c.ctl + C_LOCKCOMMIT, c.lane)) return;
+    int wmo = MG_INF, ab = 0;
+    if (c.lane < c.G && c.lane != c.grp) wmo = ag_load(c.gctl + MGC_WM + 16 * c.lane);
+    if (c.lane == 0) ab = ag_load(c.gctl + MGC_ABORT);
+    uint32_t omin = (uint32_t)MG_INF;
+    for (int g2 = 0; g2 < c.G; ++g2) omin = min(omin, (uint32_t)rlane(wmo, g2));
+    if (uni(ab)) { if (c.lane == 0) WG_STORE(c.ctl + C_ABORT, 1); unlock(c.ctl + C_LOCKCOMMIT, c.lane); return; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the notice words below are read behind the watermarks)
+    const MwCtl cl = mw_ctl(c.ctl);
+    int h = cl.head;
+    uint32_t* gi = c.gInvalAll + (size_t)c.grp * c.E;
+    int nr = lds_u(c.ctl + C_NREG);
+    bool stop = false;
+    while (!stop && h < cl.tail) {
+        const int i = h + c.lane, slot = i & c.mask;
+        const bool in = i < cl.tail;
+        const int st = in ? WG_LOAD(c.eState + slot) : (int)ST_EMPTY;
+        const uint32_t iv = in ? WG_LOAD(c.eInval + slot) : 0u;
+        const int n = in ? WG_LOAD(c.eN + slot) : 0;
+        const uint32_t rk = in ? (uint32_t)WG_LOAD(c.eRank + slot) : 0u;
+        const bool pre = st == ST_DEAD || (st == ST_DONE && iv == MW_FREE && rk < omin);
+        const unsigned long long pm = wave_vote(pre);
+        const int run0 = pm == ~0ull ? 64 : __builtin_ctzll(~pm);
+        if (run0 == 0) break;
+        uint32_t giv = MW_FREE;
+        if (c.lane < run0 && st == ST_DONE) giv = ag_load(gi + slot);
+        if (giv != MW_FREE) { __hip_atomic_fetch_min(c.eInval + slot, giv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, slot); }
+        const unsigned long long cm = wave_vote(c.lane < run0 && giv == MW_FREE);
+        const int run = cm == ~0ull ? 64 : __builtin_ctzll(~cm);
+        const unsigned long long low = run >= 64 ? ~0ull : ((1ull << run) - 1ull);
+        unsigned long long big = wave_vote(st == ST_DONE && n >= c.minRegSize) & low;
+        while (big) {
+            const int l = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const int sl = (h + l) & c.mask;
+            const int nc = nr < c.maxRegions ? mw_alloc(c) : -1;
+            if (nc < 0) { mw_abort<true>(c); stop = true; break; }
+            if (c.lane < 32) c.chunks[(size_t)nc * 32 + c.lane] = AG_LOAD(c.chunks + (size_t)(c.cb + sl) * 32 + c.lane);
+            if (c.lane == 0) {
+                c.links[nc] = AG_LOAD(c.links + c.cb + sl);
+                RegionRec rr; rr.start = nc; rr.n = rlane(n, l); rr.angle = c.eAng[sl];
+                c.sRec[nr] = rr; c.sRank[nr] = rlane((int)rk, l);
+            }
+            ++nr;
+        }
+        if (c.lane < run) WG_STORE(c.eState + slot, (int)ST_EMPTY);
+        h += run;
+        if (c.lane == 0) WG_STORE(c.ctl + C_HEAD, h);          // (room for the dispatcher at once)
+        if (run < 64) break;
+    }
+    // the notices of everything still in the buffer (regions that are told early give their claims up early)
+    for (int i2 = h + c.lane; i2 < cl.tail; i2 += 64) {
+        const int s2 = i2 & c.mask;
+        const uint32_t v = ag_load(gi + s2);
+        if (v != MW_FREE && v < WG_LOAD(c.eInval + s2)) { __hip_atomic_fetch_min(c.eInval + s2, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mw_unsettle(c, s2); }
+    }
+    // watermark of the group: rank of its oldest unresolved seed (see mw_commit for the order of the reads); what the group may treat as final lies below
+    // every group's watermark
+    const int t2 = lds_u(c.ctl + C_TAIL);
+    int wm = h < t2 ? lds_u(c.eRank + (h & c.mask)) : cl.dispNext;
+    if (wm >= c.nkeys) wm = MG_INF;              // this group has nothing left
+    if (wm != lds_u(c.ctl + C_WML) && c.lane == 0) { ag_store(c.gctl + MGC_WM + 16 * c.grp, wm); WG_STORE(c.ctl + C_WML, wm); }
+    if (c.lane == 0) { WG_STORE(c.ctl + C_OMIN, (int)omin); WG_STORE(c.ctl + C_NREG, nr); WG_STORE(c.ctl + C_WM, min(wm, (int)omin)); }
     unlock(c.ctl + C_LOCKCOMMIT, c.lane);
 }
 
@@ -765,7 +803,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
                                                       const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt,
-                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images, int wsBits)
+                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images, int wsBits, int ahead)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -832,6 +870,8 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     }
     __syncthreads();
     const double prec = g.prec, precWrap = g.precWrap;
+    const bool dedicated = MG && nw >= 4 && !(ahead & 0x10000);        // wave 0 of the group commits and publishes, the others grow (bit 16 of `ahead`: OLF_MW_NO_COMMIT_WAVE, A/B)
+    ahead &= 0xffff;
     int idle = 0;
     PROF_DECL;
     for (;;) {
@@ -843,11 +883,20 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         pf_acc = pf_all + (cv.dispNext >= OLF_MW_PROF_LATE ? PF_N : 0);
 #endif
         if (lds_u(c.ctl + C_ABORT)) break;
-        mw_commit<MG>(c, cv, MG && cv.head >= cv.tail);
+        if (MG && dedicated && wv == 0) {
+            // the group's commit wave: nothing but the hand-over of the commit order
+            if (cv.dispNext >= c.nkeys && cv.head == cv.tail) { const MwCtl c2 = mw_ctl(c.ctl); if (c2.dispNext >= c.nkeys && c2.head == c2.tail) break; }
+            mw_commit_mg(c);
+            PROF(PF_COMMIT);
+            __builtin_amdgcn_s_sleep(1);
+            if (++idle > (1 << 22)) { if (lane == 0) atomicOr(status, 16); mw_abort<MG>(c); break; }
+            continue;
+        }
+        if (!MG) mw_commit(c, cv); else if (!dedicated) mw_commit_mg(c);
         PROF(PF_COMMIT);
         // supply ahead of demand: any wave tops the reorder buffer up BEFORE it looks for a region whenever the buffer is less than half full, so that the waves do
         // not run dry together and spin through commit / pick / dispatch while one of them waits for the dispatcher's loads (profiles/r4zz_mw_dispatch_ahead_ab.txt)
-        if (nw > 1 && cv.dispNext < c.nkeys && cv.tail - cv.head < (E >> 1) && lds_u(c.ctl + C_LOCKDISP) == 0) {
+        if (nw > 1 && cv.dispNext < c.nkeys && cv.tail - cv.head < ahead && lds_u(c.ctl + C_LOCKDISP) == 0) {
             if (mw_dispatch<MG>(c, cv, angDeg, ent)) cv = mw_ctl(c.ctl);
             PROF(PF_DISPATCH);
         }
@@ -864,7 +913,6 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
             const MwCtl c2 = mw_ctl(c.ctl);
             if (c2.dispNext >= c.nkeys && c2.head == c2.tail) break;
         }
-        if (MG) mw_commit<MG>(c, cv, true);      // waiting for another group: look at its watermark again
         __builtin_amdgcn_s_sleep(8);
         PROF(PF_IDLE);
         if (++idle > (MG ? (1 << 18) : (1 << 21))) {
@@ -956,6 +1004,10 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
         }
     }
     const int poolLimit = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
+    // entries in the buffer below which any wave tops it up before it looks for a region (OLF_MW_AHEAD for A/B runs)
+    static const int envAhead = [] { const char* e = getenv("OLF_MW_AHEAD"); return e ? atoi(e) : 0; }();
+    static const int noCw = getenv("OLF_MW_NO_COMMIT_WAVE") ? 0x10000 : 0;
+    const int ahead = (envAhead > 0 ? std::min(envAhead, E - 64) : E / 2) | noCw;
     if (G > 1) {
         // OLF_LSD_WS: log2 of the seed window the groups are dealt (6 .. 10), for A/B runs
         static const int envWs = [] { const char* e = getenv("OLF_LSD_WS"); const int v = e ? atoi(e) : 0; return (v >= 6 && v <= 10) ? v : 0; }();
@@ -966,12 +1018,12 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
         const int blocks = ((n_images + 7) / 8) * 8 * G;
         hipLaunchKernelGGL(k_lsd_grow_mw<true>, dim3(blocks), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images, wsBits);
+                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images, wsBits, ahead);
         hipLaunchKernelGGL(k_mg_merge, dim3(n_images), dim3(256), 0, s, b.geom, b.mg, b.mgStride, G, reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.growFmt);
     } else
         hipLaunchKernelGGL(k_lsd_grow_mw<false>, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images, 10);
+                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images, 10, ahead);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }
