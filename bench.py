@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group bring-up, batch-size agreement, pack, size exchange, gather, per-rank timing) "
                     "even with one rank: on a 1-GPU box this is the only way the RCCL backend itself executes (no peer, so no point-to-point transfer)")
     ap.add_argument("--verify", action="store_true", help="N>1: rank 0 recomputes every rank's records of the last step and byte-compares them with what it received")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="N>1: weak = every rank runs the configuration's batch (the driver's contract, value ~ N x); "
+                    "strong = the configuration's batch is the whole job and is split over the ranks (fixed total work: value / value(N=1) / N is the scaling efficiency)")
+    ap.add_argument("--camera-rgb", type=int, default=1, choices=(0, 1), help="--images with colour files: the yaml's Camera.RGB (src/Tracking.cc:193-218; 1 in every KITTI / EuRoC "
+                    "configuration of the reference: CV_RGB2GRAY applied to imread's BGR data)")
     ap.add_argument("--images", default=None, help="recorded stereo sequence instead of synthetic input: a KITTI sequence directory (times.txt, image_0, image_1 -- "
                     "Examples/PL/PL_stereo_kitti.cc LoadImages), a EuRoC mav0 directory or any directory with left / right image folders (orb_line_slam_amd/sequence.py); "
                     "the image size comes from the files, the feature counts from --config; fewer pairs than the batch are tiled")
@@ -291,10 +295,14 @@ def main():
     seq = None
     if args.images:
         from orb_line_slam_amd.sequence import StereoSequence
-        seq = StereoSequence(args.images, limit=args.pairs or cfg["pairs"])
+        seq = StereoSequence(args.images, limit=args.pairs or cfg["pairs"], camera_rgb=bool(args.camera_rgb))
         W, H = seq.width, seq.height
     B = args.pairs or cfg["pairs"]
-    # the batch lives in HBM (context buffers + outputs, about 62 MB per KITTI pair): shrink it if this GPU has less free memory than the
+    if args.scaling == "strong" and world > 1:
+        # strong scaling: the configuration's batch is the WHOLE job, split over the ranks (shard_range's contiguous blocks, every rank the same size so that the
+        # context capacity is one number); value = that fixed total / max-over-ranks time, so N GPUs can show an efficiency below 1
+        B = max(64, (B + world - 1) // world)
+    # the batch lives in HBM (context buffers + outputs, 58 MB of context per KITTI pair, tools/mem_per_pair.py, plus the outputs): shrink it if this GPU has less free memory than the
     # batch needs, and use the same size on every rank
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     per_pair = 62e6 * (W * H) / (1242 * 375) * (1.15 if multi else 1.0)     # + packed records (double buffered) when they are gathered
@@ -317,19 +325,20 @@ def main():
     # synthetic input: `distinct` seeded pairs per rank, tiled to B pairs, resident in HBM before timing
     nd = min(args.distinct, B)
 
-    def make_input(r):
+    def make_input(r, run_len=None):
+        run_len = args.sequence if run_len is None else run_len
         if seq is not None:
             # every rank reads its own contiguous share of the recording (frame-sharded like SURVEY 8(e)), tiled to B pairs when it is shorter
             from orb_line_slam_amd.distributed import shard_range
             lo, hi = shard_range(len(seq), r, world)
-            sub_seq = StereoSequence(left=seq.left[lo:hi] or seq.left[:1], right=seq.right[lo:hi] or seq.right[:1])
+            sub_seq = StereoSequence(left=seq.left[lo:hi] or seq.left[:1], right=seq.right[lo:hi] or seq.right[:1], camera_rgb=bool(args.camera_rgb))
             host = np.concatenate([b for b, _ in sub_seq.batches(B)]).reshape(-1, 2, H, W)
             reps = (B + len(host) - 1) // len(host)
             return torch.from_numpy(np.tile(host, (reps, 1, 1, 1))[:B].reshape(2 * B, H, W).copy()).to(dev)
         host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=args.scene)
-        if args.sequence > 1:
+        if run_len > 1:
             # runs of consecutive frames: frame k of run j = scene j (both images) shifted by 2k pixels -- related frames for the frame-to-frame matchers
-            R = args.sequence
+            R = run_len
             out_h = np.empty((2 * B, H, W), np.uint8)
             for i in range(B):
                 j, k = (i // R) % nd, i % R
@@ -344,8 +353,6 @@ def main():
     imgs = make_input(rank)
     # the inputs are resident before the timed region starts: their "ready" event lets the line stream of a step start beside the previous step's tail
     in_ev = torch.cuda.Event(); in_ev.record(); torch.cuda.synchronize()
-    if args.pipeline:
-        ctx.set_input_event(in_ev)
     if not args.no_deferred_join:
         check(lib().olf_ctx_set_deferred_join(ctx.handle, 1), "olf_ctx_set_deferred_join")
 
@@ -372,6 +379,8 @@ def main():
 
     def step(images):
         s = torch.cuda.current_stream().cuda_stream
+        if args.pipeline:
+            ctx.set_input_event(in_ev)      # (one-shot: every call consumes its input event)
         check(Lh.olf_stereo_frames_dev(ctx.handle, images.data_ptr(), B, C.byref(fb), s), "olf_stereo_frames_dev")
         if B > 1 and voc is not None and not args.no_deferred_join:
             # the tracker's order (src/Tracking.cc:963-970, then :1296-1308): the point features' matcher first -- it needs nothing of the line path, whose tail
@@ -482,6 +491,24 @@ def main():
         alone = {k: v[0] / 2 for k, v in ctx.profile_read().items() if v[1]}
         ctx.profile(False)
 
+    # the companion line: the same step on runs of six consecutive frames of one scene, so that the frame-to-frame matchers (SearchByBoW, LBD match) meet related
+    # frames as they do on a recording -- SURVEY 8(d)'s generator (independent scenes) is the headline, this is what it leaves out
+    companion = None
+    if rank == 0 and world == 1 and not args.no_extras and seq is None and args.sequence == 0 and B > 1:
+        keep = imgs
+        imgs = make_input(rank, 6)
+        run_steps(1); barrier()
+        tq = time.perf_counter()
+        run_steps(3); barrier()
+        dq = (time.perf_counter() - tq) / 3
+        ctx.synchronize()
+        companion = {"workload": "runs of 6 consecutive frames per scene (bench.py --sequence 6)", "steps": 3, "ms_per_step": round(dq * 1e3, 3), "value": round(B / dq, 1),
+                     "unit": "stereo frames/s"}
+        if voc is not None:
+            companion["search_by_bow_mean_matches"] = round(float(f2f_n[:B - 1].float().mean().item()), 1)
+        imgs = keep
+        run_steps(1); barrier()             # (the outputs the checks below read belong to the headline input again)
+
     verify = None
     if gather_on and args.verify:
         # rank 0 runs every other rank's input itself and compares the record it received in the last step, byte for byte
@@ -558,7 +585,7 @@ def main():
         out = {
             "metric": f"stereo frames/s extract+match (ORB+LBD), {'KITTI ' if args.config == 'C3' else ''}{W}x{H}", "value": round(fps, 2), "unit": "stereo frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": ("recorded: " + os.path.basename(os.path.normpath(args.images))) if seq is not None else "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": ("recorded: " + os.path.basename(os.path.normpath(args.images))) if seq is not None else "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H} stereo, {cfg['nf']} ORB + {cfg['nl']} LBD per image, extract + stereo point/line match + "
                                    f"f2f LBD match + " + ("SearchByBoW vs the previous frame (synthetic k=10 L=6 vocabulary, ComputeBoW included)" if voc is not None else "f2f dense ORB kNN match"), "pairs_per_gpu_per_step": B, "parallelism": f"frame-sharded x{world}",
                        "distinct_pairs": (len(seq) if seq is not None else nd), "order": ("recorded" if seq is not None else f"runs of {args.sequence}" if args.sequence > 1 else args.order), "scene": args.scene, "mean_keypoints_per_image": round(nk, 1), "mean_keylines_per_image": round(nkl, 1),
@@ -598,6 +625,8 @@ def main():
             except Exception as e:
                 out["roofline"]["copy_kernel_GBps"] = None
                 print(f"copy ceiling failed: {e}", file=sys.stderr)
+    if rank == 0 and out is not None and companion is not None:
+        out["companion_sequence6"] = companion
     if rank == 0 and out is not None and voc is not None:
         out["config"]["search_by_bow_mean_matches"] = round(float(f2f_n[:B - 1].float().mean().item()), 1)
     del imgs, kps, desc, ur, dp, kls, ldesc, lm, ldisp, lle, f2f_lines, f2f_orb

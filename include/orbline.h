@@ -52,7 +52,8 @@ int  olf_ctx_synchronize(olf_ctx* ctx);
  * caller records on whichever stream produces d_images, before the call; NULL = default) the line stream waits for that event only, and the
  * LSD front of batch k + 1 runs beside the tail of batch k.  The context's buffers allow it: the LSD front writes line-path scratch only, and
  * everything of batch k + 1 that touches the output buffers or the shared LBD planes is ordered behind batch k's work on `stream` (api.cpp,
- * olf_stereo_frames_dev).  The caller still orders `stream` itself behind the production of d_images. */
+ * olf_stereo_frames_dev).  The caller still orders `stream` itself behind the production of d_images.  The event is ONE-SHOT: the next
+ * olf_stereo_frames_dev consumes it (set it again before every call that should use one); the host entry olf_stereo_frames ignores and clears it. */
 int  olf_ctx_set_input_event(olf_ctx* ctx, void* hip_event);
 /* Deferred join for olf_stereo_frames_dev.  By default the call ends with `stream` waiting for the line stream: every output is complete on `stream`.  The
  * reference's tracker consumes the point features first (TrackReferenceKeyFrame: ComputeBoW + SearchByBoW, src/Tracking.cc:963-970) and the line features after

@@ -55,6 +55,8 @@ struct olf_ctx {
     hipEvent_t ev_lbd = nullptr;       // fused entry: the LBD gradient images are ready (computed on the ORB stream in the seed ordering's shadow)
     bool deferred_join = false;        // olf_ctx_set_deferred_join: olf_stereo_frames_dev returns with the line path still running on the line stream
     bool join_pending = false;         // ... and this call's line path has not been joined yet (olf_stereo_frames_join_dev, or the next call)
+    const uint8_t* pend_ldesc = nullptr; size_t pend_ldesc_bytes = 0;       // the line descriptors / counts that call is still writing: an entry that is handed
+    const int32_t* pend_lcounts = nullptr; size_t pend_lcounts_n = 0;       // them (matcher, packer) joins first
     bool defer_lbd = false;            // fused entry: olf_line_extract_dev stops behind the rectangles; selection + LBD are enqueued by the caller
     bool lbd_pre = false;              // fused entry: olf_orb_extract_dev computes the LBD gradient images behind its blur and records ev_lbd
     hipEvent_t ev_sort = nullptr;      // recorded in front of the seed ordering (the dense, bandwidth-bound half of the LSD front is through)
@@ -328,11 +330,27 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
 
 static int check_status(olf_ctx* c);
 
+// a deferred join that the caller has not asked for yet, in front of an entry that reads what the line stream is still writing
+static int join_if_pending(olf_ctx* c, hipStream_t s)
+{
+    if (!c->join_pending) return OLF_OK;
+    OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    c->join_pending = false;
+    return OLF_OK;
+}
+static bool in_pending_line_outputs(const olf_ctx* c, const void* p)
+{
+    const uint8_t* q = static_cast<const uint8_t*>(p);
+    return c->join_pending && ((c->pend_ldesc && q >= c->pend_ldesc && q < c->pend_ldesc + c->pend_ldesc_bytes) ||
+                               (c->pend_lcounts && q >= reinterpret_cast<const uint8_t*>(c->pend_lcounts) && q < reinterpret_cast<const uint8_t*>(c->pend_lcounts + c->pend_lcounts_n)));
+}
+
 int olf_ctx_synchronize(olf_ctx* c)
 {
     if (!c) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
     OLF_HIP_CHECK(hipStreamSynchronize(c->stream2));
+    c->join_pending = false;            // (both streams are idle: nothing is left to wait for)
     return check_status(c);
 }
 
@@ -517,6 +535,7 @@ int olf_frames_pack_dev(olf_ctx* c, const olf_frame_buffers* fb, int n_pairs, ui
         set_error("olf_frames_pack_dev: bad argument"); return OLF_ERR_INVALID;
     }
     OLF_TRY(check_device(c, "olf_frames_pack_dev"));
+    OLF_TRY(join_if_pending(c, stream ? (hipStream_t)stream : c->stream));      // (the packer reads every output of the frame call, the line path's too)
     void* ofs = nullptr;
     OLF_TRY(scratch_get(c, 3, (size_t)8 * n_pairs * sizeof(int) + 64, &ofs));
     return olf::launch_pack_records(*fb, n_pairs, c->orb.geom.outCap, c->line.geom.outCap, d_dst, dst_capacity, static_cast<int*>(ofs),
@@ -712,6 +731,8 @@ int olf_match_bf_dev(olf_ctx* c, const uint8_t* dA, const int32_t* nA, int strid
     OLF_TRY(check_device(c, "olf_match_bf_dev"));
     if (n_sets == 0 || strideA == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // line descriptors / counts of a frame call whose line path is still running (deferred join): wait for it; ORB descriptors go ahead
+    if (in_pending_line_outputs(c, dA) || in_pending_line_outputs(c, dB) || in_pending_line_outputs(c, nA) || in_pending_line_outputs(c, nB)) OLF_TRY(join_if_pending(c, s));
     void* ws = nullptr;
     OLF_TRY(scratch_get(c, 0, (size_t)3 * (strideA + strideB) * n_sets * sizeof(int), &ws));
     StageScope t(c, s, ST_MATCH_BF);
@@ -1065,7 +1086,10 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     // matching tail of the previous batch -- and the LSD front of this batch runs beside it.  Safe with lbd_pre only: the LSD front, growth and rectangles
     // write line-path scratch that nothing on `s` reads, and selection / LBD / line stereo (which write the output buffers the previous batch's matchers
     // and packer on `s` may still read) sit behind ev_lbd, recorded on `s` behind all of the previous batch's work there.
-    if (c->input_event && lbd_pre) OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->input_event, 0));
+    // (the event is consumed by the call: one-shot -- a stale handle must never order a later call)
+    hipEvent_t in_ev = c->input_event;
+    c->input_event = nullptr;
+    if (in_ev && lbd_pre) OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, in_ev, 0));
     else {
         OLF_HIP_CHECK(hipEventRecord(c->ev_fork, s));
         OLF_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -1096,8 +1120,11 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     // the join.  Deferred (olf_ctx_set_deferred_join): the caller's stream goes on with the ORB outputs -- key points, descriptors, stereo points are complete on
     // it here -- while the line path's tail (selection, LBD, line stereo: 20 ms of a 3072-pair batch) still runs on the line stream; olf_stereo_frames_join_dev
     // (or the next call) makes the stream wait for it
-    if (c->deferred_join) c->join_pending = true;
-    else OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
+    if (c->deferred_join) {
+        c->join_pending = true;
+        c->pend_ldesc = o->ldesc; c->pend_ldesc_bytes = (size_t)n_images * c->line.geom.outCap * OLF_DESC_BYTES;
+        c->pend_lcounts = o->lcounts; c->pend_lcounts_n = (size_t)n_images;
+    } else OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     return OLF_OK;
 }
 
@@ -1126,6 +1153,7 @@ int olf_stereo_frames(olf_ctx* c, const uint8_t* images, int n_pairs, const olf_
     olf_frame_buffers d;
     d.kps = c->d_kps; d.desc = c->d_desc; d.counts = c->d_counts; d.uright = c->d_uright; d.depth = c->d_depth;
     d.kls = c->d_kls; d.ldesc = c->d_ldesc; d.lcounts = c->d_lcounts; d.lmatches12 = c->d_lm12; d.ldisp = c->d_ldisp; d.lle = c->d_lle;
+    c->input_event = nullptr;           // (the upload below is on the context's stream: the line stream must fork from it, whatever event an earlier caller left)
     OLF_HIP_CHECK(hipMemcpyAsync(c->d_images, images, npx * ni, hipMemcpyHostToDevice, c->stream));
     OLF_TRY(olf_stereo_frames_dev(c, c->d_images, n_pairs, &d, c->stream));
     OLF_TRY(olf_stereo_frames_join_dev(c, c->stream));      // (a context with the deferred join on: the copies below read the line outputs)

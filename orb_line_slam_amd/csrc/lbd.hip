@@ -18,7 +18,7 @@ __constant__ int8_t c_bandPairs[64] = {
 };
 
 // ---------------------------------------------------------------------------------------------
-constexpr int LS_LDS_KEYS = 8192;      // raw segments whose sort keys fit the 64 KB of LDS a launch may ask for without a function attribute
+constexpr int LS_LDS_KEYS = 4096;      // raw segments sorted in LDS (32 KB: two blocks per CU on the line tail; a KITTI image has a few hundred); longer lists are sorted in the key buffer
 
 // bitonic sort of sortN 64-bit keys, descending, by one 256-thread workgroup; `sk` in LDS or -- a list too long for it (noise images, lsd_scale 2) --
 // in a per-image slice of global memory (all waves of a workgroup share their CU's L1, so a barrier orders their global accesses too)

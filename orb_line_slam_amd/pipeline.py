@@ -190,7 +190,8 @@ def pcie_inclusive_rate(params, width, height, pairs=1024, batches=10, producer=
     pipe.ctx.close()
     gaps = np.diff(np.array(stamps))[: max(len(stamps) - 2, 1)] if len(stamps) > 2 else np.array([dt / max(batches, 1)])      # (the last gap is the drain)
     steady = pairs / float(np.median(gaps))
+    # (`value` has been the steady-state rate since round 4 -- rounds 1-3 reported the whole run under that key; both are spelled out so that rounds compare like with like)
     return {"value": round(steady, 1), "unit": "stereo frames/s", "pairs_per_batch": pairs, "batches": batches, "producer": producer,
-            "whole_run": round(n / dt, 1), "batch_interval_ms": {"median": round(float(np.median(gaps)) * 1e3, 2), "max": round(float(gaps.max()) * 1e3, 2)},
+            "steady_state": round(steady, 1), "whole_run": round(n / dt, 1), "value_is": "steady_state", "batch_interval_ms": {"median": round(float(np.median(gaps)) * 1e3, 2), "max": round(float(gaps.max()) * 1e3, 2)},
             "note": "host images in, host results out, upload / path / download overlapped on three streams; value = steady state (median interval between "
                     "batch completions), whole_run includes the pipeline's fill and drain"}

@@ -5,8 +5,8 @@ build -- KITTI odometry layout, `LoadImages` of Examples/PL/PL_stereo_kitti.cc:1
 `OfflinePipeline.run` / `bench.py --images` take (left image of pair p at 2p, right at 2p + 1, as everywhere in this package).
 
 Decoding is host work (PIL: PNG, PGM, JPEG ...).  8-bit grey files are passed through unchanged, which is what `cv::imread(..., CV_LOAD_IMAGE_UNCHANGED)`
-hands to `System::TrackStereo`; colour files are converted with this package's own `cvtColor` (`precond.cvtColor`, bit-exact with the
-reference's `Tracking::GrabImageStereo`, src/Tracking.cc:193-218), never with PIL's luma formula, whose rounding differs.
+hands to `System::TrackStereo`; colour files are handed over in imread's B, G, R order and converted by this package's own `cvtColor` with the code
+`Tracking::GrabImageStereo` (src/Tracking.cc:193-218) picks from `Camera.RGB` -- see `read_gray` -- never with PIL's luma formula, whose rounding differs.
 """
 import os
 import numpy as np
@@ -64,24 +64,34 @@ def find_sequence(path):
     raise FileNotFoundError(f"{path}: neither a KITTI sequence (times.txt, image_0, image_1) nor a directory with left / right image folders")
 
 
-def read_gray(path, context=None):
-    """One image file as an (H, W) uint8 array.  Grey files unchanged; colour files through cvtColor(RGB2GRAY) of this package (needs the GPU)."""
+def read_gray(path, camera_rgb=True, context=None):
+    """One image file as the (H, W) uint8 image the reference's tracker works on (src/Tracking.cc:193-218).  Grey files pass unchanged.  A colour file is what
+    `cv::imread(..., CV_LOAD_IMAGE_UNCHANGED)` delivers -- channels in B, G, R(, A) order -- put through `cvtColor` with the code `Tracking::GrabImageStereo`
+    picks from `Camera.RGB` (`camera_rgb`): CV_RGB2GRAY / CV_RGBA2GRAY when it is 1 -- which every KITTI / EuRoC yaml of the reference sets
+    (Examples/PL/PL_KITTI00-02.yaml:32), so the reference weighs imread's BLUE channel with 0.299 and its RED channel with 0.114 -- and CV_BGR2GRAY / CV_BGRA2GRAY
+    when it is 0.  The conversion is this package's own kernel (`precond.cvtColor`: needs the GPU), never PIL's luma formula, whose rounding differs."""
     from PIL import Image
     with Image.open(path) as im:
         if im.mode == "L":
             return np.asarray(im, dtype=np.uint8)
         if im.mode in ("I;16", "I;16B", "I;16L", "I", "F"):
             raise ValueError(f"{path}: 16-bit / float images are not a supported input (the reference's pipeline is 8-bit)")
-        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
-    from .precond import cvtColor, RGB2GRAY
-    return cvtColor(rgb[None], RGB2GRAY, context=context)[0]
+        alpha = im.mode in ("RGBA", "LA", "PA") or (im.mode == "P" and "transparency" in im.info)
+        px = np.asarray(im.convert("RGBA" if alpha else "RGB"), dtype=np.uint8)
+    from .precond import cvtColor, RGB2GRAY, BGR2GRAY, RGBA2GRAY, BGRA2GRAY
+    # imread's channel order: B, G, R (, A)
+    bgr = np.ascontiguousarray(np.concatenate([px[..., 2::-1], px[..., 3:]], axis=-1))
+    code = (RGBA2GRAY if camera_rgb else BGRA2GRAY) if alpha else (RGB2GRAY if camera_rgb else BGR2GRAY)
+    return cvtColor(bgr[None], code, context=context)[0]
 
 
 class StereoSequence:
     """Batches of a recorded stereo sequence: `for batch, times in StereoSequence(path).batches(pairs)` yields (2 * n, H, W) uint8 arrays, n <= pairs.
     `out` = a function i -> writable (2 * pairs, H, W) array (e.g. OfflinePipeline.input_buffer) decodes straight into pinned staging memory."""
 
-    def __init__(self, path=None, left=None, right=None, times=None, limit=None):
+    def __init__(self, path=None, left=None, right=None, times=None, limit=None, camera_rgb=True):
+        # camera_rgb: the yaml's Camera.RGB (1 in every KITTI / EuRoC configuration of the reference); only matters for colour files (read_gray)
+        self.camera_rgb = bool(camera_rgb)
         if path is not None:
             left, right, times = find_sequence(path)
         if left is None or right is None or len(left) != len(right):
@@ -90,7 +100,7 @@ class StereoSequence:
             left, right, times = left[:limit], right[:limit], (times[:limit] if times is not None else None)
         self.left, self.right = list(left), list(right)
         self.times = list(times) if times is not None else [float(i) for i in range(len(self.left))]
-        first = read_gray(self.left[0])
+        first = read_gray(self.left[0], self.camera_rgb)
         self.height, self.width = first.shape
 
     def __len__(self):
@@ -102,7 +112,7 @@ class StereoSequence:
             buf = out(b) if out is not None else np.empty((2 * pairs, self.height, self.width), np.uint8)
             for k in range(n):
                 for side, files in ((0, self.left), (1, self.right)):
-                    img = read_gray(files[start + k])
+                    img = read_gray(files[start + k], self.camera_rgb)
                     if img.shape != (self.height, self.width):
                         raise ValueError(f"{files[start + k]}: {img.shape[1]}x{img.shape[0]}, the sequence started with {self.width}x{self.height}")
                     buf[2 * k + side] = img

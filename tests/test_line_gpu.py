@@ -544,3 +544,60 @@ def test_deferred_join(oracle):
     assert ref[0][2].sum() > 1000 * n and ref[0][7].sum() > 100 * n
     chk(lib().olf_ctx_set_deferred_join(ctx.handle, 0), "olf_ctx_set_deferred_join")
     ctx.close()
+
+
+def test_stale_input_event_and_unjoined_readers(oracle):
+    """ADVICE r4.  (a) olf_ctx_set_input_event is one-shot and the host entry olf_stereo_frames ignores it: with an event left behind by an earlier caller the line
+    stream used to wait for that (long signalled) event only and could read c->d_images before the upload queued on the context's stream had landed.  (b) With the
+    deferred join on, olf_frames_pack_dev and olf_match_bf_dev on the line descriptors join by themselves instead of reading what the line stream is still writing."""
+    import ctypes as C
+    import torch
+    from orb_line_slam_amd import _lib
+    from orb_line_slam_amd._lib import FrameBuffers, check as chk, lib
+    w, h, n = 1242, 375, 48
+    p = oracle.full_params(2000, 500, 718.856, 386.1448)
+    dev = torch.device("cuda", 0)
+    host = [np.tile(synth.stereo_batch(9100 + 10 * k, 4, w, h), (n // 4, 1, 1)) for k in range(2)]
+    # (a) the host entry with a stale event set: results of alternating inputs must equal those of a clean context
+    fe = ola.StereoFrontEnd(p, w, h, max_pairs=n)
+    clean = [fe.frames(host[k]) for k in (0, 1)]
+    ev = torch.cuda.Event(); ev.record(); torch.cuda.synchronize()
+    for k in (1, 0, 1):
+        fe.ctx.set_input_event(ev)                       # signalled long ago; the caller then forgets about it
+        f = fe.frames(host[k])
+        assert np.array_equal(f.N_l, clean[k].N_l) and f.mvKeys_Line.tobytes() == clean[k].mvKeys_Line.tobytes(), k
+        assert f.mDescriptors_Line.tobytes() == clean[k].mDescriptors_Line.tobytes() and f.line_matches_12.tobytes() == clean[k].line_matches_12.tobytes(), k
+    # (b) deferred join, then the packer / the line matcher without olf_stereo_frames_join_dev
+    ctx = _lib.Context(p, w, h, 2 * n)
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    spec = [((2 * n, cap, 28), torch.uint8), ((2 * n, cap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, cap), torch.float32), ((n, cap), torch.float32),
+            ((2 * n, lcap, 68), torch.uint8), ((2 * n, lcap, 32), torch.uint8), ((2 * n,), torch.int32), ((n, lcap), torch.int32), ((n, lcap, 2), torch.float32),
+            ((n, lcap, 3), torch.float64)]
+    out = [torch.zeros(sh, dtype=dt, device=dev) for sh, dt in spec]
+    fb = FrameBuffers(*[t.data_ptr() for t in out])
+    bound = lib().olf_frames_pack_bound(ctx.handle, n)
+    packed = torch.zeros(bound, dtype=torch.uint8, device=dev); nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    m12 = torch.zeros((n - 1, 2 * lcap), dtype=torch.int32, device=dev)
+    imgs = torch.from_numpy(host[0]).to(dev)
+    st = torch.cuda.Stream(dev)
+    res = {}
+    for deferred in (0, 1):
+        torch.cuda.synchronize()
+        chk(lib().olf_ctx_set_deferred_join(ctx.handle, deferred), "olf_ctx_set_deferred_join")
+        with torch.cuda.stream(st):
+            for t in out + [packed, m12]:
+                t.zero_()
+            chk(lib().olf_stereo_frames_dev(ctx.handle, imgs.data_ptr(), n, C.byref(fb), st.cuda_stream), "olf_stereo_frames_dev")
+            chk(lib().olf_match_bf_dev(ctx.handle, out[6].data_ptr() + 2 * lcap * 32, out[7].data_ptr() + 8, 2 * lcap, 2, out[6].data_ptr(), out[7].data_ptr(),
+                                       2 * lcap, 2, n - 1, 0.75, 1, m12.data_ptr(), st.cuda_stream), "olf_match_bf_dev")
+            a = m12.clone()
+        torch.cuda.synchronize(); ctx.synchronize()
+        with torch.cuda.stream(st):
+            chk(lib().olf_stereo_frames_dev(ctx.handle, imgs.data_ptr(), n, C.byref(fb), st.cuda_stream), "olf_stereo_frames_dev")
+            chk(lib().olf_frames_pack_dev(ctx.handle, C.byref(fb), n, packed.data_ptr(), bound, nbytes.data_ptr(), st.cuda_stream), "olf_frames_pack_dev")
+            b = packed.clone()
+        torch.cuda.synchronize(); ctx.synchronize()
+        res[deferred] = (a.cpu().numpy().tobytes(), b.cpu().numpy().tobytes(), int(nbytes.item()))
+    assert res[0] == res[1] and res[0][2] > 0
+    chk(lib().olf_ctx_set_deferred_join(ctx.handle, 0), "olf_ctx_set_deferred_join")
+    ctx.close()

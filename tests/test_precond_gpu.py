@@ -64,3 +64,34 @@ def test_init_undistort_rectify_map_euroc(oracle):
         m1, m2 = precond.initUndistortRectifyMap(K, D, R, P, (320, 240))
         o1, o2 = oracle.init_undistort_rectify_map(K, D, R, P, 320, 240)
         assert np.array_equal(m1.view(np.uint32), o1.view(np.uint32)) and np.array_equal(m2.view(np.uint32), o2.view(np.uint32))
+
+
+def test_colour_files_follow_camera_rgb(oracle, tmp_path):
+    """Colour recordings as the reference's tracker sees them (src/Tracking.cc:193-218): cv::imread delivers B, G, R; Camera.RGB = 1 -- every KITTI / EuRoC yaml --
+    applies CV_RGB2GRAY to that, i.e. 0.299 B + 0.587 G + 0.114 R; Camera.RGB = 0 applies CV_BGR2GRAY.  A synthetic colour PNG pair (and an RGBA one) in both
+    settings against the oracle's cvtColor on the BGR(A)-ordered pixels; grey files pass unchanged."""
+    from PIL import Image
+    from orb_line_slam_amd import sequence
+    rng = np.random.default_rng(3)
+    h, w = 240, 320
+    l, r = tmp_path / "left", tmp_path / "right"
+    l.mkdir(); r.mkdir()
+    rgb = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2)]
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    Image.fromarray(rgb[0], "RGB").save(l / "000000.png"); Image.fromarray(rgb[1], "RGB").save(r / "000000.png")
+    grey = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    for camera_rgb, code in ((1, precond.RGB2GRAY), (0, precond.BGR2GRAY)):
+        seq = sequence.StereoSequence(str(tmp_path), camera_rgb=camera_rgb)
+        batch, _ = next(seq.batches(1))
+        for side in (0, 1):
+            bgr = np.ascontiguousarray(rgb[side][..., ::-1])
+            assert np.array_equal(batch[side], oracle.cvt_gray(bgr, code)), (camera_rgb, side)
+        # the two settings differ on colour input (the R and B weights swap)
+    a = sequence.read_gray(str(l / "000000.png"), True); b = sequence.read_gray(str(l / "000000.png"), False)
+    assert not np.array_equal(a, b)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "a.png")
+    bgra = np.ascontiguousarray(np.concatenate([rgba[..., 2::-1], rgba[..., 3:]], axis=-1))
+    assert np.array_equal(sequence.read_gray(str(tmp_path / "a.png"), True), oracle.cvt_gray(bgra, precond.RGBA2GRAY))
+    assert np.array_equal(sequence.read_gray(str(tmp_path / "a.png"), False), oracle.cvt_gray(bgra, precond.BGRA2GRAY))
+    Image.fromarray(grey, "L").save(tmp_path / "g.png")
+    assert np.array_equal(sequence.read_gray(str(tmp_path / "g.png"), True), grey)
