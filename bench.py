@@ -177,12 +177,14 @@ def small_batch_latency(params, W, H, sizes=(1, 8, 128)):
         fe = ola.StereoFrontEnd(params, W, H, max_pairs=n)
         imgs = synth.stereo_batch(11, min(n, 16), W, H)
         imgs = np.tile(imgs, ((n + 15) // 16, 1, 1))[:2 * n].copy()
-        fe.frames(imgs)
-        reps = 5 if n <= 8 else 3
-        t = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(3 if n <= 8 else 1):      # (the first calls load code objects and set function attributes)
             fe.frames(imgs)
-        out[str(n)] = round((time.perf_counter() - t) / reps * 1e3, 3)
+        ts = []
+        for _ in range(9 if n <= 8 else 3):
+            t = time.perf_counter()
+            fe.frames(imgs)
+            ts.append(time.perf_counter() - t)
+        out[str(n)] = round(float(np.median(ts)) * 1e3, 3)      # median of the calls (rounds 1-4: mean of 5 behind one warm-up call)
         fe.ctx.close()
     return out
 
@@ -412,7 +414,8 @@ def main():
     gather_on = multi and args.gather != "off"
     gstat = {"bytes": 0, "seconds": 0.0, "last": None}
     if gather_on:
-        from orb_line_slam_amd.distributed import gather_records
+        from orb_line_slam_amd.distributed import gather_records, SizeExchange
+        szx = [None, None]
         bound = int(Lh.olf_frames_pack_bound(ctx.handle, B))
         # the trimmed record is about half of the bound at the configured feature counts; a record that does not fit is reported by ctx.synchronize()
         pk_bytes = bound if args.verify else bound // 2 + (1 << 20)
@@ -426,14 +429,15 @@ def main():
             s = torch.cuda.current_stream().cuda_stream
             check(Lh.olf_frames_pack_dev(ctx.handle, C.byref(fb), B, packed[k % 2].data_ptr(), pk_bytes, nbytes[k % 2].data_ptr(), s), "olf_frames_pack_dev")
             ev[k % 2].record()
+            # the sizes of all ranks' records: asked for now (the device counter goes into the all_gather as it is), read when the record is sent one step later
+            szx[k % 2] = SizeExchange(nbytes[k % 2], dist, comm_stream)
 
         def comm(k):
             # ordered after the pack of step k; the main stream is already running step k+1 underneath
             t = time.perf_counter()
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev[k % 2])
-                n = int(nbytes[k % 2].item())
-                recs, sizes = gather_records(packed[k % 2], min(n, pk_bytes), dist, 0, recv if rank == 0 else None)
+                recs, sizes = gather_records(packed[k % 2], None, dist, 0, recv if rank == 0 else None, sizes=szx[k % 2].sizes(pk_bytes))
                 comm_stream.synchronize()
             gstat["seconds"] += time.perf_counter() - t
             gstat["bytes"] += sum(sizes) - sizes[0]

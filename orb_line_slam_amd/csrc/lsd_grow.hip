@@ -1010,7 +1010,7 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
     const int ahead = (envAhead > 0 ? std::min(envAhead, E - 64) : E / 2) | noCw;
     if (G > 1) {
         // OLF_LSD_WS: log2 of the seed window the groups are dealt (6 .. 10), for A/B runs
-        static const int envWs = [] { const char* e = getenv("OLF_LSD_WS"); const int v = e ? atoi(e) : 0; return (v >= 6 && v <= 10) ? v : 0; }();
+        static const int envWs = [] { const char* e = getenv("OLF_LSD_WS"); const int v = e ? atoi(e) : 0; return (v >= 6 && v <= 13) ? v : 0; }();
         const int wsBits = envWs ? envWs : 10;
         if (G > MG_MAX_G || E > MG_MAX_E || !b.mg || n_images > b.mgImages || poolLimit / G < E + 64) { set_error("launch_lsd_grow_mw: groups"); return OLF_ERR_INVALID; }
         // the control words of every image start at zero (watermarks 0 = nothing final yet; the notice words are set when a slot is filled)

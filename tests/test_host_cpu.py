@@ -143,7 +143,7 @@ _WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
-from orb_line_slam_amd.distributed import shard_range, gather_records
+from orb_line_slam_amd.distributed import shard_range, gather_records, SizeExchange
 from orb_line_slam_amd.records import pack_records, merge_records, parse_records
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=rank, world_size=world)
@@ -174,6 +174,12 @@ rec = pack_records(*frames(lo, hi))
 packed = torch.from_numpy(np.frombuffer(rec + b"\\0" * 100, np.uint8).copy())          # the device buffer is larger than the record
 recs, sizes = gather_records(packed, len(rec), dist)
 assert sizes[rank] == len(rec)
+# the same gather with the sizes exchanged ahead of it (SizeExchange: what the pipelined bench does -- no size exchange inside the transfer)
+sx = SizeExchange(torch.tensor([len(rec)], dtype=torch.int64), dist)
+recs2, sizes2 = gather_records(packed, None, dist, sizes=sx.sizes())
+assert sizes2 == sizes and (recs2 is None) == (recs is None)
+if recs is not None:
+    assert all(a.numpy().tobytes() == b.numpy().tobytes() for a, b in zip(recs, recs2))
 if rank == 0:
     whole = pack_records(*frames(0, n_frames))                                          # what a 1-rank run of the same frames packs
     got = merge_records([r.numpy().tobytes() for r in recs])

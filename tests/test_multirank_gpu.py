@@ -86,3 +86,20 @@ def test_rccl_point_to_point_on_device_buffers_self_loop():
     d = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["identical"] is True and d["bytes"] == 8 << 20 and len(d["seconds"]) == 4
 
+
+
+def test_cpp_driver_links_rccl_directly_single_rank():
+    """examples/stereo_batch_sharded.cpp: the batched mode behind the C ABI for a C++ caller -- one process per GPU, shard_range, olf_stereo_frames_dev,
+    olf_frames_pack_dev, ncclAllGather of the record sizes, grouped ncclSend / ncclRecv of the records one step late.  With the one rank a 1-GPU box has: the communicator,
+    the all-gather and the pipelined loop run in librccl; the line it prints must account for every pair and a non-empty record per step."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "stereo_batch_sharded")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([exe, "16", "3", "1242", "375"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["ranks"] == 1 and line["pairs_per_step"] == 16 and line["steps"] == 3 and line["stereo_frames_per_s"] > 0
+    assert line["record_bytes_all_ranks"] > 3 * 16 * 50000          # (about 0.2 MB per KITTI pair, trimmed)
