@@ -55,6 +55,9 @@ struct olf_ctx {
     hipEvent_t ev_lbd = nullptr;       // fused entry: the LBD gradient images are ready (computed on the ORB stream in the seed ordering's shadow)
     bool deferred_join = false;        // olf_ctx_set_deferred_join: olf_stereo_frames_dev returns with the line path still running on the line stream
     bool join_pending = false;         // ... and this call's line path has not been joined yet (olf_stereo_frames_join_dev, or the next call)
+    // small contexts (the drop-in's one-pair-per-call shape): the eleven output arrays of olf_stereo_frames sit in ONE device slab, so that the host entry brings them
+    // back with one copy into pinned memory instead of eleven (each a launch and a gap of its own: 0.44 ms of a 9 ms call, profiles/r5b_pair_timeline.txt)
+    uint8_t* d_outslab = nullptr; uint8_t* h_outslab = nullptr; size_t outslab_bytes = 0; size_t outslab_off[12] = {0};
     const uint8_t* pend_ldesc = nullptr; size_t pend_ldesc_bytes = 0;       // the line descriptors / counts that call is still writing: an entry that is handed
     const int32_t* pend_lcounts = nullptr; size_t pend_lcounts_n = 0;       // them (matcher, packer) joins first
     bool defer_lbd = false;            // fused entry: olf_line_extract_dev stops behind the rectangles; selection + LBD are enqueued by the caller
@@ -217,6 +220,7 @@ void olf_ctx_destroy(olf_ctx* c)
 {
     if (!c) return;
     if (c->has_tables) angle_tables_release(c->device, c->params.line.conv_libm_float);
+    if (c->h_outslab) (void)hipHostFree(c->h_outslab);
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* p : c->scratch) if (p) (void)hipFree(p);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -316,6 +320,21 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
         void* q = nullptr;
         if (hipMalloc(&q, stereo_lines_prep_bytes((int)n, lg.outCap)) != hipSuccess) { set_error("hipMalloc failed"); return fail(OLF_ERR_HIP); }
         c->allocs.push_back(q); c->d_lprep = q;
+    }
+    if (n <= 16) {
+        const size_t np = (n + 1) / 2, ocap = g.outCap, lcap = lg.outCap;
+        const size_t sz[11] = {n * ocap * sizeof(olf_keypoint), n * ocap * OLF_DESC_BYTES, n * sizeof(int), np * ocap * sizeof(float), np * ocap * sizeof(float),
+                               n * lcap * sizeof(olf_keyline), n * lcap * OLF_DESC_BYTES, n * sizeof(int), np * lcap * sizeof(int), np * lcap * 2 * sizeof(float), np * lcap * 3 * sizeof(double)};
+        size_t off = 0;
+        for (int k = 0; k < 11; ++k) { c->outslab_off[k] = off; off += (sz[k] + 255) & ~(size_t)255; }
+        c->outslab_off[11] = off; c->outslab_bytes = off;
+        A(c->d_outslab, off);
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->h_outslab), off, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc failed"); return fail(OLF_ERR_HIP); }
+        uint8_t* q = c->d_outslab;
+        c->d_kps = reinterpret_cast<olf_keypoint*>(q + c->outslab_off[0]); c->d_desc = q + c->outslab_off[1]; c->d_counts = reinterpret_cast<int*>(q + c->outslab_off[2]);
+        c->d_uright = reinterpret_cast<float*>(q + c->outslab_off[3]); c->d_depth = reinterpret_cast<float*>(q + c->outslab_off[4]);
+        c->d_kls = reinterpret_cast<olf_keyline*>(q + c->outslab_off[5]); c->d_ldesc = q + c->outslab_off[6]; c->d_lcounts = reinterpret_cast<int*>(q + c->outslab_off[7]);
+        c->d_lm12 = reinterpret_cast<int*>(q + c->outslab_off[8]); c->d_ldisp = reinterpret_cast<float*>(q + c->outslab_off[9]); c->d_lle = reinterpret_cast<double*>(q + c->outslab_off[10]);
     }
 #undef A
     l.status = b.status;
@@ -1158,6 +1177,19 @@ int olf_stereo_frames(olf_ctx* c, const uint8_t* images, int n_pairs, const olf_
     OLF_TRY(olf_stereo_frames_dev(c, c->d_images, n_pairs, &d, c->stream));
     OLF_TRY(olf_stereo_frames_join_dev(c, c->stream));      // (a context with the deferred join on: the copies below read the line outputs)
     hipStream_t s = c->stream;
+    if (c->d_outslab && (int)ni == c->max_images) {
+        // one copy for all eleven arrays, then host copies out of the pinned slab (the arrays are laid out for exactly this many images)
+        OLF_HIP_CHECK(hipMemcpyAsync(c->h_outslab, c->d_outslab, c->outslab_bytes, hipMemcpyDeviceToHost, s));
+        OLF_HIP_CHECK(hipStreamSynchronize(s));
+        const uint8_t* h = c->h_outslab;
+        memcpy(o->kps, h + c->outslab_off[0], cap * ni * sizeof(olf_keypoint)); memcpy(o->desc, h + c->outslab_off[1], cap * ni * OLF_DESC_BYTES);
+        memcpy(o->counts, h + c->outslab_off[2], ni * sizeof(int)); memcpy(o->uright, h + c->outslab_off[3], cap * n_pairs * sizeof(float));
+        memcpy(o->depth, h + c->outslab_off[4], cap * n_pairs * sizeof(float)); memcpy(o->kls, h + c->outslab_off[5], lcap * ni * sizeof(olf_keyline));
+        memcpy(o->ldesc, h + c->outslab_off[6], lcap * ni * OLF_DESC_BYTES); memcpy(o->lcounts, h + c->outslab_off[7], ni * sizeof(int));
+        memcpy(o->lmatches12, h + c->outslab_off[8], lcap * n_pairs * sizeof(int)); memcpy(o->ldisp, h + c->outslab_off[9], lcap * n_pairs * 2 * sizeof(float));
+        memcpy(o->lle, h + c->outslab_off[10], lcap * n_pairs * 3 * sizeof(double));
+        return check_status(c);
+    }
     OLF_HIP_CHECK(hipMemcpyAsync(o->kps, d.kps, cap * ni * sizeof(olf_keypoint), hipMemcpyDeviceToHost, s));
     OLF_HIP_CHECK(hipMemcpyAsync(o->desc, d.desc, cap * ni * OLF_DESC_BYTES, hipMemcpyDeviceToHost, s));
     OLF_HIP_CHECK(hipMemcpyAsync(o->counts, d.counts, ni * sizeof(int), hipMemcpyDeviceToHost, s));

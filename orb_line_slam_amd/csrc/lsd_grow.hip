@@ -872,7 +872,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     const double prec = g.prec, precWrap = g.precWrap;
     const bool dedicated = MG && nw >= 4 && !(ahead & 0x10000);        // wave 0 of the group commits and publishes, the others grow (bit 16 of `ahead`: OLF_MW_NO_COMMIT_WAVE, A/B)
     ahead &= 0xffff;
-    int idle = 0;
+    int idle = 0, cwHead = -1, cwTail = -1;
     PROF_DECL;
     for (;;) {
         MwCtl cv = mw_ctl(c.ctl);
@@ -889,7 +889,9 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
             mw_commit_mg(c);
             PROF(PF_COMMIT);
             __builtin_amdgcn_s_sleep(1);
-            if (++idle > (1 << 22)) { if (lane == 0) atomicOr(status, 16); mw_abort<MG>(c); break; }
+            // the guard counts polls without any movement of the buffer (a single region of a few hundred thousand pixels keeps a wave busy for a second)
+            if (cv.head != cwHead || cv.tail != cwTail) { cwHead = cv.head; cwTail = cv.tail; idle = 0; }
+            if (++idle > (1 << 23)) { if (lane == 0) atomicOr(status, 16); mw_abort<MG>(c); break; }
             continue;
         }
         if (!MG) mw_commit(c, cv); else if (!dedicated) mw_commit_mg(c);
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
         }
         __builtin_amdgcn_s_sleep(8);
         PROF(PF_IDLE);
-        if (++idle > (MG ? (1 << 18) : (1 << 21))) {
+        if (++idle > (1 << 21)) {
             // the guard: what the first wave to give up saw goes to status[32..] (olf_debug_status)
             if (lane == 0 && img == 0 && atomicCAS(status + 28 + grp, 0, 1) == 0) {
                 int* d = status + 64 + grp * 24;

@@ -30,7 +30,13 @@
 namespace olf {
 
 // the grid-wide top levels (launch_seedsort_top, below)
-constexpr int SS_TOP_MIN = 32768, SS_TOP_JOBS = 64, SS_TOP_LEVELS = 6, SS_TOP_FINAL = 224;
+#ifndef OLF_SS_TOP_LEVELS
+#define OLF_SS_TOP_LEVELS 8
+#endif
+#ifndef OLF_SS_TOP_MIN
+#define OLF_SS_TOP_MIN 8192
+#endif
+constexpr int SS_TOP_MIN = OLF_SS_TOP_MIN, SS_TOP_JOBS = 128, SS_TOP_LEVELS = OLF_SS_TOP_LEVELS, SS_TOP_FINAL = 512;
 constexpr int SS_JW = 12;      // words of a job: first, last, depth of its children, lb, ub, pivot key, first tile, tiles, s, cut
 constexpr int SS_TOP_WORDS = 8 + 2 * SS_TOP_JOBS * SS_JW + SS_TOP_FINAL * 5;      // per image: counters [nJobs, nNext, nFinal, tiles, Kthr, n], two job lists, final entries
 constexpr int SS_CAP = 1024;      // elements of a range held in LDS (4 KB + 2 KB of exchange arrays: 24 waves = 24 images per CU)
@@ -398,10 +404,11 @@ enum { SP_PART_MEM = 0, SP_PART_LDS, SP_EQUAL, SP_LEAF, SP_LOAD, SP_PIVOT, SP_OT
 template <int NW, int NEM, int NI = 1>
 __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_images, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                               const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                              uint32_t* s_buf, uint32_t* s_x, int* ctl, const int* topImg = nullptr, int grp = 0, int Gs = 1)
+                                              uint32_t* s_buf, uint32_t* s_x, int* ctl, int* topImg = nullptr, int grp = 0, int Gs = 1)
 {
-    // (grp, Gs: NI == 1 behind the grid-wide top levels only -- Gs workgroups share one image: each starts from every Gs-th range the top levels left; the ranges
-    // are disjoint in the key array and in the seed list, so nothing but the seed count is shared)
+    // (grp, Gs: NI == 1 behind the grid-wide top levels only -- Gs workgroups share one image: a wave that finds its workgroup's stack empty takes the next of the
+    // ranges the top levels left from the image's list (a counter in global memory); the ranges are disjoint in the key array and in the seed list, so nothing but
+    // that counter and the seed count is shared, and the result does not depend on who sorts which range)
     static_assert(NI == 1 || NI == NW, "one wave per image of the group");
 #ifdef OLF_SS_PROF
     long long sp_acc[SP_N] = {0}, sp_t = __builtin_readcyclecounter();
@@ -455,9 +462,8 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
                 // the top levels have been partitioned by the grid-wide kernels (launch_seedsort_top): start from the ranges they left
                 const int nf = min(topImg[2], SHCAP);
                 const int* f = topImg + 8 + 2 * SS_TOP_JOBS * SS_JW;
-                int e = 0;
-                for (int q = grp; q < nf; q += Gs, ++e) { shF[e] = f[5 * q]; shL[e] = f[5 * q + 1]; shD[e] = f[5 * q + 2]; shLb[e] = f[5 * q + 3]; shUb[e] = f[5 * q + 4]; }
-                ctl[1] = e;
+                ctl[1] = 0;              // (the stack starts empty: the waves pull the ranges the top levels left one by one ...)
+                cntS[0] = 0;             // ... until the image's list is exhausted
             } else { ctl[1] = 1; shF[0] = 0; shL[0] = n; shD[0] = depth0; shLb[0] = 0; shUb[0] = g.nBins - 1; }
         }
         __syncthreads();
@@ -495,6 +501,7 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
                 const int e = ssU(__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 const int bz = ssU(__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (e > 0 || bz == 0) break;
+                if (NI == 1 && topImg && ssU(__hip_atomic_load(&cntS[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;      // (ranges left in the image's list)
                 __builtin_amdgcn_s_sleep(16);
                 if (idle > (1 << 21)) { if (lane == 0) atomicOr(status, 64); break; }
             }
@@ -503,6 +510,14 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
             if (lane == 0) {
                 const int e = atomicAdd(&ctl[1], 0);
                 if (e > 0) { f = shF[e - 1]; l = shL[e - 1]; d = shD[e - 1]; a = shLb[e - 1]; b = shUb[e - 1]; atomicAdd(&ctl[2], 1); atomicExch(&ctl[1], e - 1); got = 1; }
+                else if (NI == 1 && topImg && cntS[0] == 0) {
+                    // the next range of the image's list (cnt[3], zero when the last top level ends)
+                    const int q = atomicAdd(topImg + 3, 1);
+                    if (q < topImg[2]) {
+                        const int* fq = topImg + 8 + 2 * SS_TOP_JOBS * SS_JW + 5 * q;
+                        f = fq[0]; l = fq[1]; d = fq[2]; a = fq[3]; b = fq[4]; atomicAdd(&ctl[2], 1); got = 1;
+                    } else cntS[0] = 1;
+                }
                 else if (atomicAdd(&ctl[2], 0) == 0) done = 1;
             }
             SS_UNLOCK();
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict_
 template <int NW, int NEM, int NI>
 __global__ __launch_bounds__(64 * NW) void k_lsd_seedsort_mw(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
                                                             const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride,
-                                                            int n_images, const int* __restrict__ topAll, int Gs)
+                                                            int n_images, int* __restrict__ topAll, int Gs)
 {
     extern __shared__ __align__(8) uint32_t s_dyn[];
     constexpr int BUFW = 4 * 64 * NEM, XW = 2 * 64 * NEM;
@@ -698,9 +713,14 @@ __device__ __forceinline__ void ss_top_child(const SsTop& t, int* s_next, int* s
     if (lb > Kthr) return;                                    // only undefined pixels: never seeds, never leave the range
     if (!lastLevel && last - first >= SS_TOP_MIN && lb != ub && depth > 0) {
         const int j = atomicAdd(s_next, 1);
-        int* q = t.next + j * SS_JW;
-        q[0] = first; q[1] = last; q[2] = depth - 1; q[3] = (int)lb; q[4] = (int)ub;
-    } else {
+        if (j < SS_TOP_JOBS) {
+            int* q = t.next + j * SS_JW;
+            q[0] = first; q[1] = last; q[2] = depth - 1; q[3] = (int)lb; q[4] = (int)ub;
+            return;
+        }
+        // (more ranges than a level has room for: this one is left to the per-image kernel as it is)
+    }
+    {
         const int e = atomicAdd(s_fin, 1);
         if (e < SS_TOP_FINAL) { int* q = t.fin + e * 5; q[0] = first; q[1] = last; q[2] = depth; q[3] = (int)lb; q[4] = (int)ub; }
         else atomicOr(status, 64);      // (its own flag: 32 is the frame record buffer)
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topA
         ss_top_child(t, &s_next, &s_fin, first, cut, depth, lb, min(ub, Kp), Kthr, lastLevel, status);
     }
     __syncthreads();
-    if (j == 0) { t.cnt[0] = s_next; t.cnt[2] = min(s_fin, SS_TOP_FINAL); t.cnt[3] = 0; }
+    if (j == 0) { t.cnt[0] = min(s_next, SS_TOP_JOBS); t.cnt[2] = min(s_fin, SS_TOP_FINAL); t.cnt[3] = 0; }
 }
 
 int lsd_seedsort_top_words() { return SS_TOP_WORDS; }
@@ -971,7 +991,7 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
     const int Gs = !useTop ? 1 : envG ? envG : n_images <= 4 ? 8 : n_images <= 16 ? 4 : n_images <= 32 ? 2 : 1;
     if (Gs > 1) OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));      // (the groups' seed counts meet in an atomicMax)
     hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3(((n_images + NI - 1) / NI) * Gs), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
-                       nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (const int*)nullptr, Gs);
+                       nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (int*)nullptr, Gs);
     return OLF_OK;
 }
 
