@@ -56,6 +56,16 @@ STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_s
                 "lsd_rect": "olf::k_lsd_rect", "line_select_lbd": "olf::k_lbd_rows", "stereo_lines": "olf::k_lines_dist", "match_bf": "olf::k_knn2"}
 
 
+# every kernel of a stage (name prefixes as rocprofv3 prints them, "void " stripped): the PMC traffic summary of the whole step is folded into roofline.stages with it.
+# k_sep7_strip serves three stages (ORB blur, the LSD blur of lsd_front, the LBD blur of line_select_lbd) and is reported under orb_blur, its largest user.
+STAGE_KERNELS = {"orb_pyramid": ["olf::k_ingest", "olf::k_resize_strip", "olf::k_resize_tiled"], "orb_fast_cells": ["olf::k_fast_score", "olf::k_cells_sort", "olf::k_fast_"],
+                 "orb_octree": ["olf::k_octree"], "orb_blur": ["olf::k_sep7"], "orb_describe": ["olf::k_describe", "olf::k_ic_angle", "olf::k_orb_assemble", "olf::k_assemble"],
+                 "stereo_points": ["olf::k_stereo_"], "lsd_front": ["olf::k_lsd_upgrad", "olf::k_lsd_keys", "olf::k_lsd_seedsort", "olf::k_lsd_grad", "olf::k_top_", "olf::k_radix_"],
+                 "lsd_grow": ["olf::k_lsd_grow", "olf::k_mg_merge"], "lsd_rect": ["olf::k_lsd_rect", "olf::k_lsd_emit"],
+                 "line_select_lbd": ["olf::k_line_select", "olf::k_sobel3", "olf::k_lbd_"], "stereo_lines": ["olf::k_lines_"],
+                 "match": ["olf::k_knn2", "olf::k_ratio_mutual", "olf::k_search_by_bow", "olf::k_bow_", "olf::k_match_", "olf::k_depth_mask", "olf::k_transform"]}
+
+
 def synthetic_vocabulary(k, L, sample_desc, seed=4242):
     """A full k-ary vocabulary tree of depth L in the arrays ORBVocabulary.from_arrays takes (parent, is_leaf, descriptor, weight), nodes in
     breadth-first order like TemplatedVocabulary::loadFromTextFile builds them (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1338-1425).  The
@@ -565,6 +575,22 @@ def main():
                     break
         except Exception:
             traffic = None
+        # ... and of every stage: the summary of the same command (one step at this batch) covers every kernel of the step, ORB, stereo and matcher kernels included
+        stage_traffic, kernel_traffic = {}, {}
+        try:
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
+                pm = json.load(open(f))
+                if pm.get("source_hash") != sh:
+                    continue
+                for k, v in pm["kernels"].items():
+                    kn = k.replace("void ", "")
+                    kernel_traffic[kn] = int(v["bytes_per_image"])
+                    st_of = next((st for st, pre in STAGE_KERNELS.items() if any(kn.startswith(q) for q in pre)), None)
+                    if st_of:
+                        stage_traffic[st_of] = stage_traffic.get(st_of, 0) + int(v["bytes_per_image"])
+                break
+        except Exception:
+            stage_traffic, kernel_traffic = {}, {}
         # the same kernel against the part's vector-instruction issue rate: SQ_INSTS_VALU per image (profiles/*_valu_budget.json, same source-hash rule)
         # x images per launch / launch duration, over 256 CUs x 4 SIMDs x one wave64 vector instruction per 4 cycles at 2.4 GHz = 614.4 G/s
         valu, valu_step = None, None
@@ -612,7 +638,16 @@ def main():
                 rs[k] = {"ms_alone": round(ms, 3)}
                 if by:
                     rs[k].update(GBps=round(by / (ms * 1e-3) / 1e9, 1), frac=round(by / (ms * 1e-3) / 1e9 / 8000.0, 4))
+                if k in stage_traffic:
+                    # counter traffic (2 x FETCH_SIZE + WRITE_SIZE per launch of the whole batch) next to the algorithmic bytes: the ratio is the re-read factor
+                    rs[k]["traffic"] = stage_traffic[k] * 2 * B
+                    if by:
+                        rs[k]["traffic_over_algorithmic"] = round(stage_traffic[k] * 2 * B / by, 2)
+            if "match" in stage_traffic:
+                rs["match"] = {"traffic": stage_traffic["match"] * 2 * B}
             out["roofline"]["stages"] = rs
+            if kernel_traffic:
+                out["roofline"]["kernel_traffic_bytes_per_image"] = kernel_traffic
             out["roofline"]["sum_alone_ms"] = round(sum(alone.values()), 2)
         if gather_on:
             out["gather"] = {"mode": args.gather, "bytes_per_step": int(gstat["bytes"] / max(args.steps, 1)),

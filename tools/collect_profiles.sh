@@ -6,13 +6,16 @@ O=$R/gpurun_out/$T; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout 900 python -m pytest $R/tests -q -m gpu -p no:cacheprovider > $O/${T}_pytest_gpu.txt 2>&1; tail -1 $O/${T}_pytest_gpu.txt
 rm -rf /tmp/pf /tmp/pw
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pf -o run -- python $R/tools/prof_lines.py 4096 > /tmp/pf.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d /tmp/pw -o run -- python $R/tools/prof_lines.py 4096 > /tmp/pw.log 2>&1
-python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw 4096 $O/${T}_pmc_hbm_traffic > $O/${T}_pmc_hbm_traffic_lines4096.txt 2>&1
+# HBM traffic of EVERY kernel of the step (ORB, stereo and matcher kernels included), at the bench's own batch: one step of bench.py under each counter
+BENCH1="python $R/bench.py --no-cpu-baseline --no-extras --no-isolated --steps 1 --warmup 0"
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pf -o run -- $BENCH1 > /tmp/pf.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d /tmp/pw -o run -- $BENCH1 > /tmp/pw.log 2>&1
+python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw 6144 $O/${T}_pmc_hbm_traffic > $O/${T}_pmc_hbm_traffic_step6144.txt 2>&1
 cp $O/${T}_pmc_hbm_traffic.json $R/profiles/      # bench.py reads roofline.traffic from the summary whose source hash matches the sources it runs
 rm -rf /tmp/pb
-OLF_LSD_NW=0 OLF_ONE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- python $R/bench.py --no-cpu-baseline --no-extras --no-isolated --pairs 512 --steps 1 --warmup 0 > /tmp/pb.log 2>&1
-python $R/tools/pmc_budget.py /tmp/pb 1024 $O/${T}_valu_budget.json > $O/${T}_valu_budget_per_kernel.txt 2>&1; cp $O/${T}_valu_budget.json $R/profiles/
+# instruction budget at the bench's batch (3072 pairs: the kernel variants the step really launches -- VERDICT r4 weak 7a)
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d /tmp/pb -o run -- $BENCH1 > /tmp/pb.log 2>&1
+python $R/tools/pmc_budget.py /tmp/pb 6144 $O/${T}_valu_budget.json > $O/${T}_valu_budget_per_kernel.txt 2>&1; cp $O/${T}_valu_budget.json $R/profiles/
 timeout 900 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_C3.json; cut -c1-160 $O/${T}_bench_C3.json
 OLF_ONE_STREAM=1 timeout 600 python $R/bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_C3_one_stream.json
 # the other configurations: the bench line AND the rocprofv3 kernel summary of the same command
