@@ -711,7 +711,8 @@ __device__ __forceinline__ void ss_top_child(const SsTop& t, int* s_next, int* s
                                              int* status)
 {
     if (lb > Kthr) return;                                    // only undefined pixels: never seeds, never leave the range
-    if (!lastLevel && last - first >= SS_TOP_MIN && lb != ub && depth > 0) {
+    // (cnt[6]: the smallest range the grid-wide levels still split -- SS_TOP_MIN, more for a large working image, so that the ranges they leave fit the list)
+    if (!lastLevel && last - first >= t.cnt[6] && lb != ub && depth > 0) {
         const int j = atomicAdd(s_next, 1);
         if (j < SS_TOP_JOBS) {
             int* q = t.next + j * SS_JW;
@@ -728,7 +729,7 @@ __device__ __forceinline__ void ss_top_child(const SsTop& t, int* s_next, int* s
 }
 
 __global__ __launch_bounds__(64) void k_top_init(const LineGeom* __restrict__ gp, int* __restrict__ topAll, const int* __restrict__ maxN, int nOverride, int kthrOverride,
-                                                 int depthOverride, int* __restrict__ status)
+                                                 int depthOverride, int* __restrict__ status, int topMin)
 {
     const LineGeom& g = *gp;
     const int img = blockIdx.x;
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(64) void k_top_init(const LineGeom* __restrict__ gp
             Kthr = (uint32_t)(g.nBins - 1 - (int)(normT * bin_coef));
         }
     }
-    t.cnt[0] = 0; t.cnt[1] = 0; t.cnt[2] = 0; t.cnt[3] = 0; t.cnt[4] = (int)Kthr; t.cnt[5] = empty ? 0 : n;
+    t.cnt[0] = 0; t.cnt[1] = 0; t.cnt[2] = 0; t.cnt[3] = 0; t.cnt[4] = (int)Kthr; t.cnt[5] = empty ? 0 : n; t.cnt[6] = topMin;
     if (empty) return;
     const int depth0 = depthOverride >= 0 ? depthOverride : 2 * (31 - __builtin_clz((unsigned)n));
     __shared__ int s_nj, s_nf;
@@ -957,8 +958,12 @@ static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_image
     const int maxTiles = n / 64 + SS_TOP_JOBS + 2, half = maxTiles + SS_TOP_JOBS + 2;
     const size_t stride = (size_t)g.regionStride;
     if ((size_t)2 * half > stride) return OLF_ERR_CAPACITY;
-    hipLaunchKernelGGL(k_top_init, dim3(n_images), dim3(64), 0, s, b.geom, b.topBuf, b.maxN, nOverride, kthrOverride, depthOverride, b.status);
-    if (n < SS_TOP_MIN) return OLF_OK;       // (the root is a final entry)
+    // ranges of at least topMin elements are split by the grid-wide levels: SS_TOP_MIN, or more when the image is so large that every pixel defined (noise) would
+    // leave more than about 160 ranges (the list holds SS_TOP_FINAL = 512, a level SS_TOP_JOBS = 128 jobs)
+    int topMin = SS_TOP_MIN;
+    while (n / topMin > 160) topMin <<= 1;
+    hipLaunchKernelGGL(k_top_init, dim3(n_images), dim3(64), 0, s, b.geom, b.topBuf, b.maxN, nOverride, kthrOverride, depthOverride, b.status, topMin);
+    if (n < topMin) return OLF_OK;       // (the root is a final entry)
     const dim3 tg((maxTiles + 3) / 4, n_images);
     for (int level = 0; level < SS_TOP_LEVELS; ++level) {
         hipLaunchKernelGGL(k_top_pivot, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, b.keysA, (size_t)g.Ps, level);

@@ -136,3 +136,20 @@ def test_pool_fallback_keeps_one_stride_for_both_pixel_list_formats(oracle):
             assert n == len(want[i]["kls"]), (waves, pool, i, n, len(want[i]["kls"]))
             assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (waves, pool, i)
     _lib.check(_lib.lib().olf_debug_lsd_pool(ex._ctx.handle, 0), "olf_debug_lsd_pool")
+
+
+def test_large_noise_image_fits_the_sort_levels_and_falls_back_cleanly(oracle):
+    """Every pixel defined (noise) on a 1280 x 720 image, one image per call: the grid-wide top levels of the seed sort leave the most ranges they ever can (their
+    minimum range size adapts to the image so that the list holds them), the multi-wave growth's chunk pool overflows and the image is grown again by the one-wave
+    agent -- no capacity / watchdog flag, result equal to the oracle."""
+    w, h = 1280, 720
+    rng = np.random.default_rng(17)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    p = oracle.full_params(1000, 0)
+    ex = ola.Lineextractor(0, 0.025, max_images=1)
+    o = oracle.line_extract(noise, p.line)
+    for groups in (0, 1):
+        _set(ex, w, h, 1, -1, 0, groups)
+        gk, gd = ex(noise)
+        assert (_status(ex)[0] & (8 | 16 | 64)) == 0, groups
+        assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), groups
