@@ -993,7 +993,7 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
     // behind the top levels a few images leave most of the chip idle: Gs workgroups (CUs) per image, each starting from every Gs-th of the ranges the top levels
     // left (OLF_SS_GROUPS forces 1 .. 8)
     static const int envG = [] { const char* e = getenv("OLF_SS_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
-    const int Gs = !useTop ? 1 : envG ? envG : n_images <= 4 ? 8 : n_images <= 16 ? 4 : n_images <= 32 ? 2 : 1;
+    const int Gs = !useTop ? 1 : envG ? envG : n_images <= 16 ? 8 : 4;      // (useTop: at most 64 images; 8 pairs 9.85 against 9.91 ms with 4, 32 pairs 14.0 with 4 against 14.6 with 8)
     if (Gs > 1) OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));      // (the groups' seed counts meet in an atomicMax)
     hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3(((n_images + NI - 1) / NI) * Gs), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
                        nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (int*)nullptr, Gs);
