@@ -153,3 +153,13 @@ def test_large_noise_image_fits_the_sort_levels_and_falls_back_cleanly(oracle):
         gk, gd = ex(noise)
         assert (_status(ex)[0] & (8 | 16 | 64)) == 0, groups
         assert np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), groups
+
+
+def test_cross_cu_hand_over_under_uneven_load():
+    """tools/stress_mg.py: single-pair calls (two growth workgroups and eight sort workgroups per image -- owner words, watermarks and steal notices cross CU
+    boundaries as agent-scope relaxed atomics) while another thread keeps every CU busy with 256-pair batches; every result must equal the unloaded first one.
+    (An idle chip hides visibility bugs; this is the uneven-load form.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_mg.py"), "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode()
+    assert "STRESS OK" in out, out[-1500:]
