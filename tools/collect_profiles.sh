@@ -36,5 +36,9 @@ timeout 900 python $R/tools/fuzz.py 500 11 2>/dev/null | tail -8 > $O/${T}_fuzz_
 timeout 600 python $R/tools/fuzz_match.py 300 5 2>/dev/null | tail -2 > $O/${T}_fuzz_match_300cases.txt
 timeout 600 python $R/tools/pcie_rate.py 2048 8 > $O/${T}_pcie_rate.txt 2>&1; tail -2 $O/${T}_pcie_rate.txt
 timeout 300 python $R/tools/pair_latency.py > $O/${T}_pair_latency.txt 2>&1
+# the one-pair shape: latency by growth workgroups per image, the kernel / copy timeline of one call, the cross-CU hand-over under uneven load
+OLF_AB_SETTINGS="1:512,2:512,4:512" timeout 300 python $R/tools/ab_groups.py 1 8 32 2>&1 | grep -v amdgpu.ids > $O/${T}_growth_groups.txt
+timeout 300 bash $R/tools/pair_timeline_full.sh > $O/${T}_pair_timeline.txt 2>&1
+timeout 300 python $R/tools/stress_mg.py 60 2>&1 | grep -v amdgpu.ids > $O/${T}_stress_uneven_load.txt
 timeout 300 python $R/tools/search_latency.py 2>/dev/null | tail -1 > $O/${T}_search_latency.txt
 ls -la $O
