@@ -435,12 +435,13 @@ def main():
         recv = [torch.empty(pk_bytes, dtype=torch.uint8, device=dev) if (rank == 0 and r != 0) else None for r in range(world)]
         comm_stream = torch.cuda.Stream(device=dev, priority=-1) if args.gather == "overlap" else torch.cuda.current_stream()      # (its own priority level: streams of one level can share a hardware queue, profiles/r4aq_stream_queue_aliasing.txt)
 
-        def pack(k):
+        def pack(k, exchange=True):
             s = torch.cuda.current_stream().cuda_stream
             check(Lh.olf_frames_pack_dev(ctx.handle, C.byref(fb), B, packed[k % 2].data_ptr(), pk_bytes, nbytes[k % 2].data_ptr(), s), "olf_frames_pack_dev")
             ev[k % 2].record()
             # the sizes of all ranks' records: asked for now (the device counter goes into the all_gather as it is), read when the record is sent one step later
-            szx[k % 2] = SizeExchange(nbytes[k % 2], dist, comm_stream)
+            if exchange:      # (a collective: every rank or none -- the --verify replay on rank 0 packs without it)
+                szx[k % 2] = SizeExchange(nbytes[k % 2], dist, comm_stream)
 
         def comm(k):
             # ordered after the pack of step k; the main stream is already running step k+1 underneath
@@ -533,7 +534,7 @@ def main():
                 other = make_input(r)
                 torch.cuda.synchronize()          # (the input event set above speaks for `imgs`: another input has to be complete before the call)
                 step(other)
-                pack(0)
+                pack(0, exchange=False)
                 torch.cuda.synchronize()
                 n = int(nbytes[0].item())
                 mine = records.merge_records([packed[0][:n].cpu().numpy().tobytes()])         # normalises the padding between sections
