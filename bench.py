@@ -585,10 +585,11 @@ def main():
                     continue
                 for k, v in pm["kernels"].items():
                     kn = k.replace("void ", "")
-                    kernel_traffic[kn] = int(v["bytes_per_image"])
+                    per_step = int(v.get("bytes_per_image_step", v["bytes_per_image"]))      # all launches of a step (FAST: one per level)
+                    kernel_traffic[kn] = per_step
                     st_of = next((st for st, pre in STAGE_KERNELS.items() if any(kn.startswith(q) for q in pre)), None)
                     if st_of:
-                        stage_traffic[st_of] = stage_traffic.get(st_of, 0) + int(v["bytes_per_image"])
+                        stage_traffic[st_of] = stage_traffic.get(st_of, 0) + per_step
                 break
         except Exception:
             stage_traffic, kernel_traffic = {}, {}

@@ -26,7 +26,9 @@ lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and, in a separate pass, 
          "kernel, launches, FETCH KiB/launch, WRITE KiB/launch, calibrated (2*FETCH+WRITE) bytes per image, raw (FETCH+WRITE) bytes per image"]
 for k in sorted(F, key=lambda k: -(F[k][0] + W.get(k, (0, 0))[0])):
     f, w = F[k][0], W.get(k, (0.0, 0))[0]
-    kern[k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "bytes_per_image": (2 * f + w) * 1024 / n_img, "raw_bytes_per_image": (f + w) * 1024 / n_img}
+    # (bytes_per_image: one launch; bytes_per_image_step: all launches of the profiled command -- one step of bench.py -- e.g. the eight level launches of FAST)
+    kern[k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "bytes_per_image": (2 * f + w) * 1024 / n_img, "raw_bytes_per_image": (f + w) * 1024 / n_img,
+               "launches": F[k][1], "bytes_per_image_step": (2 * f + w) * 1024 / n_img * F[k][1]}
     lines.append(f"{k}, {F[k][1]}, {f:.0f}, {w:.0f}, {(2 * f + w) * 1024 / n_img:.0f}, {(f + w) * 1024 / n_img:.0f}")
 json.dump({"images_per_launch": n_img, "source_hash": source_hash(), "calibration": "bytes_per_image = (2 * FETCH_SIZE + WRITE_SIZE) / images: FETCH_SIZE tallies 128-B read requests at 64 B (profiles/r3_fetch_calibration.txt)", "kernels": kern}, open(out + ".json", "w"), indent=1)
 open(out + ".txt", "w").write("\n".join(lines) + "\n")
