@@ -762,9 +762,9 @@ __global__ __launch_bounds__(64) void k_top_init(const LineGeom* __restrict__ gp
 }
 
 // one thread per job: __move_median_to_first(first, first + 1, mid, last - 1); thread 0 then numbers the jobs' tiles
-__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_pivot(int* __restrict__ topAll, uint32_t* keysAll, size_t Ps, int level)
+// median of three of every job of `level`, moved to the job's first position (std::__move_median_to_first); the level's flat tile numbering
+__device__ __forceinline__ void ss_top_pivot_body(int* __restrict__ topAll, uint32_t* keysAll, size_t Ps, int level, int img, int j)
 {
-    const int img = blockIdx.x, j = threadIdx.x;
     const SsTop t = ss_top(topAll, img, level);
     const int nj = t.cnt[0];
     uint32_t* A = keysAll + (size_t)img * Ps;
@@ -788,6 +788,10 @@ __global__ __launch_bounds__(SS_TOP_JOBS) void k_top_pivot(int* __restrict__ top
         for (int k = 0; k < nj; ++k) { int* q = t.jobs + k * SS_JW; q[6] = acc; acc += q[7]; }
         t.cnt[3] = acc;
     }
+}
+__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_pivot(int* __restrict__ topAll, uint32_t* keysAll, size_t Ps, int level)
+{
+    ss_top_pivot_body(topAll, keysAll, Ps, level, blockIdx.x, threadIdx.x);
 }
 
 // the tile `gt` of the level's flat tile numbering -> its job; PL / GR of job j start at (first tile + j) and leave one spare word per job (T + 1 entries)
@@ -930,7 +934,8 @@ __global__ __launch_bounds__(256) void k_top_scan(int* __restrict__ topAll, cons
 }
 
 // children of every job: [cut, last) with K >= Kp, [first, cut) with K <= Kp (the pivot sits at first)
-__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topAll, int level, int* __restrict__ status)
+// ... and, unless this was the last level, the pivots of the next level's jobs in the same launch (one launch boundary less per level)
+__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topAll, int level, int* __restrict__ status, uint32_t* keysAll, size_t Ps)
 {
     __shared__ int s_next, s_fin;
     const int img = blockIdx.x, j = threadIdx.x;
@@ -948,6 +953,9 @@ __global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topA
     }
     __syncthreads();
     if (j == 0) { t.cnt[0] = min(s_next, SS_TOP_JOBS); t.cnt[2] = min(s_fin, SS_TOP_FINAL); t.cnt[3] = 0; }
+    if (level == SS_TOP_LEVELS - 1) return;
+    __syncthreads();
+    ss_top_pivot_body(topAll, keysAll, Ps, level + 1, img, j);
 }
 
 int lsd_seedsort_top_words() { return SS_TOP_WORDS; }
@@ -966,12 +974,12 @@ static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_image
     if (n < topMin) return OLF_OK;       // (the root is a final entry)
     const dim3 tg((maxTiles + 3) / 4, n_images);
     for (int level = 0; level < SS_TOP_LEVELS; ++level) {
-        hipLaunchKernelGGL(k_top_pivot, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, b.keysA, (size_t)g.Ps, level);
+        if (level == 0) hipLaunchKernelGGL(k_top_pivot, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, b.keysA, (size_t)g.Ps, level);
         hipLaunchKernelGGL(k_top_tiles<0>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_scan, dim3(SS_TOP_JOBS, n_images), dim3(256), 0, s, b.topBuf, b.keysA, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_tiles<1>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_tiles<2>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
-        hipLaunchKernelGGL(k_top_next, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, level, b.status);
+        hipLaunchKernelGGL(k_top_next, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, level, b.status, b.keysA, (size_t)g.Ps);
     }
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
