@@ -339,6 +339,24 @@ __device__ __forceinline__ void mw_commit_mg(const MwCtx& c)
     if (wm >= c.nkeys) wm = MG_INF;              // this group has nothing left
     if (wm != lds_u(c.ctl + C_WML) && c.lane == 0) { ag_store(c.gctl + MGC_WM + 16 * c.grp, wm); WG_STORE(c.ctl + C_WML, wm); }
     if (c.lane == 0) { WG_STORE(c.ctl + C_OMIN, (int)omin); WG_STORE(c.ctl + C_NREG, nr); WG_STORE(c.ctl + C_WM, min(wm, (int)omin)); }
+#ifdef OLF_MW_TRACE
+    // (-DOLF_MW_PROF -DOLF_MW_TRACE, image 0 of a context of four running two: a record per poll that moved the head or found it waiting, into the owner words of image 3)
+    if (c.tl0) {
+        int* tr = reinterpret_cast<int*>(c.owner) + 3 * (size_t)c.Ws * c.Hs + (size_t)c.grp * 300000;
+        const int i2 = h + c.lane, s2 = i2 & c.mask;
+        const int st2 = i2 < t2 ? WG_LOAD(c.eState + s2) : (int)ST_EMPTY;
+        const int nG = (int)__popcll(wave_vote(st2 == ST_GROWING)), nR = (int)__popcll(wave_vote(st2 == ST_READY)), nP = (int)__popcll(wave_vote(st2 == ST_PARKED)), nD = (int)__popcll(wave_vote(st2 == ST_DONE || st2 == ST_DEAD));
+        if (c.lane == 0) {
+            const int k = tr[0];
+            if (k < 29000 && (h != cl.head || (k & 7) == 0 || true)) {
+                int* r = tr + 10 + 10 * k;
+                r[0] = (int)(__builtin_amdgcn_s_memrealtime() - *c.tl0); r[1] = h; r[2] = t2; r[3] = h < t2 ? c.eRank[h & c.mask] : -1; r[4] = h < t2 ? c.eState[h & c.mask] : -1;
+                r[5] = h - cl.head; r[6] = nG | (nR << 8) | (nP << 16) | (nD << 24); r[7] = cl.dispNext; r[8] = (int)omin; r[9] = h < t2 ? (int)c.eBlock[h & c.mask] : 0;
+                tr[0] = k + 1;
+            }
+        }
+    }
+#endif
     unlock(c.ctl + C_LOCKCOMMIT, c.lane);
 }
 
