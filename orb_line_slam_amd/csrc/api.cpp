@@ -307,7 +307,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     // grown again by the one-wave agent (launch_lsd_grow)
     l.nChunks = lg.regionStride / 32;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
-    A(l.region, n * (size_t)lg.regionStride); A(l.owner, n * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    A(l.region, n * (size_t)lg.regionStride); l.ownerImages = (int)std::min<size_t>(n, kMwMaxImages); A(l.owner, (size_t)l.ownerImages * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     l.mgImages = (int)std::min<size_t>(n, kMgMaxImages); l.mgStride = lsd_grow_mg_stride(lg.maxRegions);
     A(l.mg, (size_t)l.mgImages * l.mgStride);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
@@ -655,7 +655,7 @@ int olf_debug_lsd_regions(olf_ctx* c, int image, int32_t* start_n /* [cap][2] */
 // debug: the owner words (seed rank << 10 | ROB slot, 0xffffffff = never claimed) the last multi-region growth left for `image` (Ws*Hs words)
 int olf_debug_lsd_owner(olf_ctx* c, int image, uint32_t* out)
 {
-    if (!c || !out || image < 0 || image >= c->max_images) return OLF_ERR_INVALID;
+    if (!c || !out || image < 0 || image >= c->lb.ownerImages) return OLF_ERR_INVALID;
     OLF_HIP_CHECK(hipDeviceSynchronize());
     OLF_HIP_CHECK(hipMemcpy(out, c->lb.owner + (size_t)image * c->line.geom.Ps, (size_t)c->line.geom.Ps * 4, hipMemcpyDeviceToHost));
     return OLF_OK;

@@ -79,7 +79,8 @@ struct LineDeviceBufs {
     int* status = nullptr;
     float* angDeg = nullptr;       // [2^22] level-line angle (degrees) of the packed gradient pair (gx:11 | gy:11), image independent
     void* angEnt = nullptr;        // [2^22] AngEnt (lsd_device.hpp): angle in radians, cos / sin as an added pixel, the sums a seed starts with -- 32 B
-    uint32_t* owner = nullptr;     // [n][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
+    int ownerImages = 0;           // images `owner` is sized for: the multi-wave growth runs on at most 3072 images per call (lsd_grow_waves), larger calls take the one-wave agent, which has no owner words
+    uint32_t* owner = nullptr;     // [ownerImages][Ps] region growing: FREE or (seed rank << 10 | ROB slot) of the region that claimed the pixel (lsd_grow.hip)
     int* links = nullptr;          // [n][nChunks] next chunk of a region's pixel list (-1: last)
     int nChunks = 0;               // 32-pixel chunks per image in `region` (ids < 1024: the ROB slots' own chunks, then the pool)
     bool skipScaled = false;         // fused stereo entry: the enlarged working image is consumed inside k_lsd_upgrad and not written (olf_lsd_debug_scaled needs the stand-alone entry)
@@ -117,6 +118,7 @@ int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsig
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
 size_t lsd_grow_mg_stride(int maxRegions);   // bytes per image of LineDeviceBufs::mg
+constexpr int kMwMaxImages = 3072;           // images per call up to which the multi-wave growth is chosen (lsd_grow_waves)
 constexpr int kMgMaxImages = 64;             // images grown by several workgroups each in one call, at most
 int lsd_seedsort_top_words();      // ints per image of LineDeviceBufs::topBuf
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);

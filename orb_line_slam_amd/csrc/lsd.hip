@@ -1525,7 +1525,8 @@ int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipS
 int lsd_grow_waves(int n_images);
 // the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
 // (lsd_refine = STD runs in the one-wave agent only)
-static int lsd_grow_path(const LineGeom& g, const LineDeviceBufs& b, int n_images) { return g.refine ? 0 : b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
+// (a call of more images than the owner words are allocated for -- kMwMaxImages -- takes the one-wave agent whatever is forced)
+static int lsd_grow_path(const LineGeom& g, const LineDeviceBufs& b, int n_images) { return (g.refine || n_images > b.ownerImages) ? 0 : b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
@@ -1601,7 +1602,7 @@ int lsd_grow_waves(int n_images)
     if (n_images <= 1024) return 8;
     if (n_images <= 1536) return 4;      // (8 waves x 1280 images no longer fit the 8192 wave slots: the 1080p batch takes 203 ms with 8, 188 with 4; KITTI size: equal)
     if (n_images <= 2048) return 8;
-    if (n_images <= 3072) return 4;
+    if (n_images <= kMwMaxImages) return 4;
     return 0;      // big batches are throughput bound, and there the one-wave agent does the least work per image
 }
 

@@ -14,23 +14,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("gather", ["overlap", "sync"])
+@pytest.mark.parametrize("gather", ["overlap", "sync", "overlap-strong"])
 def test_two_ranks_on_one_gpu_gather_and_verify(gather):
+    # ("overlap-strong": --scaling strong -- the configuration's batch is the whole job, split over the ranks)
+    strong = gather.endswith("-strong")
+    gather = gather.split("-")[0]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "64", "--distinct", "64", "--steps", "3", "--warmup", "1",
-           "--gather", gather, "--verify", "--no-cpu-baseline", "--no-extras"]
+           "--gather", gather, "--verify", "--no-cpu-baseline", "--no-extras"] + (["--scaling", "strong", "--pairs", "128"] if strong else [])
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout.decode()[-2000:]            # rank 0 prints the one JSON line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if strong else "weak") and d["value"] > 0
     g = d["gather"]
     assert g["verify"] == {"ranks": 2, "identical": True}, g
     assert g["bytes_per_step"] > 64 * 50_000                      # rank 1's trimmed records really travelled (about 0.2 MB per pair)
-    # the whole-job value counts both ranks' pairs
+    # the whole-job value counts both ranks' pairs (strong: 128 pairs split into 64 + 64)
+    assert d["config"]["pairs_per_gpu_per_step"] == 64
     assert abs(d["value"] - 2 * 64 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
     # one line must be enough to diagnose the first real multi-GPU run: every rank's own step time and what rank 0 took in
     pr = d["per_rank_ms_per_step"]
