@@ -990,8 +990,15 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
 {
     // per wave: range buffer + staging area; then lock / counters, the shared stack's five arrays (256 entries, 64 for image groups) and the groups' slots
     const size_t lds = ((size_t)NW * (4 * 64 * NEM + 2 * 64 * NEM) + 4 + 5 * (NI > 1 ? 64 : 256) + 24) * 4;
-    if (lds > 64 * 1024)       // per launch: the attribute belongs to the device the launch goes to
-        OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {     // the attribute belongs to the device the launch goes to: set once per device (the call is a host round trip in front of every one-pair call otherwise)
+        static bool done[64] = {};
+        int dev = 0;
+        OLF_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !done[dev]) {
+            OLF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsd_seedsort_mw<NW, NEM, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) done[dev] = true;
+        }
+    }
     // OLF_SS_TOP=0: the whole recursion inside the per-image workgroup (A/B measurements)
     static const bool top = [] { const char* e = getenv("OLF_SS_TOP"); return !e || atoi(e) != 0; }();
     // (few images only: the grids cover every possible tile of every image at every level -- at 128 images the two forms are level, at 1024 the
@@ -1002,7 +1009,8 @@ static int launch_seedsort_mw(const LineGeom& g, LineDeviceBufs& b, int n_images
     // left (OLF_SS_GROUPS forces 1 .. 8)
     static const int envG = [] { const char* e = getenv("OLF_SS_GROUPS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
     const int Gs = !useTop ? 1 : envG ? envG : n_images <= 16 ? 8 : 4;      // (useTop: at most 64 images; 8 pairs 9.85 against 9.91 ms with 4, 32 pairs 14.0 with 4 against 14.6 with 8)
-    if (Gs > 1) OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));      // (the groups' seed counts meet in an atomicMax)
+    // (the groups' seed counts meet in an atomicMax: the counts start at zero -- launch_lsd_front has cleared them; the debug entry, which comes without a front, has not)
+    if (Gs > 1 && nOverride >= 0) OLF_HIP_CHECK(hipMemsetAsync(b.keyCount, 0, (size_t)n_images * 32 * sizeof(int), s));
     hipLaunchKernelGGL((k_lsd_seedsort_mw<NW, NEM, NI>), dim3(((n_images + NI - 1) / NI) * Gs), dim3(64 * NW), lds, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status,
                        nOverride, kthrOverride, depthOverride, n_images, useTop ? b.topBuf : (int*)nullptr, Gs);
     return OLF_OK;
