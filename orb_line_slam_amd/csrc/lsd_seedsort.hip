@@ -454,14 +454,7 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
     // NI > 1: per image slot the seeds listed so far and its Kthr, behind the stack's arrays
     int* const cntS = shUb + SHCAP; int* const kthS = cntS + 8; int* const okS = kthS + 8;
     int curSlot = NI > 1 ? ssU((int)(threadIdx.x >> 6)) : 0;
-    if (NW == 1) {
-        if (topImg) {
-            // (experiment, OLF_SS_TOP_BATCH: the first levels were partitioned by the grid-wide kernels over the whole batch; the wave starts from the ranges they left)
-            const int nf = min(topImg[2], 48);
-            const int* f = topImg + 8 + 2 * SS_TOP_JOBS * SS_JW;
-            for (int q = nf - 1; q >= 0; --q) SS_PUSH(f[5 * q], f[5 * q + 1], f[5 * q + 2], (uint32_t)f[5 * q + 3], (uint32_t)f[5 * q + 4]);
-        } else SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
-    }
+    if (NW == 1) SS_PUSH(0, n, depth0, 0u, (uint32_t)(g.nBins - 1));
     else if (NI == 1) {
         if (threadIdx.x == 0) {
             ctl[0] = 0; ctl[2] = 0; ctl[3] = 0;
@@ -642,13 +635,12 @@ __device__ __forceinline__ void ss_sort_image(const LineGeom& g, int img, int n_
 }
 
 __global__ __launch_bounds__(64) void k_lsd_seedsort(const LineGeom* __restrict__ gp, uint32_t* keysInAll, uint32_t* keysOutAll, int* __restrict__ keyCount,
-                                                     const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride, int* topAll)
+                                                     const int* __restrict__ maxN, int* __restrict__ status, int nOverride, int kthrOverride, int depthOverride)
 {
     __shared__ __align__(8) uint32_t s_buf[SS_CAP];
     __shared__ __align__(8) uint32_t s_x[4 * 64 * SS_NE_LDS];      // LDS path: the two stopper queues; memory path: the two staged blocks
     static_assert(4 * 64 * SS_NE_MEM <= SS_CAP && 2 * 64 * SS_NE_MEM <= 4 * 64 * SS_NE_LDS, "memory path: queues in the range buffer, staged blocks in s_x");
-    ss_sort_image<1, SS_NE_MEM>(*gp, blockIdx.x, gridDim.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, nullptr,
-                                topAll ? topAll + (size_t)blockIdx.x * SS_TOP_WORDS : nullptr);
+    ss_sort_image<1, SS_NE_MEM>(*gp, blockIdx.x, gridDim.x, keysInAll, keysOutAll, keyCount, maxN, status, nOverride, kthrOverride, depthOverride, s_buf, s_x, nullptr);
 }
 
 // few images (the drop-in's online shape: one stereo pair per call): NW waves per image, blocks of NEM tiles
@@ -944,7 +936,7 @@ __global__ __launch_bounds__(SS_SCAN_NT) void k_top_scan(int* __restrict__ topAl
 
 // children of every job: [cut, last) with K >= Kp, [first, cut) with K <= Kp (the pivot sits at first)
 // ... and, unless this was the last level, the pivots of the next level's jobs in the same launch (one launch boundary less per level)
-__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topAll, int level, int* __restrict__ status, uint32_t* keysAll, size_t Ps, int levels)
+__global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topAll, int level, int* __restrict__ status, uint32_t* keysAll, size_t Ps)
 {
     __shared__ int s_next, s_fin;
     const int img = blockIdx.x, j = threadIdx.x;
@@ -956,20 +948,20 @@ __global__ __launch_bounds__(SS_TOP_JOBS) void k_top_next(int* __restrict__ topA
         const int* q = t.jobs + j * SS_JW;
         const int first = q[0], last = q[1], depth = q[2], cut = q[9];
         const uint32_t lb = (uint32_t)q[3], ub = (uint32_t)q[4], Kp = (uint32_t)q[5], Kthr = (uint32_t)t.cnt[4];
-        const bool lastLevel = level == levels - 1;
+        const bool lastLevel = level == SS_TOP_LEVELS - 1;
         ss_top_child(t, &s_next, &s_fin, cut, last, depth, max(lb, Kp), ub, Kthr, lastLevel, status);
         ss_top_child(t, &s_next, &s_fin, first, cut, depth, lb, min(ub, Kp), Kthr, lastLevel, status);
     }
     __syncthreads();
     if (j == 0) { t.cnt[0] = min(s_next, SS_TOP_JOBS); t.cnt[2] = min(s_fin, SS_TOP_FINAL); t.cnt[3] = 0; }
-    if (level == levels - 1) return;
+    if (level == SS_TOP_LEVELS - 1) return;
     __syncthreads();
     ss_top_pivot_body(topAll, keysAll, Ps, level + 1, img, j);
 }
 
 int lsd_seedsort_top_words() { return SS_TOP_WORDS; }
 
-static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride, int levels = SS_TOP_LEVELS)
+static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride)
 {
     const int n = nOverride >= 0 ? nOverride : (g.Ws - 1) * (g.Hs - 1);
     const int maxTiles = n / 64 + SS_TOP_JOBS + 2, half = maxTiles + SS_TOP_JOBS + 2;
@@ -982,13 +974,13 @@ static int launch_seedsort_top(const LineGeom& g, LineDeviceBufs& b, int n_image
     hipLaunchKernelGGL(k_top_init, dim3(n_images), dim3(64), 0, s, b.geom, b.topBuf, b.maxN, nOverride, kthrOverride, depthOverride, b.status, topMin);
     if (n < topMin) return OLF_OK;       // (the root is a final entry)
     const dim3 tg((maxTiles + 3) / 4, n_images);
-    for (int level = 0; level < levels; ++level) {
+    for (int level = 0; level < SS_TOP_LEVELS; ++level) {
         if (level == 0) hipLaunchKernelGGL(k_top_pivot, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, b.keysA, (size_t)g.Ps, level);
         hipLaunchKernelGGL(k_top_tiles<0>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_scan, dim3(SS_TOP_JOBS, n_images), dim3(SS_SCAN_NT), 0, s, b.topBuf, b.keysA, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_tiles<1>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
         hipLaunchKernelGGL(k_top_tiles<2>, tg, dim3(256), 0, s, b.topBuf, b.keysA, b.keysB, b.region, (size_t)g.Ps, stride, half, level);
-        hipLaunchKernelGGL(k_top_next, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, level, b.status, b.keysA, (size_t)g.Ps, levels);
+        hipLaunchKernelGGL(k_top_next, dim3(n_images), dim3(SS_TOP_JOBS), 0, s, b.topBuf, level, b.status, b.keysA, (size_t)g.Ps);
     }
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
@@ -1050,13 +1042,8 @@ int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipS
     else if (mode == 5) rc = launch_seedsort_mw<2, 8, 1>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 3) rc = launch_seedsort_grp<4>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
     else if (mode == 4) rc = launch_seedsort_grp<8>(g, b, n_images, s, nOverride, kthrOverride, depthOverride);
-    else {
-        // OLF_SS_TOP_BATCH=L (experiment): the first L partition levels of every image of the BATCH as grid-wide dense passes, the one-wave agent below them
-        static const int topBatch = [] { const char* e = getenv("OLF_SS_TOP_BATCH"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 3 ? v : 0; }();
-        int* top = nullptr;
-        if (topBatch && b.topBuf && nOverride < 0) { rc = launch_seedsort_top(g, b, n_images, s, nOverride, kthrOverride, depthOverride, topBatch); if (rc != OLF_OK) return rc; top = b.topBuf; }
-        hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride, top);
-    }
+    else
+        hipLaunchKernelGGL(k_lsd_seedsort, dim3(n_images), dim3(64), 0, s, b.geom, b.keysA, b.keysB, b.keyCount, b.maxN, b.status, nOverride, kthrOverride, depthOverride);
     if (rc != OLF_OK) return rc;
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
