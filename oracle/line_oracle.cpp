@@ -73,16 +73,26 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 static thread_local int t_libm_float = 0;
 struct LibmScope { int prev; explicit LibmScope(int v) : prev(t_libm_float) { t_libm_float = v; } ~LibmScope() { t_libm_float = prev; } };
 
+// (t_grow_iters / t_grow_first: statistics for tools/ only -- the number of batches of <= 8 FIFO entries the device agent's schedule needs for this
+// region, and the region's size after its first FIFO entry)
+static thread_local int t_grow_iters = 0, t_grow_first = 0, t_grow_itersW[3] = {0, 0, 0}, t_grow_prefW[3] = {0, 0, 0};
+static thread_local std::vector<int> t_size_at;
 static void region_grow(LsdState& S, int addr0, std::vector<RegionPoint>& reg, double& reg_angle, double prec)
 {
     const int W = S.w, H = S.h;
     reg.clear();
+    t_grow_iters = 0; t_grow_first = 0;
+    size_t batch_end = 0;
+    t_size_at.clear();
     reg_angle = S.angles[addr0];
     reg.push_back({addr0 % W, addr0 / W, reg_angle, S.modgrad[addr0]});
     float sumdx = float(std::cos(reg_angle));
     float sumdy = float(std::sin(reg_angle));
     S.used[addr0] = 1;
     for (size_t i = 0; i < reg.size(); ++i) {
+        if (i == batch_end) { ++t_grow_iters; batch_end = i + std::min<size_t>(8, reg.size() - i); }
+        if (i == 1) t_grow_first = (int)reg.size();
+        t_size_at.push_back((int)reg.size());
         const int rx = reg[i].x, ry = reg[i].y;
         const int xx_min = std::max(rx - 1, 0), xx_max = std::min(rx + 1, W - 1);
         const int yy_min = std::max(ry - 1, 0), yy_max = std::min(ry + 1, H - 1);
@@ -102,6 +112,14 @@ static void region_grow(LsdState& S, int addr0, std::vector<RegionPoint>& reg, d
                 }
             }
         }
+    }
+    // a window phase that handles the leading FIFO entries within Chebyshev distance D of the seed without a gather: the batches left to the general loop
+    for (int D = 1; D <= 3; ++D) {
+        size_t i0 = 0;
+        while (i0 < reg.size() && std::max(std::abs(reg[i0].x - reg[0].x), std::abs(reg[i0].y - reg[0].y)) <= D) ++i0;
+        int it = 0;
+        for (size_t i = i0; i < reg.size(); ) { ++it; i += std::min<size_t>(8, t_size_at[i] - i); }
+        t_grow_itersW[D - 1] = it; t_grow_prefW[D - 1] = (int)i0;
     }
 }
 
@@ -450,7 +468,8 @@ void lsd_detect(const Image& image, const olf_line_params& P, std::vector<Vec4f>
         if (S.used[addr0] || S.angles[addr0] == NOTDEF) continue;
         double reg_angle;
         region_grow(S, addr0, reg, reg_angle, prec);
-        if (region_sizes) region_sizes->push_back((int)reg.size());
+        if (region_sizes) { region_sizes->push_back((int)reg.size()); region_sizes->push_back(t_grow_iters); region_sizes->push_back(reg.size() > 1 ? t_grow_first : 1);
+                            for (int D = 0; D < 3; ++D) { region_sizes->push_back(t_grow_itersW[D]); region_sizes->push_back(t_grow_prefW[D]); } }
         if ((int)reg.size() < min_reg_size) continue;
         Rect rec;
         region2rect(reg, reg_angle, prec, p, rec);

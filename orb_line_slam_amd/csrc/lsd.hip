@@ -830,6 +830,14 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // window ahead; a flush of the pending table first folds the table into the seed masks, so no window is ever gathered twice), 2 = the rows above and
 // below every live seed of a window are requested when the window starts (a region's first 3x3 gather then finds them in the cache instead of in HBM),
 // 4 = the row beyond every candidate of a growth step is requested beside its table entry (the next step's gather).
+// 8 = the WINDOW PHASE of a region start (round 6): the 7 x 7 pixels around the seed are gathered ONCE, one lane per pixel (word, pending-table slot, table
+// entry), and the leading FIFO entries -- every entry within Chebyshev distance 2 of the seed, whose 3 x 3 lies inside the window -- are replayed from
+// registers: the candidates of an entry are (3 x 3 mask << lane) & live & aligned, lane order inside the window IS the reference's raster order, an accept
+// is the plain sequential step, an entry without candidates costs a handful of scalar instructions instead of a gather.  The accepted pixels are published
+// in one batch (USED bits, pending table; ring and log only if the region goes on or reaches minRegSize).  The general loop takes over at the first entry
+// on the window's outer ring, or when OLF_WIN_MAXPEND entries are pending (there its 8 entries per gather and its speculative rounds pay).  On the bench
+// scene 10.4 k regions per image have 8.4 k non-isolated starts; 6.9 k of them end inside the window (tools/grow_region_model.py), and the general loop's
+// 38.5 k iterations per image become 8.4 k window gathers + < 20 k iterations.
 template <int REFINE, int PF>      // REFINE 0: LSD_REFINE_NONE, 1: STD, 2: ADV
 // (REFINE = 2: rect_improve / rect_nfa / nfa inlined with the AgentRect in registers need 200 VGPRs: two agents per SIMD, no scratch, no generic-pointer
 // loads; as four out-of-line functions with a stack object they were 128 VGPRs + 496 B of scratch -- 16 % slower up to 2048 images, 7 % faster at 4096)
@@ -856,6 +864,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec, precWrap = g.precWrap;
+    // (copies: read through `g` inside the seed loop they are loaded again for every region -- the stores in between may alias the geometry block)
+    const int minRegSize = g.minRegSize, maxRegions = g.maxRegions;
+    const uint32_t divM = g.divWsM; const int divS = g.divWsS;
 // (the table is cleared with 16-byte LDS stores: 4 instructions instead of a 16-trip loop of 7 -- a flush happens 1.5 k times per image)
 #define PEND_CLEAR() do { _Pragma("unroll") for (int _i = 0; _i < PEND / 256; ++_i) reinterpret_cast<int4*>(s_pend)[_i * 64 + lane] = make_int4(-1, -1, -1, -1); } while (0)
     PEND_CLEAR();
@@ -882,7 +893,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #else
 #define ST_FLUSH
 #endif
-    constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4);
+    constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4), WIN = !REFINE && (PF & 8);
+#ifndef OLF_WIN_MAXPEND
+#define OLF_WIN_MAXPEND 8
+#endif
+    // window phase: lane L < 49 is pixel (seed.x + L % 7 - 3, seed.y + L / 7 - 3)
+    constexpr unsigned long long kW49 = (1ull << 49) - 1ull, kSeedBit = 1ull << 24, kM3 = 7ull | (7ull << 7) | (7ull << 14);
+    constexpr unsigned long long kRow5 = 0x3eull, kD2 = (kRow5 << 7) | (kRow5 << 14) | (kRow5 << 21) | (kRow5 << 28) | (kRow5 << 35);      // rows, columns 1 .. 5
+    const int wdr = lane / 7 - 3, wdc = lane % 7 - 3, woff = wdr * g.Ws + wdc;
 // PIPE: what the table holds is folded into the seed masks of the current and of the next window before it is cleared -- the masks then stay complete
 // (a window's words as loaded + every pixel marked since), and a window is never gathered again
 #define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; \
@@ -946,10 +964,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
         float2 seedSum = make_float2(0.f, 0.f);
         if (wave_bit(mask) && !isoSeed) { const AngEnt* t = ent + (wseed & 0x3fffffu); seedAng = t->ang; seedSum = t->seed; }
         unsigned long long tabM = mask;      // lanes whose table entries are loaded (REFINE: the mask can gain lanes)
+        const unsigned long long isoWin = wave_vote(isoSeed);
         while (mask) {
             // isolated seeds ahead of the first growable one are one-pixel regions: mark them all at once
-            {
-                const unsigned long long isoM = wave_vote(isoSeed) & mask;
+            if (const unsigned long long isoM = isoWin & mask) {      // (nothing to do -- and three instructions -- for a window without isolated seeds left)
                 const unsigned long long grow = mask & ~isoM;
                 const unsigned long long lead = isoM & (grow ? ((1ull << __builtin_ctzll(grow)) - 1ull) : ~0ull);
                 if (lead) {
@@ -958,7 +976,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                     if (wave_vote(mine && s_pend[slot] != -1)) PEND_FLUSH();
                     if (mine) { grad[addr] = wseed | kUsed; s_pend[slot] = addr; }
                     __builtin_amdgcn_wave_barrier();
-                    if (wave_vote(mine && s_pend[slot] != addr)) PEND_FLUSH();
+                    { unsigned long long bad = wave_vote(mine && s_pend[slot] != addr);
+                      while (bad) { PEND_FLUSH(); if (wave_bit(bad)) s_pend[slot] = addr; __builtin_amdgcn_wave_barrier(); bad = wave_vote(wave_bit(bad) && s_pend[slot] != addr); } }
                     mask &= ~lead;
                     if (!mask) break;
                 }
@@ -981,21 +1000,86 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             n = 1;
             reg_angle = rlane_d(seedAng, l);
             float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
-            MARK_USED(seed, pseed);
-            if (lane == 0) { const uint32_t pk = (uint32_t)(seed % Ws) | ((uint32_t)(seed / Ws) << 16); s_ring[0] = pk; reg[rbase] = make_uint2(pk, pseed); }
-            __builtin_amdgcn_wave_barrier();
+            // (seed / Ws through the host's exact multiply-shift pair: 4 scalar instructions where the compiler's division by a run-time value takes 20)
+            const uint32_t sy0 = __umulhi((uint32_t)seed, divM) >> divS, sx0 = (uint32_t)seed - sy0 * (uint32_t)Ws;
+            int i = 0;
+            if (WIN) {
+                // ---- window phase: gather the 7 x 7 around the seed, one lane per pixel
+                const int wx = (int)sx0 + wdc, wy = (int)sy0 + wdr;
+                const unsigned long long winIn = kW49 & wave_vote((unsigned)wx < (unsigned)Ws) & wave_vote((unsigned)wy < (unsigned)Hs);
+                const int wa = wave_bit(winIn) ? seed + woff : 0;
+                const uint32_t ww = grad[(uint32_t)wa];
+                const int wslot = wa & (PEND - 1);
+                const int wpend = s_pend[wslot];
+                unsigned long long live = winIn & wave_vote(!(ww & (kUsed | kNotDef))) & wave_vote(wpend != wa) & ~kSeedBit;
+                double wang, wcs, wsn;
+                asm volatile("" : "=v"(wang), "=v"(wcs), "=v"(wsn));
+                if (wave_bit(live)) { const AngEnt* t = ent + (ww & 0x3fffffu); wcs = t->cs; wsn = t->sn; wang = t->ang; }
+                int fidx = lane == 24 ? 0 : -1;          // this pixel's place in the FIFO
+                unsigned long long accM = kSeedBit;      // the region's pixels inside the window
+#ifdef OLF_STATS
+                ++st_first; st_cand1 += __popcll(live);
+#endif
+#define WIN_ALIGNED() ({ const double _n = fabs(d_sub(reg_angle, wang)); live & (wave_vote(_n <= prec) | wave_vote(_n >= precWrap)); })
+                unsigned long long la = WIN_ALIGNED();
+                bool handover = false;
+                for (;;) {
+                    const int p = __builtin_ctzll(wave_vote(fidx == i));
+                    // an entry on the outer ring looks outside the window; a long FIFO is what the general loop's 8 entries per gather are for
+                    if (!((kD2 >> p) & 1ull) || n - i >= OLF_WIN_MAXPEND) { handover = true; break; }
+                    const unsigned long long nbr = kM3 << (p - 8);
+                    unsigned long long cm = nbr & la;
+                    while (cm) {
+                        const int c = __builtin_ctzll(cm);
+                        const unsigned long long bit = 1ull << c;
+                        live &= ~bit; accM |= bit;
+                        fidx = wave_bit(bit) ? n : fidx;
+                        ++n;
+                        const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
+                        sumdx = (float)d_add((double)sumdx, cs_c);
+                        sumdy = (float)d_add((double)sumdy, sn_c);
+                        reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                        la = WIN_ALIGNED();
+                        cm = nbr & la & ~((2ull << c) - 1ull);      // the entry's later neighbours, under the new angle
+                    }
+                    if (++i == n) break;
+                }
+#undef WIN_ALIGNED
+#ifdef OLF_STATS
+                st_acc1 += n - 1; st_iters += i;
+#endif
+                // ---- publish the batch: USED bits + pending table; FIFO ring and log only where somebody will read them
+                const bool mine = wave_bit(accM);
+                if (wave_vote(wpend != -1) & accM) PEND_FLUSH();
+                if (mine) { grad[wa] = ww | kUsed; s_pend[wslot] = wa; }
+                __builtin_amdgcn_wave_barrier();
+                { unsigned long long bad = wave_vote(mine && s_pend[wslot] != wa);
+                  while (bad) { PEND_FLUSH(); if (wave_bit(bad)) s_pend[wslot] = wa; __builtin_amdgcn_wave_barrier(); bad = wave_vote(wave_bit(bad) && s_pend[wslot] != wa); } }
+                if (handover || n >= minRegSize) {
+                    if (mine) { const uint32_t xy = (uint32_t)wx | ((uint32_t)wy << 16); s_ring[fidx & (RING - 1)] = xy; reg[rbase + fidx] = make_uint2(xy, ww); }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                MARK_USED(seed, pseed);
+                if (lane == 0) { const uint32_t pk = sx0 | (sy0 << 16); s_ring[0] = pk; reg[rbase] = make_uint2(pk, pseed); }
+                __builtin_amdgcn_wave_barrier();
+            }
 #ifdef OLF_TIMING
             { long long t1 = __builtin_readcyclecounter(); t_seed += t1 - t0; t0 = t1; }
 #endif
-            int i = 0;
             // the check that two pixels accepted in one iteration did not hash to one table slot is read back after the commit's writes but only
             // looked at below the next iteration's ring read (one LDS round trip less on the agent's dependent chain)
             bool chkOn = false;
             int chkA = -1, chkV = -1;
-#define PEND_VERIFY() do { if (chkOn) { if (wave_vote(chkV != chkA)) PEND_FLUSH(); chkOn = false; } } while (0)
+// (a pixel that lost its slot to another pixel of the same batch is entered again once the table has been flushed: the table -- and with it the seed masks
+// a flush folds it into -- must hold EVERY pixel marked since the window's words were loaded)
+#define PEND_VERIFY() do { if (chkOn) { unsigned long long _bad = wave_vote(chkV != chkA); \
+                               while (_bad) { PEND_FLUSH(); const int _s = chkA & (PEND - 1); if (wave_bit(_bad)) s_pend[_s] = chkA; __builtin_amdgcn_wave_barrier(); \
+                                              _bad = wave_vote(wave_bit(_bad) && s_pend[_s] != chkA); } \
+                               chkOn = false; } } while (0)
             while (i < n) {
 #ifdef OLF_TIMING
-                if (n >= g.minRegSize) ++it_big; else ++it_small;
+                if (n >= minRegSize) ++it_big; else ++it_small;
 #endif
                 const int nb = min(8, n - i);
                 const int e = lane >> 3, k = (lane & 7) + ((lane & 7) >= 4 ? 1 : 0);      // 8 FIFO entries x 8 neighbours (k = 4 is the entry's own pixel)
@@ -1009,7 +1093,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ps = __builtin_readcyclecounter(); ++p_n;
 #endif
                 // candidates as lane masks (scalar registers) from here on: lane 8 e + j looks at neighbour j of FIFO entry e, the first nb entries count
-                const unsigned long long geo = nb == 8 ? ~0ull : (1ull << (8 * nb)) - 1ull;
+                const unsigned long long geo = ~0ull >> (64 - 8 * nb);      // (nb in [1, 8]: one shift instead of shift + not + two selects)
                 // (the ring read is unconditional and the memory read a rare wave-uniform branch: as one conditional expression the two became a
                 // generic-pointer flat load, in front of which the compiler waits for the previous iteration's stores to be acknowledged)
                 uint32_t rp = s_ring[(i + e) & (RING - 1)];
@@ -1166,7 +1250,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             if (!REFINE) break;
             const uint2* lg = reg + rbase;
             if (!regrown) {
-                if (n < g.minRegSize) break;
+                if (n < minRegSize) break;
                 __threadfence_block();                       // the log of this region is read back from memory
                 rec = agent_region2rect(lg, n, reg_angle, prec);
                 if (agent_density(n, rec) >= g.densityTh) { accept = true; break; }
@@ -1237,22 +1321,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                     if (agent_rect_improve(g, grad, ent, rec, lane) <= g.logEps) accept = false;
                 }
                 if (accept) {
-                    if (nreg < g.maxRegions) {
+                    if (nreg < maxRegions) {
                         const SegCand cnd = rect_to_cand(g, rec.x1, rec.y1, rec.x2, rec.y2);
                         if (lane == 0) {
-                            candAll[(size_t)img * g.maxRegions + nreg] = cnd;
+                            candAll[(size_t)img * maxRegions + nreg] = cnd;
                         }
                         ++nreg;
                     } else if (lane == 0) atomicOr(status, 8);
                 }
             }
 #ifdef OLF_TIMING
-            { long long t1 = __builtin_readcyclecounter(); if (n >= g.minRegSize) { t_big += t1 - t0; ++n_big; } else { t_small += t1 - t0; ++n_small; } t0 = t1; }
+            { long long t1 = __builtin_readcyclecounter(); if (n >= minRegSize) { t_big += t1 - t0; ++n_big; } else { t_small += t1 - t0; ++n_small; } t0 = t1; }
 #endif
-            if (!REFINE && n >= g.minRegSize) {
+            if (!REFINE && n >= minRegSize) {
                 // a region large enough to become a segment: keep its pixel list (the log only moves forward for these) and record
                 // (start, size, final region angle); k_lsd_rect fits all rectangles of the batch in parallel afterwards
-                if (nreg < g.maxRegions) {
+                if (nreg < maxRegions) {
                     if (lane == 0) {
                         RegionRec rr; rr.start = rbase; rr.n = n; rr.angle = reg_angle;
                         recs[nreg] = rr;
@@ -1266,7 +1350,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #endif
             // seeds later in this 64-key window may have been consumed by the region just grown
 #ifdef OLF_STATS
-            st_acc += n; if (n >= g.minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(wave_vote(valid && lane > l));
+            st_acc += n; if (n >= minRegSize) st_logged += n; if (n > 1) st_regl += __popcll(wave_vote(valid && lane > l));
 #endif
             if (REFINE && maskEpoch != flushEpoch) {
                 // pixels may have been given back since the window was loaded (refine un-uses whole regions): seeds of this window that were USED
@@ -1634,10 +1718,10 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         hipLaunchKernelGGL((k_lsd_grow<1, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
     else {
-        static const int pf = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 3; }();
+        static const int pf = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 11; }();
 #define GROW0(PFV) hipLaunchKernelGGL((k_lsd_grow<0, PFV>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr)
-        if (pf == 0) GROW0(0); else if (pf == 1) GROW0(1); else if (pf == 7) GROW0(7); else GROW0(3);
+        if (pf == 0) GROW0(0); else if (pf == 1) GROW0(1); else if (pf == 7) GROW0(7); else if (pf == 3) GROW0(3); else GROW0(11);
 #undef GROW0
     }
     OLF_HIP_CHECK(hipGetLastError());
