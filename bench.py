@@ -123,6 +123,8 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
     from orb_line_slam_amd import synth
     times, stages, t_all, seed = [], [], time.time(), 1000
     L.orc_frame_stage_ms.argtypes = [C.c_void_p]
+    L.orc_frame_orb_stage_ms.argtypes = [C.c_void_p]
+    orb12, orb_stages = np.zeros(12, np.float64), []
     WARM, TIMED = 20, 200                       # at least 200 timed frames after 20 warm-up frames
     st8 = np.zeros(8, np.float64)
     while len(times) < WARM + TIMED:
@@ -137,11 +139,14 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
         assert rc == 0
         L.orc_frame_stage_ms(st8.ctypes.data_as(C.c_void_p))
         stages.append(st8.copy())
+        L.orc_frame_orb_stage_ms(orb12.ctypes.data_as(C.c_void_p))
+        orb_stages.append(orb12.copy())
         if time.time() - t_all > max(seconds_budget, 10.0) * 3 and len(times) >= WARM + 20:      # a very slow host: keep the default run bounded
             break
     times = np.array(times[WARM:]); stages = np.array(stages[WARM:])
     med = float(np.median(times))
     sm = np.median(stages, axis=0)
+    om = np.median(np.array(orb_stages[WARM:]), axis=0)
     out = {"value": round(1.0 / med, 3), "unit": "stereo frames/s", "cores": 4, "kind": "port",
            "sample": f"{len(times)} synthetic {W}x{H} stereo pairs after {WARM} warm-up frames, one at a time, 4 threads/frame like src/Frame.cc:164-171, "
                      f"median {med * 1e3:.1f} ms/frame (mean {times.mean() * 1e3:.1f}, p95 {np.percentile(times, 95) * 1e3:.1f})",
@@ -149,7 +154,9 @@ def cpu_baseline(W, H, params, seconds_budget=20.0):
            # wall time per stage, median over the timed frames (the four extractions run concurrently on their own threads, the two stereo
            # matchers after them on the calling thread): the frame time is about max(extractions) + stereo points + stereo lines
            "stages_ms": {"orb_left": round(sm[0], 2), "orb_right": round(sm[1], 2), "lsd_left": round(sm[2], 2), "lbd_left": round(sm[3], 2),
-                         "lsd_right": round(sm[4], 2), "lbd_right": round(sm[5], 2), "stereo_points": round(sm[6], 2), "stereo_lines": round(sm[7], 2)}}
+                         "lsd_right": round(sm[4], 2), "lbd_right": round(sm[5], 2), "stereo_points": round(sm[6], 2), "stereo_lines": round(sm[7], 2),
+                         # orb_left by stage (the port's FAST has FAST_t<16>'s opposite-pair pre-test since round 6)
+                         **{"orb_left_" + k: round(float(om[i]), 2) for i, k in enumerate(("pyramid", "fast", "octree", "ic_angle", "blur", "rbrief"))}}}
     # Mode B: throughput, one whole frame per thread at a time (threads = 1 inside a frame), at 1, 4, 16, 64, ... all host threads: does it scale?
     try:
         cores = len(os.sched_getaffinity(0))
@@ -337,8 +344,9 @@ def main():
     # synthetic input: `distinct` seeded pairs per rank, tiled to B pairs, resident in HBM before timing
     nd = min(args.distinct, B)
 
-    def make_input(r, run_len=None):
+    def make_input(r, run_len=None, scene=None):
         run_len = args.sequence if run_len is None else run_len
+        scene = args.scene if scene is None else scene
         if seq is not None:
             # every rank reads its own contiguous share of the recording (frame-sharded like SURVEY 8(e)), tiled to B pairs when it is shorter
             from orb_line_slam_amd.distributed import shard_range
@@ -347,7 +355,7 @@ def main():
             host = np.concatenate([b for b, _ in sub_seq.batches(B)]).reshape(-1, 2, H, W)
             reps = (B + len(host) - 1) // len(host)
             return torch.from_numpy(np.tile(host, (reps, 1, 1, 1))[:B].reshape(2 * B, H, W).copy()).to(dev)
-        host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=args.scene)
+        host = synth.stereo_batch(7000 + 100000 * r, nd, W, H, scene=scene)
         if run_len > 1:
             # runs of consecutive frames: frame k of run j = scene j (both images) shifted by 2k pixels -- related frames for the frame-to-frame matchers
             R = run_len
@@ -508,7 +516,7 @@ def main():
 
     # the companion line: the same step on runs of six consecutive frames of one scene, so that the frame-to-frame matchers (SearchByBoW, LBD match) meet related
     # frames as they do on a recording -- SURVEY 8(d)'s generator (independent scenes) is the headline, this is what it leaves out
-    companion = None
+    companion, companion_long = None, None
     if rank == 0 and world == 1 and not args.no_extras and seq is None and args.sequence == 0 and B > 1:
         keep = imgs
         imgs = make_input(rank, 6)
@@ -521,6 +529,24 @@ def main():
                      "unit": "stereo frames/s"}
         if voc is not None:
             companion["search_by_bow_mean_matches"] = round(float(f2f_n[:B - 1].float().mean().item()), 1)
+        # the second companion: long thin bars -> key lines of about 0.08 * W pixels, SURVEY App. D's model of a street scene (the headline's scene makes
+        # key lines a third as long); the line-length-sensitive stages -- growth of long regions, rectangle fit, LBD -- with their times in the step
+        # 
+        if args.scene == "default":
+            imgs = make_input(rank, 0, "bars")
+            run_steps(1); barrier()
+            ctx.profile(True)
+            tq = time.perf_counter()
+            run_steps(3); barrier()
+            dq = (time.perf_counter() - tq) / 3
+            ctx.synchronize()
+            pq = ctx.profile_read(); ctx.profile(False)
+            nq = min(64, 2 * B)
+            klq = kls[:nq].cpu().numpy().view(ola.KEYLINE_DTYPE).reshape(nq, lcap); lcq = lcounts[:nq].cpu().numpy()
+            companion_long = {"workload": "long thin bars (bench.py --scene bars)", "steps": 3, "ms_per_step": round(dq * 1e3, 3), "value": round(B / dq, 1), "unit": "stereo frames/s",
+                              "mean_line_pixels": round(float(np.mean([klq[i, :lcq[i]]["numOfPixels"].mean() for i in range(nq) if lcq[i] > 0])), 1),
+                              "survey_appD_line_pixels": round(0.08 * W, 1), "mean_keylines_per_image": round(float(lcounts.float().mean().item()), 1),
+                              "stages_ms_per_step": {k: round(v[0] / 3, 3) for k, v in pq.items() if v[1] and k in ("lsd_front", "lsd_grow", "lsd_rect", "line_select_lbd", "stereo_lines")}}
         imgs = keep
         run_steps(1); barrier()             # (the outputs the checks below read belong to the headline input again)
 
@@ -668,6 +694,8 @@ def main():
                 print(f"copy ceiling failed: {e}", file=sys.stderr)
     if rank == 0 and out is not None and companion is not None:
         out["companion_sequence6"] = companion
+    if rank == 0 and out is not None and companion_long is not None:
+        out["companion_long_lines"] = companion_long
     if rank == 0 and out is not None and voc is not None:
         out["config"]["search_by_bow_mean_matches"] = round(float(f2f_n[:B - 1].float().mean().item()), 1)
     del imgs, kps, desc, ur, dp, kls, ldesc, lm, ldisp, lle, f2f_lines, f2f_orb
@@ -691,7 +719,12 @@ def main():
             except Exception as e:
                 out["pcie_inclusive"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(W, H, params, args.cpu_seconds)
+            out["cpu_baseline"] = cb = cpu_baseline(W, H, params, args.cpu_seconds)
+            # the GPU figure against both CPU shapes, side by side: Mode A = the reference's own (one frame at a time, 4 threads), Mode B = the box's
+            # cores all busy with whole frames; and the drop-in's online shape (one pair per call) against Mode A's frame time
+            cb["gpu_over_cpu"] = {"batched_vs_mode_a": round(out["value"] / cb["value"], 1),
+                                  "batched_vs_mode_b": round(out["value"] / cb["mode_b"]["value"], 1) if cb.get("mode_b", {}).get("value") else None,
+                                  "one_pair_vs_mode_a": round(1e3 / cb["value"] / out["pair_latency_ms"]["1"], 2) if isinstance(out.get("pair_latency_ms", {}).get("1"), float) else None}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -24,6 +24,8 @@ void stereo_lines(const std::vector<olf_keyline>& klL, const uint8_t* descL, con
 #include <atomic>
 #include <chrono>
 thread_local double g_frame_stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_frame_orb_stage_ms[12] = {0};      // orb_extract's six stages (orb_oracle.cpp g_orb_stage_ms), left then right image
+namespace orc { extern thread_local double g_orb_stage_ms[6]; }
 namespace orc { extern thread_local double g_line_stage_ms[2]; }
 using namespace orc;
 
@@ -72,8 +74,9 @@ int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, con
     // wall time per stage (ms) of this frame: ORB L, ORB R, LSD L, LBD L, LSD R, LBD R, stereo points, stereo lines (g_frame_stage_ms)
     double* st = g_frame_stage_ms;
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    auto f0 = [&] { const auto t = std::chrono::steady_clock::now(); orb_extract(L, p->orb, rl); st[0] = ms_since(t); };
-    auto f1 = [&] { const auto t = std::chrono::steady_clock::now(); orb_extract(R, p->orb, rr); st[1] = ms_since(t); };
+    double* ost = g_frame_orb_stage_ms;      // (the extractions may run on their own threads: their thread-local stage times are copied out there)
+    auto f0 = [&, ost] { const auto t = std::chrono::steady_clock::now(); orb_extract(L, p->orb, rl); st[0] = ms_since(t); for (int i = 0; i < 6; ++i) ost[i] = g_orb_stage_ms[i]; };
+    auto f1 = [&, ost] { const auto t = std::chrono::steady_clock::now(); orb_extract(R, p->orb, rr); st[1] = ms_since(t); for (int i = 0; i < 6; ++i) ost[6 + i] = g_orb_stage_ms[i]; };
     auto f2 = [&] { line_extract(L, p->line, false, kl, dl, nullptr); st[2] = g_line_stage_ms[0]; st[3] = g_line_stage_ms[1]; };
     auto f3 = [&] { line_extract(R, p->line, false, kr, dr, nullptr); st[4] = g_line_stage_ms[0]; st[5] = g_line_stage_ms[1]; };
     if (threads >= 4) {
@@ -112,6 +115,8 @@ int orc_stereo_frame(const uint8_t* imgL, const uint8_t* imgR, int w, int h, con
 
 // the stage times of the calling thread's last orc_stereo_frame (8 doubles, see there)
 void orc_frame_stage_ms(double* out8) { for (int i = 0; i < 8; ++i) out8[i] = g_frame_stage_ms[i]; }
+// orb_extract's stages of the same frame: pyramid, FAST, octree, IC_Angle, blur, rBRIEF -- left image, then right (12 doubles)
+void orc_frame_orb_stage_ms(double* out12) { for (int i = 0; i < 12; ++i) out12[i] = g_frame_orb_stage_ms[i]; }
 
 // cpu_baseline "mode B" of bench.py: n_threads workers, each running whole frames (the four extractions back to back) taken from a shared
 // counter, over n_frames frames cycling through n_distinct stereo pairs (imgs: [2 * n_distinct][h][w]); returns stereo frames per second

@@ -11,6 +11,7 @@
 // key-point counts are expanded most-recently-created first.
 #include "oracle_common.hpp"
 #include "orb_oracle.hpp"
+#include <chrono>
 #include <list>
 #include <utility>
 
@@ -105,20 +106,42 @@ static void fast9_16(const Image& img, int x0, int y0, int x1, int y1, int thres
     if (w < 7 || h < 7) return;
     threshold = std::min(std::max(threshold, 0), 255);
     std::vector<uint8_t> score((size_t)w * h, 0);
-    for (int y = 3; y < h - 3; ++y)
+    // ring offsets in this image's stride, and the darker / brighter class of every difference (FAST_t<16>'s threshold_tab: 1 = darker than v - t,
+    // 2 = brighter than v + t)
+    int off[25];
+    for (int k = 0; k < 25; ++k) off[k] = kRing[k % 16][1] * img.w + kRing[k % 16][0];
+    uint8_t tab[512];
+    for (int i = -255; i <= 255; ++i) tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+    for (int y = 3; y < h - 3; ++y) {
+        const uint8_t* rowp = img.row(y0 + y) + x0;
         for (int x = 3; x < w - 3; ++x) {
-            const int v = img.at(x0 + x, y0 + y);
+            const uint8_t* ptr = rowp + x;
+            const int v = ptr[0];
+            const uint8_t* t = tab + 255 - v;      // t[ring value] = class of (ring value - v)
+            // the result-neutral pre-test every FAST implementation has (FAST_t<16> does it in this order): 9 contiguous ring pixels of one class contain
+            // one pixel of every opposite pair (k, k + 8), so the AND over the eight pairs of the OR of the pair's classes keeps that class's bit
+            int d = t[ptr[off[0]]] | t[ptr[off[8]]];
+            if (d == 0) continue;
+            d &= t[ptr[off[2]]] | t[ptr[off[10]]];
+            d &= t[ptr[off[4]]] | t[ptr[off[12]]];
+            d &= t[ptr[off[6]]] | t[ptr[off[14]]];
+            if (d == 0) continue;
+            d &= t[ptr[off[1]]] | t[ptr[off[9]]];
+            d &= t[ptr[off[3]]] | t[ptr[off[11]]];
+            d &= t[ptr[off[5]]] | t[ptr[off[13]]];
+            d &= t[ptr[off[7]]] | t[ptr[off[15]]];
+            if (d == 0) continue;
             int ring[25];
-            for (int k = 0; k < 25; ++k) ring[k] = img.at(x0 + x + kRing[k % 16][0], y0 + y + kRing[k % 16][1]);
+            for (int k = 0; k < 25; ++k) ring[k] = ptr[off[k]];
             bool corner = false;
-            {   // >= 9 contiguous darker
+            if (d & 1) {   // >= 9 contiguous darker
                 int vt = v - threshold, count = 0;
                 for (int k = 0; k < 25; ++k) {
                     if (ring[k] < vt) { if (++count > 8) { corner = true; break; } }
                     else count = 0;
                 }
             }
-            if (!corner) {  // >= 9 contiguous brighter
+            if (!corner && (d & 2)) {  // >= 9 contiguous brighter
                 int vt = v + threshold, count = 0;
                 for (int k = 0; k < 25; ++k) {
                     if (ring[k] > vt) { if (++count > 8) { corner = true; break; } }
@@ -126,11 +149,12 @@ static void fast9_16(const Image& img, int x0, int y0, int x1, int y1, int thres
                 }
             }
             if (corner) {
-                int d[25];
-                for (int k = 0; k < 25; ++k) d[k] = v - ring[k];
-                score[(size_t)y * w + x] = (uint8_t)corner_score16(d, threshold);
+                int dd[25];
+                for (int k = 0; k < 25; ++k) dd[k] = v - ring[k];
+                score[(size_t)y * w + x] = (uint8_t)corner_score16(dd, threshold);
             }
         }
+    }
     for (int y = 3; y < h - 3; ++y)
         for (int x = 3; x < w - 3; ++x) {
             int s = score[(size_t)y * w + x];
@@ -264,6 +288,12 @@ static std::vector<KP> distribute_octree(const std::vector<KP>& toDistribute, in
 
 // ---- pyramid / key points / descriptors ---------------------------------------------------
 
+// wall time (ms) of the calling thread's last orb_extract by stage: pyramid, FAST (both thresholds, incl. the 3x3 suppression), DistributeOctTree, IC_Angle,
+// Gaussian blur, rBRIEF + record assembly (bench.py's cpu_baseline.stages_ms.orb_*)
+thread_local double g_orb_stage_ms[6] = {0, 0, 0, 0, 0, 0};
+namespace { struct StageClock { std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double lap() { const auto n = std::chrono::steady_clock::now(); const double ms = std::chrono::duration<double, std::milli>(n - t).count(); t = n; return ms; } }; }
+
 static void compute_pyramid(const Image& img, const OrbTables& T, std::vector<Image>& pyr)
 {
     pyr.resize(T.nlevels);
@@ -304,8 +334,10 @@ static void compute_keypoints_octree(const OrbTables& T, OrbResult& R)
                 float maxX = iniX + wCell + 6;
                 if (iniX >= maxBorderX - 6) continue;
                 if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                StageClock fc;
                 fast9_16(im, (int)iniX, (int)iniY, (int)maxX, (int)maxY, T.iniTh, cell);
                 if (cell.empty()) fast9_16(im, (int)iniX, (int)iniY, (int)maxX, (int)maxY, T.minTh, cell);
+                g_orb_stage_ms[1] += fc.lap();
                 for (const FastKP& f : cell) {
                     KP kp;
                     kp.x = (float)f.x + j * wCell; kp.y = (float)f.y + i * hCell;
@@ -315,7 +347,9 @@ static void compute_keypoints_octree(const OrbTables& T, OrbResult& R)
             }
         }
         std::vector<KP>& kps = R.level_kps[level];
+        StageClock oc;
         if (!cand.empty()) kps = distribute_octree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY, T.nPerLevel[level]);
+        g_orb_stage_ms[2] += oc.lap();
         const int scaledPatchSize = (int)(PATCH_SIZE * T.sf[level]);
         for (KP& kp : kps) {
             kp.x += minBorderX; kp.y += minBorderY;
@@ -323,6 +357,7 @@ static void compute_keypoints_octree(const OrbTables& T, OrbResult& R)
         }
     }
     // IC_Angle on the un-blurred level images
+    StageClock ac;
     for (int level = 0; level < T.nlevels; ++level) {
         const Image& im = R.pyramid[level];
         for (KP& kp : R.level_kps[level]) {
@@ -341,6 +376,7 @@ static void compute_keypoints_octree(const OrbTables& T, OrbResult& R)
             kp.angle = fastAtan2((float)m_01, (float)m_10);
         }
     }
+    g_orb_stage_ms[3] = ac.lap();
 }
 
 static void compute_orb_descriptor(const KP& kpt, const Image& img, uint8_t* desc)
@@ -368,7 +404,10 @@ static void compute_orb_descriptor(const KP& kpt, const Image& img, uint8_t* des
 void orb_extract(const Image& img, const olf_orb_params& p, OrbResult& R)
 {
     OrbTables T(p);
+    for (double& v : g_orb_stage_ms) v = 0;
+    StageClock sc;
     compute_pyramid(img, T, R.pyramid);
+    g_orb_stage_ms[0] = sc.lap();
     compute_keypoints_octree(T, R);
     R.kps.clear(); R.desc.clear();
     R.blurred.assign(T.nlevels, Image());
@@ -376,7 +415,9 @@ void orb_extract(const Image& img, const olf_orb_params& p, OrbResult& R)
     for (int level = 0; level < T.nlevels; ++level) {
         std::vector<KP>& kps = R.level_kps[level];
         if (kps.empty()) continue;
+        sc.lap();
         R.blurred[level] = gaussian_blur_u8(R.pyramid[level], taps);
+        g_orb_stage_ms[4] += sc.lap();
         size_t off = R.desc.size();
         R.desc.resize(off + kps.size() * 32);
         for (size_t i = 0; i < kps.size(); ++i) compute_orb_descriptor(kps[i], R.blurred[level], &R.desc[off + i * 32]);
@@ -388,6 +429,7 @@ void orb_extract(const Image& img, const olf_orb_params& p, OrbResult& R)
             o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = -1;
             R.kps.push_back(o);
         }
+        g_orb_stage_ms[5] += sc.lap();
     }
 }
 

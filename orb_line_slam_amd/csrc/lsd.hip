@@ -877,6 +877,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     long long st_rounds = 0, st_k = 0, st_t = 0, st_full = 0, st_single = 0, st_rounds_big = 0, st_k_big = 0, st_t_big = 0;
     long long st_mem = 0, st_flush = 0, st_iters = 0, st_deep1 = 0, st_deep2 = 0, st_cand = 0, st_regions = 0;
     long long st_win = 0, st_seedl = 0, st_regl = 0, st_acc = 0, st_isos = 0, st_logged = 0, st_winLive = 0, st_first = 0, st_cand1 = 0, st_acc1 = 0;
+    long long st_wentries = 0, st_whand = 0, st_wdone = 0, st_wpend = 0;
 #endif
 #ifdef OLF_TIMING2
     long long p_ring = 0, p_gather = 0, p_table = 0, p_chain = 0, p_commit = 0, p_n = 0, ps;
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #endif
     constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4), WIN = !REFINE && (PF & 8);
 #ifndef OLF_WIN_MAXPEND
-#define OLF_WIN_MAXPEND 8
+#define OLF_WIN_MAXPEND 16
 #endif
     // window phase: lane L < 49 is pixel (seed.x + L % 7 - 3, seed.y + L / 7 - 3)
     constexpr unsigned long long kW49 = (1ull << 49) - 1ull, kSeedBit = 1ull << 24, kM3 = 7ull | (7ull << 7) | (7ull << 14);
@@ -1022,31 +1023,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #endif
 #define WIN_ALIGNED() ({ const double _n = fabs(d_sub(reg_angle, wang)); live & (wave_vote(_n <= prec) | wave_vote(_n >= precWrap)); })
                 unsigned long long la = WIN_ALIGNED();
-                bool handover = false;
+                // FIFO entries [i, lim) are replayed here: lim = min(n, place of the first pixel on the window's outer ring -- its 3 x 3 looks outside);
+                // a long FIFO is what the general loop's 8 entries per gather are for
+                int lim = 1, ringAt = 1 << 20;
                 for (;;) {
                     const int p = __builtin_ctzll(wave_vote(fidx == i));
-                    // an entry on the outer ring looks outside the window; a long FIFO is what the general loop's 8 entries per gather are for
-                    if (!((kD2 >> p) & 1ull) || n - i >= OLF_WIN_MAXPEND) { handover = true; break; }
                     const unsigned long long nbr = kM3 << (p - 8);
                     unsigned long long cm = nbr & la;
-                    while (cm) {
-                        const int c = __builtin_ctzll(cm);
-                        const unsigned long long bit = 1ull << c;
-                        live &= ~bit; accM |= bit;
-                        fidx = wave_bit(bit) ? n : fidx;
-                        ++n;
-                        const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
-                        sumdx = (float)d_add((double)sumdx, cs_c);
-                        sumdy = (float)d_add((double)sumdy, sn_c);
-                        reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
-                        la = WIN_ALIGNED();
-                        cm = nbr & la & ~((2ull << c) - 1ull);      // the entry's later neighbours, under the new angle
+                    if (cm) {
+                        do {
+                            const int c = __builtin_ctzll(cm);
+                            const unsigned long long bit = 1ull << c;
+                            live &= ~bit; accM |= bit;
+                            fidx = wave_bit(bit) ? n : fidx;
+                            ringAt = (kD2 & bit) ? ringAt : min(ringAt, n);
+                            ++n;
+                            const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
+                            sumdx = (float)d_add((double)sumdx, cs_c);
+                            sumdy = (float)d_add((double)sumdy, sn_c);
+                            reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                            la = WIN_ALIGNED();
+                            cm = nbr & la & ~((2ull << c) - 1ull);      // the entry's later neighbours, under the new angle
+                        } while (cm);
+                        lim = n - i > OLF_WIN_MAXPEND ? i + 1 : min(n, ringAt);
                     }
-                    if (++i == n) break;
+                    if (++i >= lim) break;
                 }
+                const bool handover = i < n;
 #undef WIN_ALIGNED
 #ifdef OLF_STATS
-                st_acc1 += n - 1; st_iters += i;
+                st_acc1 += n - 1; st_wentries += i; if (handover) { ++st_whand; st_wpend += n - i; } else ++st_wdone;
 #endif
                 // ---- publish the batch: USED bits + pending table; FIFO ring and log only where somebody will read them
                 const bool mine = wave_bit(accM);
@@ -1386,7 +1392,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #ifdef OLF_STATS
     if (lane == 0 && img == 0) { long long* o = reinterpret_cast<long long*>(status + 16); o[0] = st_rounds; o[1] = st_k; o[2] = st_t; o[3] = st_full; o[4] = st_single; o[5] = st_rounds_big; o[6] = st_k_big; o[7] = st_t_big;
         o[8] = st_flush; o[9] = st_iters; o[10] = st_deep1; o[11] = st_deep2; o[12] = st_cand; o[13] = st_regions; o[14] = st_mem;
-        o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; o[22] = st_winLive; o[23] = st_first; o[24] = st_cand1; }
+        o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; o[22] = st_winLive; o[23] = st_first; o[24] = st_cand1;
+        o[25] = st_acc1; o[26] = st_wentries; o[27] = st_whand; o[28] = st_wdone; o[29] = st_wpend; }
 #endif
     if (lane == 0) { regCount[img] = nreg; if (growFmt) growFmt[img] = 1; }
 }

@@ -20,5 +20,5 @@ ex = ola.Lineextractor(500, 0.025, max_images=n, **kw)
 k, d, c = ex.extract_batch(imgs)
 out = np.zeros(128, np.int32)
 _lib.lib().olf_debug_status_n(ex._ctx.handle, out.ctypes.data_as(C.c_void_p), 128)
-t = out[16:66].view(np.int64)
-print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions", "iters_fifo_from_memory", "nkeys", "windows_entered", "seed_lanes_gathered", "regather_lanes", "pixels_in_regions", "iso_seeds", "pixels_logged", "windows_with_live_seeds", "region_starts(first_steps)", "candidates_in_first_steps"], t.tolist())))
+t = out[16:76].view(np.int64)
+print(dict(zip(["rounds", "k_speculated", "t_committed", "rounds_fully_committed", "single_steps", "rounds_big", "k_big", "t_big", "flushes", "iterations", "iters_fifo>=14", "iters_fifo>=21", "candidates", "grown_regions", "iters_fifo_from_memory", "nkeys", "windows_entered", "seed_lanes_gathered", "regather_lanes", "pixels_in_regions", "iso_seeds", "pixels_logged", "windows_with_live_seeds", "region_starts(first_steps)", "candidates_in_first_steps", "window_accepts", "window_entries", "window_handovers", "regions_done_in_window", "pending_at_handover"], t.tolist())))
