@@ -59,7 +59,11 @@ int  olf_ctx_set_input_event(olf_ctx* ctx, void* hip_event);
  * reference's tracker consumes the point features first (TrackReferenceKeyFrame: ComputeBoW + SearchByBoW, src/Tracking.cc:963-970) and the line features after
  * them (:1296-1308); with the deferred join on, the call returns with the ORB-side outputs (key points, descriptors, counts, mvuRight, mvDepth) complete on
  * `stream` and the line-side outputs (key lines, LBD descriptors, line matches) still being produced on the context's line stream --
- * olf_stereo_frames_join_dev(ctx, stream) makes `stream` wait for them (the next olf_stereo_frames_dev call does it itself if the caller did not). */
+ * olf_stereo_frames_join_dev(ctx, stream) makes `stream` wait for them (the next olf_stereo_frames_dev call does it itself if the caller did not).
+ * A join on the frame call's own stream discharges the obligation for the context; a join on any OTHER stream (explicit, or the implicit one of
+ * olf_match_bf_dev / olf_stereo_lines_dev / olf_frames_pack_dev when they are handed a line-side output of the pending call) orders that stream only,
+ * and later entries on the frame call's stream still wait.  A kernel of the caller's own that reads line-side outputs must be ordered by the caller
+ * (olf_stereo_frames_join_dev on its stream). */
 int  olf_ctx_set_deferred_join(olf_ctx* ctx, int on);
 int  olf_stereo_frames_join_dev(olf_ctx* ctx, void* stream);
 int  olf_ctx_poll_status(olf_ctx* ctx);
@@ -185,8 +189,12 @@ int olf_debug_lsd_regions(olf_ctx* ctx, int image, int32_t* start_n, double* ang
  * size) and entries of its reorder buffer (128, 256, 512, or 1024 with several workgroups per image; 0 = automatic).  Results do not depend on either. */
 int olf_debug_lsd_waves(olf_ctx* ctx, int waves_per_image, int rob_entries);
 /* debug/test: workgroups (CUs) that grow ONE image together when the kernel runs 16 waves per image (1, 2 or 4; 0 = automatic from the batch
- * size: the one-pair-per-call shape of Frame::Frame, src/Frame.cc:164-171, takes 4).  Results do not depend on it. */
+ * size: calls of up to 64 images -- the one-pair-per-call shape of Frame::Frame, src/Frame.cc:164-171 -- take 2).  Results do not depend on it. */
 int olf_debug_lsd_groups(olf_ctx* ctx, int groups);
+/* debug/test: where the groups of an image run.  0 (default): on workgroups 8 apart, which the hardware's round-robin placement puts on ONE XCD (they
+ * meet in its L2); 1: on consecutive workgroups, i.e. on DIFFERENT XCDs.  What crosses between groups is agent-scope traffic either way: results do
+ * not depend on it (tests/test_lsd_grow_gpu.py::test_growth_groups_scattered_over_xcds), only the time does. */
+int olf_debug_lsd_scatter(olf_ctx* ctx, int on);
 /* debug / tests: the kernel that replays libstdc++'s std::sort for the LSD seed order (convention C.9 variant 1, csrc/lsd_seedsort.hip) on a
  * caller-supplied array of n <= Ws*Hs keys, (field << 22) | payload with a 10-bit field: out receives the keys whose field is <= kthr in the
  * order std::sort(keys, keys + n, field ascending) leaves them; depth_limit < 0 = introsort's own 2 * floor(log2 n), a small value forces

@@ -58,8 +58,11 @@ struct olf_ctx {
     // small contexts (the drop-in's one-pair-per-call shape): the eleven output arrays of olf_stereo_frames sit in ONE device slab, so that the host entry brings them
     // back with one copy into pinned memory instead of eleven (each a launch and a gap of its own: 0.44 ms of a 9 ms call, profiles/r5b_pair_timeline.txt)
     uint8_t* d_outslab = nullptr; uint8_t* h_outslab = nullptr; size_t outslab_bytes = 0; size_t outslab_off[12] = {0};
-    const uint8_t* pend_ldesc = nullptr; size_t pend_ldesc_bytes = 0;       // the line descriptors / counts that call is still writing: an entry that is handed
-    const int32_t* pend_lcounts = nullptr; size_t pend_lcounts_n = 0;       // them (matcher, packer) joins first
+    // every line-side output that call is still writing (key lines, LBD descriptors, counts, line matches, disparities, line equations): an entry that is handed
+    // one of them (matcher, line stereo, packer) joins first.  The obligation is discharged for the whole context only when the frame call's OWN stream has
+    // waited (pend_stream); a join on another stream orders that stream and leaves the obligation standing
+    struct { const uint8_t* p; size_t bytes; } pend[6] = {};
+    hipStream_t pend_stream = nullptr;
     bool defer_lbd = false;            // fused entry: olf_line_extract_dev stops behind the rectangles; selection + LBD are enqueued by the caller
     bool lbd_pre = false;              // fused entry: olf_orb_extract_dev computes the LBD gradient images behind its blur and records ev_lbd
     hipEvent_t ev_sort = nullptr;      // recorded in front of the seed ordering (the dense, bandwidth-bound half of the LSD front is through)
@@ -354,14 +357,15 @@ static int join_if_pending(olf_ctx* c, hipStream_t s)
 {
     if (!c->join_pending) return OLF_OK;
     OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    c->join_pending = false;
+    if (s == c->pend_stream) c->join_pending = false;      // (a side stream's wait orders the side stream only)
     return OLF_OK;
 }
 static bool in_pending_line_outputs(const olf_ctx* c, const void* p)
 {
+    if (!c->join_pending || !p) return false;
     const uint8_t* q = static_cast<const uint8_t*>(p);
-    return c->join_pending && ((c->pend_ldesc && q >= c->pend_ldesc && q < c->pend_ldesc + c->pend_ldesc_bytes) ||
-                               (c->pend_lcounts && q >= reinterpret_cast<const uint8_t*>(c->pend_lcounts) && q < reinterpret_cast<const uint8_t*>(c->pend_lcounts + c->pend_lcounts_n)));
+    for (const auto& r : c->pend) if (r.p && q >= r.p && q < r.p + r.bytes) return true;
+    return false;
 }
 
 int olf_ctx_synchronize(olf_ctx* c)
@@ -600,6 +604,14 @@ int olf_debug_lsd_groups(olf_ctx* c, int groups)
 {
     if (!c || !(groups == 0 || groups == 1 || groups == 2 || groups == 4)) { set_error("olf_debug_lsd_groups: bad argument"); return OLF_ERR_INVALID; }
     c->lb.forceG = groups > 0 ? groups : -1;
+    return OLF_OK;
+}
+
+// debug / tests: deal the growth groups of an image to consecutive workgroups (different XCDs under round-robin placement) instead of to one XCD
+int olf_debug_lsd_scatter(olf_ctx* c, int on)
+{
+    if (!c) { set_error("olf_debug_lsd_scatter: bad argument"); return OLF_ERR_INVALID; }
+    c->lb.scatter = on ? 1 : 0;
     return OLF_OK;
 }
 
@@ -1045,6 +1057,8 @@ int olf_stereo_lines_dev(olf_ctx* c, int n_pairs, const olf_keyline* d_kls, cons
     if (n_pairs < 0 || 2 * n_pairs > c->max_images) return OLF_ERR_CAPACITY;
     if (n_pairs == 0) return OLF_OK;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // key lines / descriptors of a frame call whose line path is still running (deferred join): this stream waits for it first
+    if (s != c->stream2 && (in_pending_line_outputs(c, d_kls) || in_pending_line_outputs(c, d_ldesc) || in_pending_line_outputs(c, d_lcounts))) OLF_TRY(join_if_pending(c, s));
     StageScope t(c, s, ST_STEREO_LINES);
     return launch_stereo_lines(c->W, c->H, c->params.stereo, n_pairs, d_kls, d_ldesc, d_lcounts, c->line.geom.outCap, c->d_lprep, c->d_ldist,
                                c->d_lm21, d_m12, d_disp, d_le, s);
@@ -1141,8 +1155,14 @@ int olf_stereo_frames_dev(olf_ctx* c, const uint8_t* d_images, int n_pairs, cons
     // (or the next call) makes the stream wait for it
     if (c->deferred_join) {
         c->join_pending = true;
-        c->pend_ldesc = o->ldesc; c->pend_ldesc_bytes = (size_t)n_images * c->line.geom.outCap * OLF_DESC_BYTES;
-        c->pend_lcounts = o->lcounts; c->pend_lcounts_n = (size_t)n_images;
+        c->pend_stream = s;
+        const size_t lc = (size_t)c->line.geom.outCap;
+        c->pend[0] = {reinterpret_cast<const uint8_t*>(o->kls), (size_t)n_images * lc * sizeof(olf_keyline)};
+        c->pend[1] = {reinterpret_cast<const uint8_t*>(o->ldesc), (size_t)n_images * lc * OLF_DESC_BYTES};
+        c->pend[2] = {reinterpret_cast<const uint8_t*>(o->lcounts), (size_t)n_images * sizeof(int32_t)};
+        c->pend[3] = {reinterpret_cast<const uint8_t*>(o->lmatches12), (size_t)n_pairs * lc * sizeof(int32_t)};
+        c->pend[4] = {reinterpret_cast<const uint8_t*>(o->ldisp), (size_t)n_pairs * lc * 2 * sizeof(float)};
+        c->pend[5] = {reinterpret_cast<const uint8_t*>(o->lle), (size_t)n_pairs * lc * 3 * sizeof(double)};
     } else OLF_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     return OLF_OK;
 }
@@ -1157,10 +1177,7 @@ int olf_ctx_set_deferred_join(olf_ctx* c, int on)
 int olf_stereo_frames_join_dev(olf_ctx* c, void* stream)
 {
     if (!c) return OLF_ERR_INVALID;
-    if (!c->join_pending) return OLF_OK;
-    OLF_HIP_CHECK(hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, c->ev_join, 0));
-    c->join_pending = false;
-    return OLF_OK;
+    return join_if_pending(c, stream ? (hipStream_t)stream : c->stream);
 }
 
 int olf_stereo_frames(olf_ctx* c, const uint8_t* images, int n_pairs, const olf_frame_buffers* o)

@@ -94,6 +94,7 @@ struct LineDeviceBufs {
     size_t mgStride = 0;
     int mgImages = 0;              // images `mg` is sized for (small batches only: the latency path)
     int forceG = -1;               // olf_debug_lsd_groups: workgroups per image of the multi-wave growth (1, 2, 4); -1: by batch size
+    int scatter = 0;               // olf_debug_lsd_scatter: the groups of an image on consecutive blocks (different XCDs) instead of on one XCD
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
 };
 

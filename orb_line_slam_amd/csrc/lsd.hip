@@ -1021,30 +1021,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #ifdef OLF_STATS
                 ++st_first; st_cand1 += __popcll(live);
 #endif
-#define WIN_ALIGNED() ({ const double _n = fabs(d_sub(reg_angle, wang)); live & (wave_vote(_n <= prec) | wave_vote(_n >= precWrap)); })
-                unsigned long long la = WIN_ALIGNED();
+// (lanes aligned with the region angle, live or not; lanes that hold no table entry give garbage -- every use is masked with `live`)
+#define WIN_ALIGNED(TH) ({ const double _n = fabs(d_sub((TH), wang)); wave_vote(_n <= prec) | wave_vote(_n >= precWrap); })
+                unsigned long long alM = WIN_ALIGNED(reg_angle);
                 // FIFO entries [i, lim) are replayed here: lim = min(n, place of the first pixel on the window's outer ring -- its 3 x 3 looks outside);
                 // a long FIFO is what the general loop's 8 entries per gather are for
                 int lim = 1, ringAt = 1 << 20;
                 for (;;) {
                     const int p = __builtin_ctzll(wave_vote(fidx == i));
-                    const unsigned long long nbr = kM3 << (p - 8);
-                    unsigned long long cm = nbr & la;
-                    if (cm) {
+                    unsigned long long cand = (kM3 << (p - 8)) & live;      // the entry's live neighbours, in lane order = the reference's visiting order
+                    unsigned long long al = cand & alM;
+                    if (al) {
                         do {
-                            const int c = __builtin_ctzll(cm);
-                            const unsigned long long bit = 1ull << c;
-                            live &= ~bit; accM |= bit;
-                            fidx = wave_bit(bit) ? n : fidx;
-                            ringAt = (kD2 & bit) ? ringAt : min(ringAt, n);
-                            ++n;
-                            const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
-                            sumdx = (float)d_add((double)sumdx, cs_c);
-                            sumdy = (float)d_add((double)sumdy, sn_c);
-                            reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
-                            la = WIN_ALIGNED();
-                            cm = nbr & la & ~((2ull << c) - 1ull);      // the entry's later neighbours, under the new angle
-                        } while (cm);
+                            const int n0 = n;
+                            unsigned long long acc1, after;
+                            if ((al & (al - 1ull)) == 0) {
+                                // one aligned neighbour: the plain sequential step
+                                const int c = __builtin_ctzll(al);
+                                acc1 = al; after = ~((2ull << c) - 1ull);
+                                fidx = wave_bit(al) ? n : fidx;
+                                ++n;
+                                const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
+                                sumdx = (float)d_add((double)sumdx, cs_c);
+                                sumdy = (float)d_add((double)sumdy, sn_c);
+                                reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                            } else {
+                                // several: speculate that they are accepted in lane order (the general loop's round, without its duplicate views -- a pixel is one
+                                // lane here).  Lane L keeps the sums in force at its turn; lane 63, never a candidate, ends with the sums after all of them.
+                                float sx = sumdx, sy = sumdy, bsx = sumdx, bsy = sumdy;
+                                unsigned long long todo = al;
+                                do {
+                                    const int c = __builtin_ctzll(todo);
+                                    todo &= todo - 1ull;
+                                    const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
+                                    sx = (float)d_add((double)sx, cs_c);
+                                    sy = (float)d_add((double)sy, sn_c);
+                                    if (lane > c) { bsx = sx; bsy = sy; }
+                                } while (todo);
+                                const int c0 = __builtin_ctzll(al);
+                                const double thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);
+                                const double thg = lane <= c0 ? reg_angle : thOwn;
+                                const unsigned long long reM = WIN_ALIGNED(thg);
+                                const unsigned long long mis = (reM ^ alM) & cand;          // a decision that differs under the angle that governs it
+                                const int mLane = mis ? __builtin_ctzll(mis) : 63;
+                                const unsigned long long bm = mis ? ((1ull << mLane) - 1ull) : ~0ull;
+                                acc1 = al & bm; after = ~bm;
+                                fidx = wave_bit(acc1) ? n + wave_rank_below(acc1) : fidx;
+                                n += __popcll(acc1);
+                                // the state after the committed accepts: what the first undecided lane sees before its turn, or lane 63 after all of them
+                                sumdx = __int_as_float(rlane(__float_as_int(bsx), mLane));
+                                sumdy = __int_as_float(rlane(__float_as_int(bsy), mLane));
+                                reg_angle = rlane_d(thOwn, mLane);
+                            }
+                            live &= ~acc1; accM |= acc1;
+                            if (const unsigned long long rm = acc1 & ~kD2) ringAt = min(ringAt, n0 + __popcll(acc1 & ((1ull << __builtin_ctzll(rm)) - 1ull)));
+                            alM = WIN_ALIGNED(reg_angle);
+                            cand &= after;                                   // the entry's later neighbours, under the new angle
+                            al = cand & alM;
+                        } while (al);
                         lim = n - i > OLF_WIN_MAXPEND ? i + 1 : min(n, ringAt);
                     }
                     if (++i >= lim) break;
@@ -1676,7 +1710,7 @@ int lsd_grow_groups(int n_images, int nw)
 {
     static const int forced = [] { const char* e = getenv("OLF_LSD_GROUPS"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
     if (nw < 16) return 1;
-    if (forced) return n_images * forced <= 256 && n_images <= kMgMaxImages ? forced : 1;
+    if (forced) return n_images <= kMgMaxImages ? forced : 1;      // (launch_lsd_grow halves it until every group fits a CU of its own)
     // (two groups, not four: one pair 8.45 against 8.95 ms, 8 pairs 10.3 against 10.8 -- the further a group runs ahead of the commit order the more of what it grows
     // is taken from it again by older seeds, profiles/r5a_growth_groups.txt)
     if (n_images <= kMgMaxImages) return 2;
@@ -1707,7 +1741,9 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         int E = b.forceE > 0 ? b.forceE : envE > 0 ? envE : (nw >= 16 ? 512 : nw >= 8 ? 256 : 128);
         int G = b.forceG > 0 ? b.forceG : lsd_grow_groups(n_images, nw);
         const int pool = b.poolChunks > 0 ? std::min(b.poolChunks, b.nChunks) : b.nChunks;
-        while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > 256 || pool / G < E + 64)) G >>= 1;      // (every group of an image has to be resident: one workgroup per CU)
+        // (every group of an image has to be resident -- a group spins on its partners' watermarks -- i.e. one workgroup per CU of THIS device)
+        static const int nCU = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64; return n; }();
+        while (G > 1 && (!b.mg || n_images > b.mgImages || n_images * G > nCU || pool / G < E + 64)) G >>= 1;
         const int rc = launch_lsd_grow_mw(g, b, n_images, nw, E, G, s);
         if (rc != OLF_OK) return rc;
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the

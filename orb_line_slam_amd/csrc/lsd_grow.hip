@@ -67,6 +67,11 @@ __device__ __forceinline__ void ag_store(uint32_t* p, uint32_t v) { __hip_atomic
 __device__ __forceinline__ void ag_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // release towards the other waves of the workgroup; MG: towards other CUs as well -- every memory operation of this wave has been performed (the compiler's
 // workgroup fence does not wait for the vector-memory counter when the workgroup sits on one CU)
+// (the protocol's premise is a gfx9 property: stores and atomics without return are counted in vmcnt -- gfx10 and later count them in vscnt, where this wait
+// would order nothing; tools/micro/mp_litmus.hip tests the exact pattern between CUs of one and of two XCDs)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "lsd_grow.hip: the cross-CU ordering (relaxed agent-scope accesses + s_waitcnt vmcnt(0)) is written for gfx9-class ISAs (gfx950)"
+#endif
 template <bool MG> __device__ __forceinline__ void rel_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -814,14 +819,15 @@ size_t lsd_grow_mw_lds_bytes(int nw, int E)
 
 // MG = false: one workgroup per image (blockIdx.x = image).  MG = true: G workgroups per image; block b serves image (b / 8 / G) * 8 + b % 8 as group (b / 8) % G, so that
 // the groups of an image land on ONE XCD under the observed round-robin placement (block b -> XCD b % 8) and meet in that XCD's L2 -- a speed matter only: every
-// cross-group access is an agent-scope atomic, correct under any placement.
+// cross-group access is an agent-scope atomic, correct under any placement.  `scatter` (olf_debug_lsd_scatter, tests) deals the groups of an image to CONSECUTIVE
+// blocks instead -- image b / G, group b % G: different XCDs under that placement -- so that tests/test_lsd_grow_gpu.py can hold the claim to a bit-exact result.
 template <bool MG>
 __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll, uint32_t* __restrict__ ownerAll,
                                                       const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                       uint32_t* __restrict__ chunksAll, int* __restrict__ linksAll, RegionRec* __restrict__ recsAll,
                                                       int* __restrict__ regCount, int* __restrict__ status, const float* __restrict__ angDeg,
                                                       const AngEnt* __restrict__ ent, int E, int nChunks, int poolLimit, int* __restrict__ growFmt,
-                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images, int wsBits, int ahead)
+                                                      unsigned char* __restrict__ mgAll, size_t mgStride, int G, int n_images, int wsBits, int ahead, int scatter)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LineGeom& g = *gp;
@@ -830,6 +836,7 @@ __global__ __launch_bounds__(1024) void k_lsd_grow_mw(const LineGeom* __restrict
     if (MG) {
         const int k = blockIdx.x >> 3;
         img = (k / G) * 8 + (blockIdx.x & 7); grp = k % G;
+        if (scatter) { img = blockIdx.x / G; grp = blockIdx.x % G; }
         if (img >= n_images) return;
     }
     MwCtx c;
@@ -1036,14 +1043,16 @@ int launch_lsd_grow_mw(const LineGeom& g, LineDeviceBufs& b, int n_images, int n
         // the control words of every image start at zero (watermarks 0 = nothing final yet; the notice words are set when a slot is filled)
         OLF_HIP_CHECK(hipMemset2DAsync(b.mg, b.mgStride, 0, MG_INVAL_OFF, (size_t)n_images, s));
         const int blocks = ((n_images + 7) / 8) * 8 * G;
+        static const int envScatter = getenv("OLF_LSD_SCATTER") ? atoi(getenv("OLF_LSD_SCATTER")) : 0;       // (tools/stress_mg.py under scatter)
+        const int scatter = b.scatter || envScatter;
         hipLaunchKernelGGL(k_lsd_grow_mw<true>, dim3(blocks), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images, wsBits, ahead);
+                           b.nChunks, poolLimit, b.growFmt, b.mg, b.mgStride, G, n_images, wsBits, ahead, scatter);
         hipLaunchKernelGGL(k_mg_merge, dim3(n_images), dim3(256), 0, s, b.geom, b.mg, b.mgStride, G, reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.growFmt);
     } else
         hipLaunchKernelGGL(k_lsd_grow_mw<false>, dim3(n_images), dim3(64 * nw), lds, s, b.geom, b.grad, b.owner, b.keysB, b.keyCount, b.region, b.links,
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, b.angDeg, reinterpret_cast<const AngEnt*>(b.angEnt), E,
-                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images, 10, ahead);
+                           b.nChunks, poolLimit, b.growFmt, (unsigned char*)nullptr, (size_t)0, 1, n_images, 10, ahead, 0);
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
 }

@@ -8,10 +8,11 @@ from orb_line_slam_amd import synth, _lib
 pytestmark = pytest.mark.gpu
 
 
-def _set(ex, w, h, n, waves, rob, groups=1):
+def _set(ex, w, h, n, waves, rob, groups=1, scatter=0):
     ctx = ex._context(w, h, n)
     _lib.check(_lib.lib().olf_debug_lsd_waves(ctx.handle, waves, rob), "olf_debug_lsd_waves")
     _lib.check(_lib.lib().olf_debug_lsd_groups(ctx.handle, groups), "olf_debug_lsd_groups")
+    _lib.check(_lib.lib().olf_debug_lsd_scatter(ctx.handle, scatter), "olf_debug_lsd_scatter")
 
 
 def _status(ex):
@@ -27,7 +28,7 @@ def test_growth_is_independent_of_wave_count(oracle, w, h):
     want = [oracle.line_extract(im, p.line) for im in imgs]
     ex = ola.Lineextractor(0, 0.025, max_images=4)
     # workgroups per image {1, 2, 4} (several CUs on one image: per-group reorder buffers over rank-interleaved 1024-seed windows) x the ten settings;
-    # groups = 0 is the automatic choice (4 for a batch this small)
+    # groups = 0 is the automatic choice (2 for a batch this small, lsd_grow_groups)
     for groups in (1, 2, 4, 0):
         for waves, rob in [(0, 0), (1, 128), (2, 128), (2, 256), (4, 256), (8, 512), (16, 512), (16, 128), (3, 256), (-1, 0)]:
             if groups != 1 and waves == 0:
@@ -163,3 +164,63 @@ def test_cross_cu_hand_over_under_uneven_load():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_mg.py"), "8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode()
     assert "STRESS OK" in out, out[-1500:]
+
+
+def _xcd_images(w=480, h=360):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    fan = np.full((h, w), 40, np.uint8)
+    ang = np.arctan2(yy - h / 2, xx - w / 2)
+    fan[(np.floor(ang / (np.pi / 12)) % 2) == 0] = 210
+    checker = (((xx // 24) + (yy // 24)) % 2 * 170 + 40).astype(np.uint8)
+    rings = (np.sin(np.hypot(xx - w / 2, yy - h / 2) / 6.0) * 100 + 128).astype(np.uint8)
+    noise = np.random.default_rng(23).integers(0, 256, (h, w), dtype=np.uint8)
+    return np.stack([fan, checker, rings, noise, synth.stereo_batch(31, 1, w, h)[0]])
+
+
+def test_growth_groups_scattered_over_xcds(oracle):
+    """"A speed matter only" held to a bit-exact result: with olf_debug_lsd_scatter the G groups of an image run on CONSECUTIVE workgroups --
+    different XCDs under the hardware's round-robin placement, so owner words, watermarks and steal notices cross between L2s -- for G in {2, 4} on the structured
+    images, noise and a synthetic scene, repeated (a visibility bug is a race: one pass proves little); every result equals the oracle."""
+    w, h = 480, 360
+    imgs = _xcd_images(w, h)
+    p = oracle.full_params(1000, 0)
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    ex = ola.Lineextractor(0, 0.025, max_images=len(imgs))
+    for scatter in (1, 0):
+        for groups in (2, 4):
+            for waves, rob in [(16, 512), (16, 128)]:
+                _set(ex, w, h, len(imgs), waves, rob, groups, scatter)
+                for rep in range(6):
+                    kls, desc, counts = ex.extract_batch(imgs)
+                    assert (_status(ex)[0] & (8 | 16)) == 0, (scatter, groups, waves, rob, rep)
+                    for i in range(len(imgs)):
+                        n = int(counts[i])
+                        assert n == len(want[i]["kls"]), (scatter, groups, waves, rob, rep, i, n, len(want[i]["kls"]))
+                        assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (scatter, groups, waves, rob, rep, i)
+    _set(ex, w, h, len(imgs), -1, 0, 0, 0)
+
+
+def test_cross_xcd_hand_over_under_uneven_load():
+    """tools/stress_mg.py with the groups of every image scattered over XCDs (OLF_LSD_SCATTER=1) while 256-pair batches keep every CU busy."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OLF_LSD_SCATTER="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_mg.py"), "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode()
+    assert "STRESS OK" in out, out[-1500:]
+
+
+def test_message_passing_litmus_between_cus_and_xcds():
+    """tools/micro/mp_litmus.hip: the exact pattern the commit waves rely on -- relaxed agent-scope store (or atomicMin) ; s_waitcnt vmcnt(0) ; relaxed agent-scope
+    store, read in the opposite order by a workgroup on another CU of the same XCD and on another XCD, under read-modify-write noise from 60 other workgroups -- must
+    show no reader that saw the flag without the data it announces."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "micro", "mp_litmus")
+    if not os.path.exists(exe):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-Wno-unused-value", "-o", exe, exe + ".hip"], check=True)
+    out = subprocess.run([exe, "1000000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    d = json.loads(out.stdout.decode())
+    assert out.returncode == 0 and d["ordering_holds"] is True, d
+    real = [r for r in d["results"] if r and not r["variant"].startswith("control")]
+    assert len(real) >= 5 and all(r["violations"] == 0 and r["distinct_flags_seen"] > 1000 for r in real), real
+    assert any(r["placement"].startswith("different XCDs") for r in real)

@@ -107,3 +107,91 @@ def test_cpp_driver_links_rccl_directly_single_rank():
     line = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert line["ranks"] == 1 and line["pairs_per_step"] == 16 and line["steps"] == 3 and line["stereo_frames_per_s"] > 0
     assert line["record_bytes_all_ranks"] > 3 * 16 * 50000          # (about 0.2 MB per KITTI pair, trimmed)
+
+
+def test_cpp_driver_verify_single_rank():
+    """examples/stereo_batch_sharded --verify (SURVEY 8(e) "Verification"): after the last step rank 0 recomputes every rank's shard from the seeds
+    and memcmp's the records.  Four steps, so that the double-buffer hand-over (the pack of step k + 2 waits for step k's record to leave its buffer) runs."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "stereo_batch_sharded")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([exe, "12", "4", "640", "480", "--verify"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["verify"] == {"ranks": 1, "identical": True}, line
+    assert line["pairs_per_step"] == 12 and line["steps"] == 4 and line["record_bytes_all_ranks"] > 0
+
+
+_WORKER8 = r'''
+import os, sys, ctypes as C
+root, n_frames = sys.argv[1], int(sys.argv[2])
+sys.path.insert(0, root)
+import numpy as np, torch, torch.distributed as dist
+from orb_line_slam_amd import _lib, synth, records
+from orb_line_slam_amd.distributed import shard_range, gather_records
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)                                      # every rank on the one GPU of the box
+dev = torch.device("cuda", 0)
+W, H = 640, 480
+p = _lib.default_params(); p.orb.nfeatures, p.line.lsd_nfeatures = 1000, 200
+L = _lib.lib()
+
+def record_of(lo, hi, capacity):
+    """the trimmed record of job frames [lo, hi) (frame f has seed 300 + f) from a context of `capacity` pairs"""
+    n = hi - lo
+    ctx = _lib.Context(p, W, H, 2 * max(capacity, 1))
+    cap, lcap = ctx.orb_capacity, ctx.line_capacity
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    m = max(n, 1)
+    t = [z((2 * m, cap, 28), torch.uint8), z((2 * m, cap, 32), torch.uint8), z((2 * m,), torch.int32), z((m, cap), torch.float32), z((m, cap), torch.float32),
+         z((2 * m, lcap, 68), torch.uint8), z((2 * m, lcap, 32), torch.uint8), z((2 * m,), torch.int32), z((m, lcap), torch.int32), z((m, lcap, 2), torch.float32),
+         z((m, lcap, 3), torch.float64)]
+    fb = _lib.FrameBuffers(*[x.data_ptr() for x in t])
+    s = torch.cuda.current_stream().cuda_stream
+    bound = L.olf_frames_pack_bound(ctx.handle, m)
+    dst = torch.zeros(bound, dtype=torch.uint8, device=dev)
+    nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    if n > 0:
+        imgs = torch.from_numpy(np.concatenate([synth.stereo_batch(300 + f, 1, W, H) for f in range(lo, hi)])).to(dev)
+        _lib.check(L.olf_stereo_frames_dev(ctx.handle, imgs.data_ptr(), n, C.byref(fb), s), "olf_stereo_frames_dev")
+    _lib.check(L.olf_frames_pack_dev(ctx.handle, C.byref(fb), n, dst.data_ptr(), bound, nbytes.data_ptr(), s), "olf_frames_pack_dev")
+    torch.cuda.synchronize(); ctx.synchronize()
+    out = dst[:int(nbytes.item())].clone()
+    ctx.close()
+    return out
+
+lo, hi = shard_range(n_frames, rank, world)
+mine = record_of(lo, hi, hi - lo)
+recs, sizes = gather_records(mine, mine.numel(), dist, 0)
+if rank == 0:
+    assert len(recs) == world and [int(s) for s in sizes] == [r.numel() for r in recs]
+    shards = [shard_range(n_frames, r, world) for r in range(world)]
+    assert len({b - a for a, b in shards}) > 1, "the job must give uneven shards"
+    merged = records.merge_records([r.cpu().numpy().tobytes() for r in recs])
+    whole = records.merge_records([record_of(0, n_frames, n_frames).cpu().numpy().tobytes()])
+    assert merged == whole, "the gathered records differ from the one-rank run"
+    pr = records.parse_records(merged)
+    assert pr["n_pairs"] == n_frames and pr["counts"].min() > 0
+    print("GATHER8_OK", n_frames, [b - a for a, b in shards], len(merged))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_eight_ranks_share_the_gpu_uneven_shards(tmp_path):
+    """The driver's 8-rank shape on the one GPU of the box (gloo; the records are staged through host memory): 27 stereo pairs frame-sharded 4,4,4,3,3,3,3,3 by
+    shard_range, every rank runs the HIP path on its shard and packs its record on the device, rank 0 gathers point to point; the merge of the eight records must be
+    byte-identical to the record of the same job on one rank (VERDICT r5 item 8; the CPU suite has the same shape with fixture rows)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, "27"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[-1500:] for o in outs]
+    assert "GATHER8_OK 27 [4, 4, 4, 3, 3, 3, 3, 3]" in outs[0], outs[0][-1500:]
