@@ -49,7 +49,7 @@ CONFIGS = {   # BASELINE.json configs / SURVEY.md 8(d): size, ORB features, LBD 
     "C2": dict(w=640, h=480, nf=1000, nl=200, fx=435.2047, bf=47.9064, pairs=3072),
     "C3": dict(w=1242, h=375, nf=2000, nl=500, fx=718.856, bf=386.1448, pairs=3072),
     "C4": dict(w=752, h=480, nf=1200, nl=500, fx=435.2047, bf=47.9064, pairs=3072),
-    "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=640),
+    "C5": dict(w=1920, h=1080, nf=4000, nl=1000, fx=1050.0, bf=126.0, pairs=1536),
 }
 STAGE_KERNEL = {"orb_pyramid": "olf::k_resize_tiled", "orb_fast": "olf::k_fast_score", "orb_fast_cells": "olf::k_fast_score", "orb_octree": "olf::k_octree", "orb_blur": "olf::k_sep7",
                 "orb_describe": "olf::k_describe", "stereo_points": "olf::k_stereo_match", "lsd_front": "olf::k_lsd_keys", "lsd_grow": "olf::k_lsd_grow<0",
@@ -324,7 +324,9 @@ def main():
     # the batch lives in HBM (context buffers + outputs, 58 MB of context per KITTI pair, tools/mem_per_pair.py, plus the outputs): shrink it if this GPU has less free memory than the
     # batch needs, and use the same size on every rank
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    per_pair = 62e6 * (W * H) / (1242 * 375) * (1.15 if multi else 1.0)     # + packed records (double buffered) when they are gathered
+    # (batch contexts, > 1024 pairs: 42.5 MB per KITTI pair, 172 MB per 1080p pair since round 6 -- log sized by a bound, no owner words, work images inside the key
+    # buffers; smaller contexts keep the full-size log and the owner words: 55 MB per KITTI pair)
+    per_pair = (43e6 if B > 1024 else 62e6) * (W * H) / (1242 * 375) * (1.15 if multi else 1.0)     # + packed records (double buffered) when they are gathered
     fit = int((free_b - 6e9) / per_pair) // 64 * 64
     if fit < B:
         print(f"[rank {rank}] {free_b / 1e9:.0f} GB free: {B} pairs per step do not fit, using {max(fit, 64)}", file=sys.stderr, flush=True)

@@ -195,6 +195,10 @@ int olf_debug_lsd_groups(olf_ctx* ctx, int groups);
  * meet in its L2); 1: on consecutive workgroups, i.e. on DIFFERENT XCDs.  What crosses between groups is agent-scope traffic either way: results do
  * not depend on it (tests/test_lsd_grow_gpu.py::test_growth_groups_scattered_over_xcds), only the time does. */
 int olf_debug_lsd_scatter(olf_ctx* ctx, int on);
+/* debug/test: cap the primary pixel log of the one-wave region growing at `entries` pixels per image (0 = the context's own capacity: every pixel in
+ * contexts of up to 2048 images, half of the pixels in larger -- batch -- contexts).  Images that log more are grown again on a block of the context's spill
+ * arena inside the same call; when the arena is exhausted the call reports OLF_ERR_CAPACITY.  Results do not depend on it. */
+int olf_debug_lsd_log_cap(olf_ctx* ctx, int entries);
 /* debug / tests: the kernel that replays libstdc++'s std::sort for the LSD seed order (convention C.9 variant 1, csrc/lsd_seedsort.hip) on a
  * caller-supplied array of n <= Ws*Hs keys, (field << 22) | payload with a 10-bit field: out receives the keys whose field is <= kthr in the
  * order std::sort(keys, keys + n, field ascending) leaves them; depth_limit < 0 = introsort's own 2 * floor(log2 n), a small value forces

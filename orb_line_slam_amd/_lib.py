@@ -151,6 +151,7 @@ def lib():
         L.olf_debug_lsd_pool.argtypes = [C.c_void_p, C.c_int]
         L.olf_debug_lsd_groups.argtypes = [C.c_void_p, C.c_int]
         L.olf_debug_lsd_scatter.argtypes = [C.c_void_p, C.c_int]
+        L.olf_debug_lsd_log_cap.argtypes = [C.c_void_p, C.c_int]
         L.olf_debug_seed_sort_mode.argtypes = [C.c_void_p, C.c_int]
         L.olf_debug_seed_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
         L.olf_frames_pack_bound.argtypes = [C.c_void_p, C.c_int]

@@ -54,6 +54,7 @@ struct olf_ctx {
     hipEvent_t input_event = nullptr;  // olf_ctx_set_input_event: not owned; the fused entry's line stream waits for it instead of forking from the caller's stream
     hipEvent_t ev_lbd = nullptr;       // fused entry: the LBD gradient images are ready (computed on the ORB stream in the seed ordering's shadow)
     bool deferred_join = false;        // olf_ctx_set_deferred_join: olf_stereo_frames_dev returns with the line path still running on the line stream
+    bool scaled_aliased = false;       // batch context: the LSD working images live in the key buffers (dead before those are written)
     bool join_pending = false;         // ... and this call's line path has not been joined yet (olf_stereo_frames_join_dev, or the next call)
     // small contexts (the drop-in's one-pair-per-call shape): the eleven output arrays of olf_stereo_frames sit in ONE device slab, so that the host entry brings them
     // back with one copy into pinned memory instead of eleven (each a launch and a gap of its own: 0.44 ms of a 9 ms call, profiles/r5b_pair_timeline.txt)
@@ -266,7 +267,9 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     const OrbGeom& g = c->orb.geom;
     const size_t n = (size_t)max_images;
     OrbDeviceBufs& b = c->ob;
-#define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
+    const bool allocTrace = getenv("OLF_ALLOC_TRACE") != nullptr;      // (tools/mem_per_pair.py: every buffer of the context, per image)
+#define A(ptr, count) do { if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc); \
+                           if (allocTrace) fprintf(stderr, "alloc %-18s %8.3f MB per image\n", #ptr, (double)(count) * sizeof(*(ptr)) / 1e6 / (double)n); } while (0)
     A(b.pyr, n * g.pyrBytes); A(b.blur, n * g.pyrBytes);
     A(b.cells, n * g.totalCells * g.cellCap); A(b.cellCount, n * g.totalCells);
     A(b.cand, n * g.candTotal); A(b.candNode, n * g.candTotal); A(b.candCount, n * g.nlevels);
@@ -302,15 +305,27 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
         hipEventCreateWithFlags(&c->ev_lbd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { set_error("stream/event creation failed"); return fail(OLF_ERR_HIP); }
     LineDeviceBufs& l = c->lb;
-#define A(ptr, count) if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc)
-    A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
+#define A(ptr, count) do { if ((rc = dev_alloc(c, &(ptr), (count))) != OLF_OK) return fail(rc); \
+                           if (allocTrace) fprintf(stderr, "alloc %-18s %8.3f MB per image\n", #ptr, (double)(count) * sizeof(*(ptr)) / 1e6 / (double)n); } while (0)
+    // batch contexts (> kBatchCtxImages images): the LSD blur and the enlarged working image are dead before the key kernel / the seed sort write the key
+    // buffers (one stream, kernels in order): they live there
+    const bool batchCtx = n > (size_t)kBatchCtxImages;
+    A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
+    if (batchCtx && lg.Ps * 4 >= lg.pitchW * lg.H && lg.Ps * 4 >= lg.pitchS * lg.Hs) { l.lsdBlur = reinterpret_cast<uint8_t*>(l.keysA); l.scaled = reinterpret_cast<uint8_t*>(l.keysB); c->scaled_aliased = true; }
+    else { A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); }
     A(l.topBuf, n * (size_t)lsd_seedsort_top_words()); A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
     // chunk pool of the multi-wave growth: every pixel in a list once (Ps / 32) plus one partly filled chunk per logged region and ROB slot;
     // at least the 2 * Ps words the one-wave agent's log needs (LineGeom::regionStride, one stride for both formats).  An image that still runs out is
     // grown again by the one-wave agent (launch_lsd_grow)
     l.nChunks = lg.regionStride / 32;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
-    A(l.region, n * (size_t)lg.regionStride); l.ownerImages = (int)std::min<size_t>(n, kMwMaxImages); A(l.owner, (size_t)l.ownerImages * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    // (batch contexts: the one-wave agent only -- no owner words, a log sized by a bound (host_tables.cpp) and a spill arena of full-size logs for the images that outgrow it)
+    A(l.region, n * (size_t)lg.regionStride); l.ownerImages = batchCtx ? 0 : (int)std::min<size_t>(n, kMwMaxImages); A(l.owner, (size_t)l.ownerImages * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    // (a full-size log never spills: other contexts get an arena only when olf_debug_lsd_log_cap asks for one)
+    l.spillBlocks = lg.regionStride / 2 >= lg.Ps ? 0 : (int)std::max<size_t>(4, n / 16);      // (one image in 16 may have more than half of its pixels in logged regions)
+    if (l.spillBlocks) A(l.spill, (size_t)l.spillBlocks * 2 * lg.Ps);
+    A(l.spillCtl, 64); A(l.spillOf, n);
+    c->line.geom.logCap = lg.regionStride / 2; c->line.geom.spillBlocks = l.spillBlocks; c->line.geom.spillArena = l.spill; c->line.geom.spillCtl = l.spillCtl; c->line.geom.spillOf = l.spillOf;
     l.mgImages = (int)std::min<size_t>(n, kMgMaxImages); l.mgStride = lsd_grow_mg_stride(lg.maxRegions);
     A(l.mg, (size_t)l.mgImages * l.mgStride);
     A(l.rawLines, n * lg.maxDetect); A(l.rawCount, n); A(l.regCount, n); A(l.growFmt, n); A(l.lbdBlur, n * lg.pitchW * lg.H); A(l.dxdy, n * lg.pitchD * lg.H);
@@ -604,6 +619,27 @@ int olf_debug_lsd_groups(olf_ctx* c, int groups)
 {
     if (!c || !(groups == 0 || groups == 1 || groups == 2 || groups == 4)) { set_error("olf_debug_lsd_groups: bad argument"); return OLF_ERR_INVALID; }
     c->lb.forceG = groups > 0 ? groups : -1;
+    return OLF_OK;
+}
+
+// debug / tests: cap the one-wave agent's primary pixel log at `entries` (0: the context's own size): images whose logged regions need more move to the spill arena
+int olf_debug_lsd_log_cap(olf_ctx* c, int entries)
+{
+    if (!c || entries < 0) { set_error("olf_debug_lsd_log_cap: bad argument"); return OLF_ERR_INVALID; }
+    OLF_TRY(check_device(c, "olf_debug_lsd_log_cap"));
+    if (entries > 0 && !c->lb.spill) {      // a context whose log holds every pixel has no arena of its own
+        const size_t blocks = std::max<size_t>(2, (size_t)c->max_images - (size_t)c->max_images / 4);      // (tests: three quarters of the images may spill)
+        void* q = nullptr;
+        OLF_HIP_CHECK(hipMalloc(&q, blocks * 8 * (size_t)c->line.geom.Ps));
+        c->allocs.push_back(q);
+        c->lb.spill = static_cast<uint32_t*>(q); c->lb.spillBlocks = (int)blocks;
+    }
+    c->lb.logCapOverride = entries;
+    LineGeom& g = c->line.geom;
+    g.spillArena = c->lb.spill; g.spillBlocks = c->lb.spillBlocks;
+    g.logCap = entries > 0 ? std::min(entries, g.regionStride / 2) : g.regionStride / 2;
+    OLF_HIP_CHECK(hipDeviceSynchronize());
+    OLF_HIP_CHECK(hipMemcpy(c->lb.geom, &g, sizeof(LineGeom), hipMemcpyHostToDevice));
     return OLF_OK;
 }
 
@@ -1041,6 +1077,7 @@ int olf_lbd_compute(olf_ctx* c, const uint8_t* images, int n_images, const olf_k
 int olf_lsd_debug_scaled(olf_ctx* c, int image, uint8_t* dst, int32_t* ws, int32_t* hs)
 {
     if (!c || !dst || image < 0 || image >= c->max_images) return OLF_ERR_INVALID;
+    if (c->scaled_aliased) { set_error("olf_lsd_debug_scaled: a batch context does not keep the enlarged image (use a context of at most 2048 images)"); return OLF_ERR_INVALID; }
     const LineGeom& g = c->line.geom;
     OLF_HIP_CHECK(hipDeviceSynchronize());
     OLF_HIP_CHECK(hipMemcpy2D(dst, g.Ws, c->lb.scaled + (size_t)image * g.pitchS * g.Hs, g.pitchS, g.Ws, g.Hs, hipMemcpyDeviceToHost));

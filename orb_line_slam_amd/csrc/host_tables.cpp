@@ -226,6 +226,10 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
     g.libmFloat = p.conv_libm_float ? 1 : 0;
     g.alignDeg = p.lsd_ang_th < 90 ? (float)(180.0 - p.lsd_ang_th) : -1.f;      // (tolerances of 90 degrees and more: the folded form does not hold, k_lsd_keys decides in double)
     g.regionStride = std::max(1024 + g.Ps / 32 + 64, (2 * g.Ps + 31) / 32) * 32;
+    // batch contexts (more than kBatchCtxImages images; only the one-wave agent runs there): the log is sized for HALF of the pixels in logged regions -- the
+    // bench scene logs 105 k of 670 k, its long-line scene 231 k -- and an image that needs more is grown again on a full-size block of the spill arena by a
+    // second launch (k_lsd_grow `retry`).  The seed sort's grid-wide top levels keep their 2 * (Ps / 64 + 2 * SS_TOP_JOBS + 4) words of scratch.
+    if (max_images > kBatchCtxImages) g.regionStride = ((std::max(g.Ps, 8192) + 31) / 32) * 32;
     if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
     g.prec = kPI * p.lsd_ang_th / 180;
     {   // 2*pi - prec in 64-bit-mantissa arithmetic is exact (two doubles three binades apart), then rounded up to a double

@@ -52,6 +52,14 @@ struct LineGeom {
     int regionStride;          // 32-bit words per image of LineDeviceBufs::region: ONE stride for both pixel-list formats (chunk chains of the multi-wave growth: regionStride / 32
                                // chunks; contiguous (pixel, gradient word) log of the one-wave agent: 2 * Ps words), so a fallen-back image never lands in a neighbour's chunks
     int resizeExact;           // convention C.10: the upsampling is cv::resize INTER_LINEAR_EXACT (8-bit coefficients in rx / ry)
+    // the one-wave agent's pixel log (filled in by olf_ctx_create / olf_debug_lsd_log_cap): entries of the image's own log, and the spill arena -- blocks of Ps
+    // entries for the images that outgrow it; spillCtl[0] counts the blocks handed out in a call, spillOf[img] is the image's block or -1.  Read from here (scalar
+    // loads on the rare path) instead of travelling as kernel arguments: the agent has no scalar registers to spare
+    int logCap;
+    int spillBlocks;
+    uint32_t* spillArena;
+    int* spillCtl;
+    int* spillOf;
 };
 
 struct LineDeviceBufs {
@@ -96,7 +104,18 @@ struct LineDeviceBufs {
     int forceG = -1;               // olf_debug_lsd_groups: workgroups per image of the multi-wave growth (1, 2, 4); -1: by batch size
     int scatter = 0;               // olf_debug_lsd_scatter: the groups of an image on consecutive blocks (different XCDs) instead of on one XCD
     bool chained = false;          // the last growth wrote chunk chains (multi-wave kernel), not the contiguous log of the one-wave agent
+    // the one-wave agent's pixel log is sized by a measured bound in batch contexts (LineGeom::regionStride): an image whose logged regions outgrow it moves on
+    // to a block of the spill arena -- a full-size log (Ps entries); spillCtl[0] counts the blocks handed out in a call, spillOf[img] is the image's block or -1
+    uint32_t* spill = nullptr; int* spillCtl = nullptr; int* spillOf = nullptr; int spillBlocks = 0;
+    int logCapOverride = 0;        // olf_debug_lsd_log_cap: > 0 caps the primary log (entries) -- tests of the spill path
 };
+
+#ifdef OLF_NO_BATCH_CTX
+constexpr int kBatchCtxImages = 1 << 30;      // (A/B builds)
+#else
+constexpr int kBatchCtxImages = 2048;
+#endif
+//        // contexts for more images than this are batch contexts: the one-wave agent only (no owner words), pixel log sized by a bound + spill arena
 
 struct LineHostTables {
     LineGeom geom;

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                                  const uint32_t* __restrict__ keysAll, const int* __restrict__ keyCount,
                                                  uint32_t* __restrict__ regionAll, RegionRec* __restrict__ recsAll, int* __restrict__ regCount,
                                                  int* __restrict__ status, const AngEnt* __restrict__ ent, int* __restrict__ growFmt,
-                                                 SegCand* __restrict__ candAll)
+                                                 SegCand* __restrict__ candAll, int retry)
 {
     OLF_SET_AGENT_PRIO();
     __shared__ uint32_t s_ring[RING];
@@ -860,7 +860,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     const uint32_t* keys = keysAll + (size_t)img * g.Ps;
     // the pixel log: (x | y << 16, gradient word) per pixel -- k_lsd_rect needs the gradient norm of every region pixel and reads it from here
     // instead of gathering the word again
+    // The log: the image's own (g.logCap entries -- every pixel, or half of them in a batch context) or, in the RETRY launch, a full-size block of the spill
+    // arena.  An image whose logged regions outgrow its own log keeps running with its log writes clamped to the last entry (`over`: its regions are garbage,
+    // its USED marks are not) and is marked g.spillOf[img] = -1 at the end; the retry launch behind this one clears the image's USED bits and grows it again
+    // from its first seed; an exhausted arena is a capacity error (status 8) like every other fixed-capacity buffer.  The hot loop pays a compare and a
+    // v_min per commit.  (Built first and removed: switching logs inside the loop -- 106 scalar registers, the agent lost its eighth wave per SIMD; leaving
+    // the image with a `return` at the overflow -- exits out of the five-deep loop nest made the structurizer rebuild it with 300 more instructions.)
     uint2* reg = reinterpret_cast<uint2*>(regionAll + (size_t)img * g.regionStride);
+    int logCap = g.logCap;
+    if (retry) {
+        if (g.spillOf[img] != -1) return;
+        int blk = 0;
+        if (lane == 0) blk = atomicAdd(g.spillCtl, 1);
+        blk = __builtin_amdgcn_readfirstlane(blk);
+        if (blk >= g.spillBlocks) { if (lane == 0) { atomicOr(status, 8); regCount[img] = 0; g.spillOf[img] = 0; } return; }
+        reg = reinterpret_cast<uint2*>(g.spillArena) + (size_t)blk * g.Ps;
+        logCap = g.Ps;
+        if (lane == 0) g.spillOf[img] = blk + 1;
+        for (int q = lane; q < g.Ps; q += 64) gradAll[(size_t)img * g.Ps + q] &= ~kUsed;      // what the first attempt marked
+        __threadfence_block();
+    }
+    const uint32_t logLast = (uint32_t)logCap - 1u;
+    bool over = false;
+#ifdef OLF_NO_LOGCHECK      // (A/B builds only: the log is assumed to fit)
+#define LOG_ROOM(NEED) do { } while (0)
+#define LOG_AT(IDX) reg[rbase + (IDX)]
+#else
+#define LOG_ROOM(NEED) do { if (rbase + (NEED) > logCap) over = true; } while (0)
+#define LOG_AT(IDX) reg[min((uint32_t)(rbase + (IDX)), logLast)]
+#endif
     RegionRec* recs = recsAll + (size_t)img * g.maxRegions;
     const int nkeys = keyCount[img * 32];
     const double prec = g.prec, precWrap = g.precWrap;
@@ -901,7 +929,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     // window phase: lane L < 49 is pixel (seed.x + L % 7 - 3, seed.y + L / 7 - 3)
     constexpr unsigned long long kW49 = (1ull << 49) - 1ull, kSeedBit = 1ull << 24, kM3 = 7ull | (7ull << 7) | (7ull << 14);
     constexpr unsigned long long kRow5 = 0x3eull, kD2 = (kRow5 << 7) | (kRow5 << 14) | (kRow5 << 21) | (kRow5 << 28) | (kRow5 << 35);      // rows, columns 1 .. 5
-    const int wdr = lane / 7 - 3, wdc = lane % 7 - 3, woff = wdr * g.Ws + wdc;
+    // (one register for both offsets: the agent sits at the 64-register line of eight waves per SIMD)
+    const int wpk = ((lane % 7 - 3) & 0xffff) | ((lane / 7 - 3) << 16);
 // PIPE: what the table holds is folded into the seed masks of the current and of the next window before it is cleared -- the masks then stay complete
 // (a window's words as loaded + every pixel marked since), and a window is never gathered again
 #define PEND_FLUSH() do { ST_FLUSH ++flushEpoch; \
@@ -1006,9 +1035,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             int i = 0;
             if (WIN) {
                 // ---- window phase: gather the 7 x 7 around the seed, one lane per pixel
-                const int wx = (int)sx0 + wdc, wy = (int)sy0 + wdr;
+                const int wx = (int)sx0 + (int)(short)(wpk & 0xffff), wy = (int)sy0 + (wpk >> 16);
                 const unsigned long long winIn = kW49 & wave_vote((unsigned)wx < (unsigned)Ws) & wave_vote((unsigned)wy < (unsigned)Hs);
-                const int wa = wave_bit(winIn) ? seed + woff : 0;
+                const int wa = wave_bit(winIn) ? wy * Ws + wx : 0;
                 const uint32_t ww = grad[(uint32_t)wa];
                 const int wslot = wa & (PEND - 1);
                 const int wpend = s_pend[wslot];
@@ -1096,12 +1125,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 { unsigned long long bad = wave_vote(mine && s_pend[wslot] != wa);
                   while (bad) { PEND_FLUSH(); if (wave_bit(bad)) s_pend[wslot] = wa; __builtin_amdgcn_wave_barrier(); bad = wave_vote(wave_bit(bad) && s_pend[wslot] != wa); } }
                 if (handover || n >= minRegSize) {
-                    if (mine) { const uint32_t xy = (uint32_t)wx | ((uint32_t)wy << 16); s_ring[fidx & (RING - 1)] = xy; reg[rbase + fidx] = make_uint2(xy, ww); }
+                    LOG_ROOM(n);
+                    if (mine) { const uint32_t xy = (uint32_t)wx | ((uint32_t)wy << 16); s_ring[fidx & (RING - 1)] = xy; LOG_AT(fidx) = make_uint2(xy, ww); }
                     __builtin_amdgcn_wave_barrier();
                 }
             } else {
                 MARK_USED(seed, pseed);
-                if (lane == 0) { const uint32_t pk = sx0 | (sy0 << 16); s_ring[0] = pk; reg[rbase] = make_uint2(pk, pseed); }
+                LOG_ROOM(1);
+                if (lane == 0) { const uint32_t pk = sx0 | (sy0 << 16); s_ring[0] = pk; LOG_AT(0) = make_uint2(pk, pseed); }
                 __builtin_amdgcn_wave_barrier();
             }
 #ifdef OLF_TIMING
@@ -1139,7 +1170,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 uint32_t rp = s_ring[(i + e) & (RING - 1)];
                 asm volatile("" : "+v"(rp));        // (keeps the two loads from being merged again)
                 PEND_VERIFY();
-                if (n - i > RING) { __threadfence_block(); rp = reg[rbase + i + (wave_bit(geo) ? e : 0)].x; __builtin_amdgcn_s_waitcnt(0x0F70); }   // window left the ring: read the FIFO from memory
+                if (n - i > RING) { __threadfence_block(); rp = LOG_AT(i + (wave_bit(geo) ? e : 0)).x; __builtin_amdgcn_s_waitcnt(0x0F70); }   // window left the ring: read the FIFO from memory
                 const int xx = (int)(rp & 0xffffu) + (k % 3) - 1, yy = (int)(rp >> 16) + (k / 3) - 1;
                 const unsigned long long inImg = geo & wave_vote((unsigned)xx < (unsigned)Ws) & wave_vote((unsigned)yy < (unsigned)Hs);
                 const int a = wave_bit(inImg) ? yy * Ws + xx : 0;
@@ -1265,6 +1296,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 if (PFCAND) asm volatile("" :: "v"(pfC));
                 // the accepted lanes publish their pixel: USED bit, FIFO slot (ring + memory), pending-visibility table
                 if (acc) {
+                    LOG_ROOM(n);
                     const bool mine = wave_bit(acc);
                     const int slot = a & (PEND - 1);
                     if (wave_vote(pendv != -1) & acc) PEND_FLUSH();        // (nothing has written the table since the gather read the lane's slot)
@@ -1272,7 +1304,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                         const int idx = n0 + wave_rank_below(acc);
                         grad[a] = pw | kUsed;
                         s_ring[idx & (RING - 1)] = (uint32_t)xy;
-                        reg[rbase + idx] = make_uint2((uint32_t)xy, pw);
+                        LOG_AT(idx) = make_uint2((uint32_t)xy, pw);
                         s_pend[slot] = a;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1288,6 +1320,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             PEND_VERIFY();
 #undef PEND_VERIFY
             if (!REFINE) break;
+            if (over) break;                                 // (the log is clamped garbage from here on: the retry launch redoes the image)
             const uint2* lg = reg + rbase;
             if (!regrown) {
                 if (n < minRegSize) break;
@@ -1414,6 +1447,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
         }
         if (PFSEED) asm volatile("" :: "v"(pfA), "v"(pfB));      // (the requests are only ever waited for here)
     }
+#undef LOG_ROOM
+#undef LOG_AT
 #undef MARK_USED
 #undef PEND_FLUSH
 #undef PEND_CLEAR
@@ -1429,7 +1464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
         o[15] = nkeys; o[16] = st_win; o[17] = st_seedl; o[18] = st_regl; o[19] = st_acc; o[20] = st_isos; o[21] = st_logged; o[22] = st_winLive; o[23] = st_first; o[24] = st_cand1;
         o[25] = st_acc1; o[26] = st_wentries; o[27] = st_whand; o[28] = st_wdone; o[29] = st_wpend; }
 #endif
-    if (lane == 0) { regCount[img] = nreg; if (growFmt) growFmt[img] = 1; }
+    if (lane == 0) { regCount[img] = over ? 0 : nreg; if (growFmt) growFmt[img] = 1; if (g.spillOf && !retry) g.spillOf[img] = over ? -1 : 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1442,12 +1477,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 template <bool CHAINED>
 __device__ __forceinline__ void lsd_rect_region(const LineGeom& g, int img, int r, const uint32_t* __restrict__ gradAll,
                                                 const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
-                                                SegCand* __restrict__ candAll, const int* __restrict__ linksAll, int nChunks)
+                                                SegCand* __restrict__ candAll, const int* __restrict__ linksAll, int nChunks, const int* __restrict__ spillOf,
+                                                const uint32_t* __restrict__ spillArena)
 {
     const uint32_t* grad = gradAll + (size_t)img * g.Ps;
     const RegionRec rr = recsAll[(size_t)img * g.maxRegions + r];
     const uint32_t* px_list = CHAINED ? regionAll + (size_t)img * nChunks * 32 : nullptr;
-    const uint2* log2 = CHAINED ? nullptr : reinterpret_cast<const uint2*>(regionAll + (size_t)img * g.regionStride) + rr.start;      // (pixel, gradient word) pairs of the one-wave agent
+    // (pixel, gradient word) pairs of the one-wave agent: in the image's own log or, for an image the retry launch grew, in its block of the spill arena
+    // (spillOf: null in contexts whose log holds every pixel)
+    const int sblk = CHAINED || !spillOf ? 0 : spillOf[img];
+    const uint2* log2 = CHAINED ? nullptr
+                      : (sblk > 0 ? reinterpret_cast<const uint2*>(spillArena) + (size_t)(sblk - 1) * g.Ps
+                                  : reinterpret_cast<const uint2*>(regionAll + (size_t)img * g.regionStride)) + rr.start;
     const int* links = CHAINED ? linksAll + (size_t)img * nChunks : nullptr;
     const int n = rr.n, Ws = g.Ws;
     int cid = rr.start, nxt = -1;
@@ -1577,23 +1618,24 @@ template <bool CHAINED>
 __global__ __launch_bounds__(256) void k_lsd_rect(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
                                                   const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
                                                   const int* __restrict__ regCount, SegCand* __restrict__ candAll,
-                                                  const int* __restrict__ linksAll, int nChunks)
+                                                  const int* __restrict__ linksAll, int nChunks, const int* __restrict__ spillOf, const uint32_t* __restrict__ spillArena)
 {
     const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
     if (r >= regCount[img]) return;
-    lsd_rect_region<CHAINED>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
+    lsd_rect_region<CHAINED>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks, spillOf, spillArena);
 }
 
 // after the multi-wave growth: chunk chains, except for the images that kernel gave up and the one-wave agent grew again (growFmt 1)
 __global__ __launch_bounds__(256) void k_lsd_rect_mixed(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ gradAll,
                                                         const uint32_t* __restrict__ regionAll, const RegionRec* __restrict__ recsAll,
                                                         const int* __restrict__ regCount, SegCand* __restrict__ candAll,
-                                                        const int* __restrict__ linksAll, int nChunks, const int* __restrict__ growFmt)
+                                                        const int* __restrict__ linksAll, int nChunks, const int* __restrict__ growFmt, const int* __restrict__ spillOf,
+                                                        const uint32_t* __restrict__ spillArena)
 {
     const int img = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
     if (r >= regCount[img]) return;
-    if (growFmt[img] == 1) lsd_rect_region<false>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
-    else lsd_rect_region<true>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks);
+    if (growFmt[img] == 1) lsd_rect_region<false>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks, spillOf, spillArena);
+    else lsd_rect_region<true>(*gp, img, r, gradAll, regionAll, recsAll, candAll, linksAll, nChunks, spillOf, spillArena);
 }
 
 // LSDDetectorC::detectImpl, Vec4f -> KeyLine (LSDDetector_custom.cpp:290-307): one workgroup per image, candidates in detection order,
@@ -1734,6 +1776,7 @@ int lsd_grow_waves(int n_images)
 int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s)
 {
     const int nw = lsd_grow_path(g, b, n_images);
+    if (b.spillCtl) OLF_HIP_CHECK(hipMemsetAsync(b.spillCtl, 0, sizeof(int), s));      // blocks of the spill arena handed out in this call
     b.chained = nw != 0;
     if (nw > 0) {
         // OLF_LSD_ROB: reorder-buffer entries for experiments (a power of two in [128, 512]; anything else is ignored)
@@ -1749,23 +1792,27 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         // an image whose chunk pool or region log ran out under the multi-wave kernel (it re-runs regions, so it needs more of both than the
         // sequential replay) is grown again by the one-wave agent, whose log cannot overflow; every other workgroup of this launch exits at once
         hipLaunchKernelGGL((k_lsd_grow<0, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt, (SegCand*)nullptr);
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), b.growFmt, (SegCand*)nullptr, 0);
         OLF_HIP_CHECK(hipGetLastError());
         return OLF_OK;
     }
+    // a log smaller than the image (batch contexts, olf_debug_lsd_log_cap): a second launch grows the images that outgrew theirs again, on blocks of the spill
+    // arena; every other workgroup of it exits at once
+    for (int RETRY = 0; RETRY < (g.logCap < g.Ps ? 2 : 1); ++RETRY) {
     // (lsd_refine: the candidates go to keysA -- keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
     if (g.refine >= 2)
         hipLaunchKernelGGL((k_lsd_grow<2, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
+                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA), RETRY);
     else if (g.refine)
         hipLaunchKernelGGL((k_lsd_grow<1, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
-                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA));
+                           (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA), RETRY);
     else {
         static const int pf = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 11; }();
 #define GROW0(PFV) hipLaunchKernelGGL((k_lsd_grow<0, PFV>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
-                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr)
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr, RETRY)
         if (pf == 0) GROW0(0); else if (pf == 1) GROW0(1); else if (pf == 7) GROW0(7); else if (pf == 3) GROW0(3); else GROW0(11);
 #undef GROW0
+    }
     }
     OLF_HIP_CHECK(hipGetLastError());
     return OLF_OK;
@@ -1782,13 +1829,13 @@ int launch_lsd_rect(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     // the sorted keys (keysB) are dead once the agents are done: the 24-byte segment candidates live there
     if (b.chained)
         hipLaunchKernelGGL(k_lsd_rect_mixed, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
-                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks, b.growFmt);
+                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks, b.growFmt, g.logCap < g.Ps ? b.spillOf : (const int*)nullptr, b.spill);
     else
         // (one thread per region in index order.  Dealing an image's regions out by size -- one block per image, (size, index) keys sorted in LDS, so that a wave's 64
         // lists have similar lengths -- was built and measured: 10.2 against 8.1 ms per 6144 images (profiles/r4ac_rect_sorted_ab.txt); the fit waits for its list
         // loads, not for the longest list of its wave)
         hipLaunchKernelGGL(k_lsd_rect<false>, dim3((g.rectGrid + 255) / 256, n_images), dim3(256), 0, s, b.geom, b.grad, b.region,
-                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks);
+                           reinterpret_cast<const RegionRec*>(b.keysA), b.regCount, reinterpret_cast<SegCand*>(b.keysB), b.links, b.nChunks, g.logCap < g.Ps ? b.spillOf : (const int*)nullptr, b.spill);
     hipLaunchKernelGGL(k_lsd_emit, dim3(n_images), dim3(256), 0, s, b.geom, reinterpret_cast<const SegCand*>(b.keysB), b.regCount, b.rawLines,
                        b.rawCount, b.status);
     OLF_HIP_CHECK(hipGetLastError());

@@ -224,3 +224,82 @@ def test_message_passing_litmus_between_cus_and_xcds():
     real = [r for r in d["results"] if r and not r["variant"].startswith("control")]
     assert len(real) >= 5 and all(r["violations"] == 0 and r["distinct_flags_seen"] > 1000 for r in real), real
     assert any(r["placement"].startswith("different XCDs") for r in real)
+
+
+def _stripes(w, h):
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = (((xx // 5) % 2) * 150 + 50).astype(np.uint8)                 # vertical stripes: nearly every working pixel lies in a logged region
+    b = (((xx + yy) // 7 % 2) * 160 + 40).astype(np.uint8)            # diagonal stripes
+    return a, b
+
+
+@pytest.mark.parametrize("refine", [0, 1, 2])
+def test_pixel_log_spills_to_the_arena(oracle, refine):
+    """The one-wave agent's pixel log is sized by a bound in batch contexts; an image that outgrows it is grown again by a second launch on a block of the spill
+    arena (k_lsd_grow LOG_ROOM / `retry`, k_lsd_rect reads the block through LineGeom::spillOf).  olf_debug_lsd_log_cap forces the situation on a small
+    context: caps from "every image overflows in its first large region" to "some overflow late", with lsd_refine NONE / STD / ADV (the refining agents keep ONE
+    region in the log and read it back); every result equals the oracle, and no capacity flag is raised."""
+    w, h = 480, 360
+    sa, sb = _stripes(w, h)
+    flat = np.full((h, w), 99, np.uint8)                              # (never spills: the arena holds three blocks for these four images)
+    imgs = np.stack([synth.stereo_batch(41, 1, w, h)[0], sa, flat, sb])
+    p = oracle.full_params(1000, 0)
+    p.line.lsd_refine = refine
+    want = [oracle.line_extract(im, p.line) for im in imgs]
+    assert sum(len(o["kls"]) > 4 for o in want) == 3
+    ex = ola.Lineextractor(0, 0.025, lsd_refine=refine, max_images=len(imgs))
+    _set(ex, w, h, len(imgs), 0, 0)                                    # the one-wave agent
+    L = _lib.lib()
+    for cap in (40, 700, 20000, 0):
+        _lib.check(L.olf_debug_lsd_log_cap(ex._ctx.handle, cap), "olf_debug_lsd_log_cap")
+        kls, desc, counts = ex.extract_batch(imgs)
+        assert (_status(ex)[0] & (8 | 16)) == 0, (refine, cap)
+        for i in range(len(imgs)):
+            n = int(counts[i])
+            assert n == len(want[i]["kls"]), (refine, cap, i, n, len(want[i]["kls"]))
+            assert np.array_equal(kls[i, :n], want[i]["kls"]) and np.array_equal(desc[i, :n], want[i]["desc"]), (refine, cap, i)
+
+
+def test_exhausted_spill_arena_is_a_capacity_error():
+    """More spilling images than the arena has blocks: the call must say OLF_ERR_CAPACITY (status flag 8), not write past a log."""
+    w, h = 320, 240
+    sa, _ = _stripes(w, h)
+    imgs = np.stack([sa] * 8)
+    ex = ola.Lineextractor(0, 0.025, max_images=8)
+    _set(ex, w, h, 8, 0, 0)
+    _lib.check(_lib.lib().olf_debug_lsd_log_cap(ex._ctx.handle, 64), "olf_debug_lsd_log_cap")      # arena of 6 blocks, 8 images spill
+    with pytest.raises(_lib.OlfError):
+        ex.extract_batch(imgs)
+    _lib.check(_lib.lib().olf_debug_lsd_log_cap(ex._ctx.handle, 0), "olf_debug_lsd_log_cap")
+    kls, desc, counts = ex.extract_batch(imgs)                        # the context works again with the full log
+    assert counts.min() > 0 and np.array_equal(kls[0], kls[7])
+
+
+def test_batch_context_small_log_and_aliased_work_images(oracle):
+    """A context for more than 2048 images is a batch context: no owner words (one-wave agent only), pixel log for half of the pixels + spill arena, LSD blur
+    and enlarged image inside the key buffers.  2056 small images -- scenes, stripes (most of their pixels lie in logged regions), noise -- in one call: spot-checked
+    against the oracle, identical images must give identical results wherever they sit in the batch, and the stereo entry runs on the same context."""
+    w, h = 150, 111
+    p = oracle.full_params(300, 0)
+    p.orb.nlevels = 1
+    # (one image in 24 overflows the half-size log -- the arena holds blocks for one in 16)
+    base = list(synth.stereo_batch(19, 11, w, h)) + [_stripes(w, h)[0]] + [np.random.default_rng(3).integers(0, 256, (h, w), dtype=np.uint8)]
+    n = 2056
+    imgs = np.stack([base[i % len(base)] for i in range(n)])
+    want = [oracle.line_extract(im, p.line) for im in base]
+    ex = ola.Lineextractor(0, 0.025, max_images=n)
+    ex._params.orb.nlevels = 1
+    ex._params.orb.nfeatures = 300
+    kls, desc, counts = ex.extract_batch(imgs)
+    assert (_status(ex)[0] & (8 | 16)) == 0
+    assert int((counts[22::24] > 0).all())                           # the stripes, every one of them grown again on an arena block
+    for i in list(range(2 * len(base))) + list(range(n - len(base) - 3, n)):
+        o = want[i % len(base)]
+        m = int(counts[i])
+        assert m == len(o["kls"]), (i, m, len(o["kls"]))
+        assert np.array_equal(kls[i, :m], o["kls"]) and np.array_equal(desc[i, :m], o["desc"]), i
+    for j in range(len(base)):
+        same = counts[j::len(base)]
+        assert (same == same[0]).all(), j
+    with pytest.raises(_lib.OlfError):
+        ex.debug_scaled(0)                                             # a batch context does not keep the enlarged image
