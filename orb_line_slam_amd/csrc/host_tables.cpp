@@ -238,6 +238,16 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
         if ((long double)t < w) t = std::nextafter(t, 1e300);
         g.precWrap = t;
     }
+    {   // the cheap alignment test of the growth agent.  m = 6e-4 rad: cv::fastAtan2's polynomial is within 0.00955 degrees of the true angle over every float
+        // quotient (exhaustive: tools/micro/fastatan2_bound.c), its three reflections add 3 half-ulps of 360 (4.6e-5 degrees), together 1.7e-4 rad; the
+        // direction a table entry stands for (cos / sin of the float-rounded angle, rounded to float) is within 4e-7 rad of the entry's angle and the float dot /
+        // cross products within 4e-7 rad of the exact ones -- the margin is three times the sum
+        const double m = 6e-4;
+        if (p.lsd_ang_th <= 80.0) {
+            g.alignTanLo = std::nextafter((float)std::tan(g.prec - m), 0.f);
+            g.alignTanHi = std::nextafter((float)std::tan(g.prec + m), 1e30f);
+        } else { g.alignTanLo = -1.f; g.alignTanHi = -1.f; }
+    }
     const double pp = p.lsd_ang_th / 180;
     const double rho = p.lsd_quant / std::sin(g.prec);
     int n = 0;

@@ -48,6 +48,11 @@ struct LineGeom {
     double logNT, logEps, pProb;   // LSD_REFINE_ADV: 5 (log10 Ws + log10 Hs) / 2 + log10 11 (host libm), lsd_log_eps, ang_th / 180
     int libmFloat;             // convention C.6 (conv_libm_float): 1 = the float overloads of cos / sin / atan2 / sqrt inside LSD / KeyLine / LBD
     uint32_t divWsM; int divWsS; // idx / Ws for 0 <= idx < 2^22 without a division: __umulhi(idx, divWsM) >> divWsS (exact: host_tables.cpp)
+    // the growth agent's cheap alignment test (lsd.hip, PF bit 16): a pixel whose level-line direction d (unit vector, AngEnt::seed) makes the angle D with the
+    // region's float sums S is aligned for certain if |S x d| <= tan(prec - m) S.d - delta, not aligned for certain if |S x d| >= tan(prec + m) S.d + delta; m
+    // covers the error of cv::fastAtan2 (the reference's region angle) against the true angle of S.  alignTanLo < 0: the tolerance is too wide for the folded
+    // form (ang_th > 80 degrees) -- every decision takes the reference's expression
+    float alignTanLo, alignTanHi;
     float alignDeg;            // 180 - lsd_ang_th as a float: two level-line angles (degrees) a, b are aligned <=> | |a - b| - 180 | >= alignDeg (decided exactly in double near the boundary)
     int regionStride;          // 32-bit words per image of LineDeviceBufs::region: ONE stride for both pixel-list formats (chunk chains of the multi-wave growth: regionStride / 32
                                // chunks; contiguous (pixel, gradient word) log of the one-wave agent: 2 * Ps words), so a fallen-back image never lands in a neighbour's chunks

@@ -838,6 +838,12 @@ constexpr int PEND = 1024;   // hash table of pixels whose USED store may not be
 // on the window's outer ring, or when OLF_WIN_MAXPEND entries are pending (there its 8 entries per gather and its speculative rounds pay).  On the bench
 // scene 10.4 k regions per image have 8.4 k non-isolated starts; 6.9 k of them end inside the window (tools/grow_region_model.py), and the general loop's
 // 38.5 k iterations per image become 8.4 k window gathers + < 20 k iterations.
+// 16 = the CHEAP ALIGNMENT TEST (round 6): the reference's region angle is cv::fastAtan2 of the float sums -- 33 vector instructions for a value that is only
+// ever compared with the candidates' angles.  A candidate whose direction d = (cos a, sin a) (AngEnt::seed) satisfies |S x d| <= tan(prec - m) S.d is aligned
+// whatever fastAtan2's approximation error (m bounds it, host_tables.cpp), one with |S x d| >= tan(prec + m) S.d is not: four multiply-adds, two more and two
+// compares per lane decide all but the candidates within 0.035 degrees of the tolerance (about one decision in a thousand), and only for those is the region
+// angle evaluated and the reference's double expression taken.  The sums themselves stay the reference's float chain, so the angle can be formed at any time:
+// it is formed where the reference's expression is needed and at the end of a logged region (a region's first angle is its seed's own, not fastAtan2 of the seed sums).
 template <int REFINE, int PF>      // REFINE 0: LSD_REFINE_NONE, 1: STD, 2: ADV
 // (REFINE = 2: rect_improve / rect_nfa / nfa inlined with the AgentRect in registers need 200 VGPRs: two agents per SIMD, no scratch, no generic-pointer
 // loads; as four out-of-line functions with a stack object they were 128 VGPRs + 496 B of scratch -- 16 % slower up to 2048 images, 7 % faster at 4096)
@@ -922,7 +928,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #else
 #define ST_FLUSH
 #endif
-    constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4), WIN = !REFINE && (PF & 8);
+    constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4), WIN = !REFINE && (PF & 8), CHEAP = !REFINE && (PF & 16);
+    const float tanLo = g.alignTanLo, tanHi = g.alignTanHi;      // (a tolerance too wide for the folded test -- alignTanLo < 0 -- takes the kernel without the bit: launch_lsd_grow)
+    constexpr float kAlDelta = 1e-4f;      // sums shorter than this decide nothing (fastAtan2 of a vanishing vector is dominated by its epsilon)
+// the lanes whose direction DIR is aligned / not aligned with the sums (SX, SY) for certain (garbage in the lanes that hold no table entry)
+#define ALIGN_CHEAP(SX, SY, DIR, SA, SN) do { const float _dot = __fmaf_rn((SY), (DIR).y, __fmul_rn((SX), (DIR).x)); \
+                                              const float _crs = __fmaf_rn((SX), (DIR).y, -__fmul_rn((SY), (DIR).x)); \
+                                              SA = wave_vote(fabsf(_crs) <= __fmaf_rn(tanLo, _dot, -kAlDelta)); \
+                                              SN = wave_vote(fabsf(_crs) >= __fmaf_rn(tanHi, _dot, kAlDelta)); } while (0)
+// reg_angle as the reference has it at this point (CHEAP keeps the sums only: a region's first angle is its seed's own, every later one fastAtan2 of the sums)
+#define ENSURE_ANGLE() do { if (CHEAP) reg_angle = n == 1 ? rlane_d(seedAng, l) : d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads); } while (0)
 #ifndef OLF_WIN_MAXPEND
 #define OLF_WIN_MAXPEND 16
 #endif
@@ -1043,8 +1058,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 const int wpend = s_pend[wslot];
                 unsigned long long live = winIn & wave_vote(!(ww & (kUsed | kNotDef))) & wave_vote(wpend != wa) & ~kSeedBit;
                 double wang, wcs, wsn;
-                asm volatile("" : "=v"(wang), "=v"(wcs), "=v"(wsn));
-                if (wave_bit(live)) { const AngEnt* t = ent + (ww & 0x3fffffu); wcs = t->cs; wsn = t->sn; wang = t->ang; }
+                float2 wdir;
+                if (CHEAP) asm volatile("" : "=v"(wcs), "=v"(wsn), "=v"(wdir.x), "=v"(wdir.y)); else asm volatile("" : "=v"(wang), "=v"(wcs), "=v"(wsn));
+                if (wave_bit(live)) { const AngEnt* t = ent + (ww & 0x3fffffu); wcs = t->cs; wsn = t->sn; if (CHEAP) wdir = t->seed; else wang = t->ang; }
                 int fidx = lane == 24 ? 0 : -1;          // this pixel's place in the FIFO
                 unsigned long long accM = kSeedBit;      // the region's pixels inside the window
 #ifdef OLF_STATS
@@ -1052,7 +1068,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #endif
 // (lanes aligned with the region angle, live or not; lanes that hold no table entry give garbage -- every use is masked with `live`)
 #define WIN_ALIGNED(TH) ({ const double _n = fabs(d_sub((TH), wang)); wave_vote(_n <= prec) | wave_vote(_n >= precWrap); })
-                unsigned long long alM = WIN_ALIGNED(reg_angle);
+// CHEAP: the cheap test on the sums (SX, SY); a live pixel it cannot decide sends every lane to the reference's expression under the angle TH (evaluated there only)
+#define WIN_ALIGNED_C(SX, SY, TH) ({ unsigned long long _sa, _sn; ALIGN_CHEAP(SX, SY, wdir, _sa, _sn); \
+                                     if (live & ~(_sa | _sn)) { asm volatile("" : "=v"(wang)); if (wave_bit(live)) wang = ent[ww & 0x3fffffu].ang; _sa = WIN_ALIGNED(TH); } _sa; })
+                unsigned long long alM = CHEAP ? WIN_ALIGNED_C(sumdx, sumdy, reg_angle) : WIN_ALIGNED(reg_angle);
                 // FIFO entries [i, lim) are replayed here: lim = min(n, place of the first pixel on the window's outer ring -- its 3 x 3 looks outside);
                 // a long FIFO is what the general loop's 8 entries per gather are for
                 int lim = 1, ringAt = 1 << 20;
@@ -1073,7 +1092,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                 const double cs_c = rlane_d(wcs, c), sn_c = rlane_d(wsn, c);
                                 sumdx = (float)d_add((double)sumdx, cs_c);
                                 sumdy = (float)d_add((double)sumdy, sn_c);
-                                reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                                if (!CHEAP) reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
                             } else {
                                 // several: speculate that they are accepted in lane order (the general loop's round, without its duplicate views -- a pixel is one
                                 // lane here).  Lane L keeps the sums in force at its turn; lane 63, never a candidate, ends with the sums after all of them.
@@ -1088,9 +1107,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                     if (lane > c) { bsx = sx; bsy = sy; }
                                 } while (todo);
                                 const int c0 = __builtin_ctzll(al);
-                                const double thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);
-                                const double thg = lane <= c0 ? reg_angle : thOwn;
-                                const unsigned long long reM = WIN_ALIGNED(thg);
+                                double thOwn = 0;
+                                unsigned long long reM;
+                                if (CHEAP) {
+                                    // (lanes up to c0 hold the sums before the round: their test is alM's)
+                                    reM = WIN_ALIGNED_C(bsx, bsy, ({ ENSURE_ANGLE(); lane <= c0 ? reg_angle : d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads); }));
+                                } else {
+                                    thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);
+                                    const double thg = lane <= c0 ? reg_angle : thOwn;
+                                    reM = WIN_ALIGNED(thg);
+                                }
                                 const unsigned long long mis = (reM ^ alM) & cand;          // a decision that differs under the angle that governs it
                                 const int mLane = mis ? __builtin_ctzll(mis) : 63;
                                 const unsigned long long bm = mis ? ((1ull << mLane) - 1ull) : ~0ull;
@@ -1100,11 +1126,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                 // the state after the committed accepts: what the first undecided lane sees before its turn, or lane 63 after all of them
                                 sumdx = __int_as_float(rlane(__float_as_int(bsx), mLane));
                                 sumdy = __int_as_float(rlane(__float_as_int(bsy), mLane));
-                                reg_angle = rlane_d(thOwn, mLane);
+                                if (!CHEAP) reg_angle = rlane_d(thOwn, mLane);
                             }
                             live &= ~acc1; accM |= acc1;
                             if (const unsigned long long rm = acc1 & ~kD2) ringAt = min(ringAt, n0 + __popcll(acc1 & ((1ull << __builtin_ctzll(rm)) - 1ull)));
-                            alM = WIN_ALIGNED(reg_angle);
+                            alM = CHEAP ? WIN_ALIGNED_C(sumdx, sumdy, ({ ENSURE_ANGLE(); reg_angle; })) : WIN_ALIGNED(reg_angle);
                             cand &= after;                                   // the entry's later neighbours, under the new angle
                             al = cand & alM;
                         } while (al);
@@ -1114,6 +1140,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 }
                 const bool handover = i < n;
 #undef WIN_ALIGNED
+#undef WIN_ALIGNED_C
 #ifdef OLF_STATS
                 st_acc1 += n - 1; st_wentries += i; if (handover) { ++st_whand; st_wpend += n - i; } else ++st_wdone;
 #endif
@@ -1181,12 +1208,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                 unsigned long long cm = inImg & wave_vote(!(pw & (kUsed | kNotDef))) & wave_vote(pendv != a);
                 // (left undefined for the lanes that are no candidates: nothing below looks at them, and three 64-bit zero moves per step are saved)
                 double ang, cs, sn;
-                asm volatile("" : "=v"(ang), "=v"(cs), "=v"(sn));
+                float2 dir;
+                if (CHEAP) asm volatile("" : "=v"(cs), "=v"(sn), "=v"(dir.x), "=v"(dir.y)); else asm volatile("" : "=v"(ang), "=v"(cs), "=v"(sn));
                 PSTAMP(p_gather);
                 uint32_t pfC = 0;
                 if (wave_bit(cm)) {
                     const AngEnt* t = ent + (pw & 0x3fffffu);      // one 32-byte sector per candidate
-                    cs = t->cs; sn = t->sn; ang = t->ang;
+                    cs = t->cs; sn = t->sn;
+                    if (CHEAP) dir = t->seed; else ang = t->ang;
                     // PFCAND: an accepted candidate is a FIFO entry of the next step, whose gather reaches one row further out (issued behind the table
                     // loads: vector memory returns in order)
                     if (PFCAND) { const int ar = a + pfOff; if ((unsigned)ar < (unsigned)g.Ps && pfOff != 0) pfC = grad[ar]; }
@@ -1205,10 +1234,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                     // (Sterbenz), so the wrapped test is n >= 2pi - prec, with that bound rounded up to a double on the host (precWrap);
                     // angles lie in [0, 2pi], so n never exceeds 2pi + prec.
                     // (votes per comparison, combined as lane masks: a vote on the combined predicate costs a v_cndmask + v_cmp pair on top)
+                    unsigned long long wasM;
+                    if (CHEAP) {
+                        unsigned long long sN;
+                        ALIGN_CHEAP(sumdx, sumdy, dir, wasM, sN);
+                        if (cm & ~(wasM | sN)) {      // a candidate within the margin of the tolerance: the reference's expression for everybody
+                            ENSURE_ANGLE();
+                            double angx;
+                            asm volatile("" : "=v"(angx));
+                            if (wave_bit(cm)) angx = ent[pw & 0x3fffffu].ang;
+                            const double nth = fabs(d_sub(reg_angle, angx));
+                            wasM = wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+                        }
+                    } else {
                     const double nth = fabs(d_sub(reg_angle, ang));
                     // (REFINE: the tolerance of a second growth is computed on the device, so the wrapped test keeps its original form)
-                    const unsigned long long wasM = REFINE ? wave_vote((nth > kM32PI ? fabs(d_sub(nth, kM2PI)) : nth) <= precC)
-                                                           : wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+                    wasM = REFINE ? wave_vote((nth > kM32PI ? fabs(d_sub(nth, kM2PI)) : nth) <= precC)
+                                  : wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
+                    }
                     const unsigned long long al = wasM & cm;      // cm only ever holds live candidates
                     if (!al) break;
 #ifndef OLF_GROW_SINGLE_MAX
@@ -1227,7 +1270,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                         ++n;
                         sumdx = (float)d_add((double)sumdx, cs_c);
                         sumdy = (float)d_add((double)sumdy, sn_c);
-                        reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
+                        if (!CHEAP) reg_angle = d_mul((double)agent_fastAtan2(sumdy, sumdx), kDegToRads);
                         cm &= ~wave_vote(a == a_c);                   // the same pixel seen through another FIFO entry of this batch
                         continue;
                     }
@@ -1260,11 +1303,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                     const unsigned long long freeM = ~cm;
                     const int spare = freeM ? __builtin_ctzll(freeM) : 0;
                     if (freeM && lane == spare) { bsx = sx; bsy = sy; }
-                    const double thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);     // the angle in force at this lane's turn (spare: after all accepts)
+                    double thOwn = 0;
+                    unsigned long long reM;
+                    if (CHEAP) {
+                        // every candidate against the sums in force at its turn (lanes up to c0: the sums before the round, i.e. wasM's test again)
+                        unsigned long long sN;
+                        ALIGN_CHEAP(bsx, bsy, dir, reM, sN);
+                        if (cm & ~dupM & ~(reM | sN)) {
+                            ENSURE_ANGLE();
+                            double angx;
+                            asm volatile("" : "=v"(angx));
+                            if (wave_bit(cm)) angx = ent[pw & 0x3fffffu].ang;
+                            const double thg = lane <= c0 ? reg_angle : d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);
+                            const double n2 = fabs(d_sub(thg, angx));
+                            reM = wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+                        }
+                    } else {
+                    thOwn = d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);     // the angle in force at this lane's turn (spare: after all accepts)
                     const double thg = lane <= c0 ? reg_angle : thOwn;                              // nothing accepted before this lane: the current, exact angle
                     const double n2 = fabs(d_sub(thg, ang));
-                    const unsigned long long reM = REFINE ? wave_vote((n2 > kM32PI ? fabs(d_sub(n2, kM2PI)) : n2) <= precC)
-                                                          : wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+                    reM = REFINE ? wave_vote((n2 > kM32PI ? fabs(d_sub(n2, kM2PI)) : n2) <= precC)
+                                 : wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);
+                    }
                     const unsigned long long mis = (reM ^ wasM) & ~dupM & cm;
                     const int mLane = mis ? __builtin_ctzll(mis) : 64;               // everything below the first changed decision is decided
                     const unsigned long long bm = mis ? ((1ull << mLane) - 1ull) : ~0ull;
@@ -1282,10 +1342,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                         const int src = left ? __builtin_ctzll(left) : spare;
                         sumdx = __int_as_float(rlane(__float_as_int(bsx), src));
                         sumdy = __int_as_float(rlane(__float_as_int(bsy), src));
-                        reg_angle = rlane_d(thOwn, src);
+                        if (!CHEAP) reg_angle = rlane_d(thOwn, src);
                     } else {      // all 64 lanes held live candidates and all of the round committed (never seen on images): the final angle on its own
                         sumdx = sx; sumdy = sy;
-                        reg_angle = d_mul((double)agent_fastAtan2(sy, sx), kDegToRads);
+                        if (!CHEAP) reg_angle = d_mul((double)agent_fastAtan2(sy, sx), kDegToRads);
                     }
                 }
                 PSTAMP(p_chain);
@@ -1319,6 +1379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             }
             PEND_VERIFY();
 #undef PEND_VERIFY
+            if (CHEAP && n >= minRegSize) ENSURE_ANGLE();      // (a region that will be logged: the reference's final region angle)
             if (!REFINE) break;
             if (over) break;                                 // (the log is clamped garbage from here on: the retry launch redoes the image)
             const uint2* lg = reg + rbase;
@@ -1447,6 +1508,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
         }
         if (PFSEED) asm volatile("" :: "v"(pfA), "v"(pfB));      // (the requests are only ever waited for here)
     }
+#undef ALIGN_CHEAP
+#undef ENSURE_ANGLE
 #undef LOG_ROOM
 #undef LOG_AT
 #undef MARK_USED
@@ -1807,10 +1870,11 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
         hipLaunchKernelGGL((k_lsd_grow<1, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA), RETRY);
     else {
-        static const int pf = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 11; }();
+        static const int pfEnv = [] { const char* e = getenv("OLF_GROW_PF"); return e ? atoi(e) : 27; }();
+        const int pf = g.alignTanLo < 0.f ? (pfEnv & ~16) : pfEnv;      // (ang_th > 80 degrees: no cheap alignment test)
 #define GROW0(PFV) hipLaunchKernelGGL((k_lsd_grow<0, PFV>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
                            reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr, RETRY)
-        if (pf == 0) GROW0(0); else if (pf == 1) GROW0(1); else if (pf == 7) GROW0(7); else if (pf == 3) GROW0(3); else GROW0(11);
+        if (pf == 0) GROW0(0); else if (pf == 3) GROW0(3); else if (pf == 11) GROW0(11); else if (pf == 19) GROW0(19); else GROW0(27);
 #undef GROW0
     }
     }
