@@ -217,6 +217,12 @@ int olf_debug_fdiv_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread
 /* debug/test: the lean sqrt(n / 4.0) of the LSD key kernel (ll_angle's gradient norm; lsd_device.hpp sqrt_quarter) against the compiler's IEEE
  * sqrt on every integer n in [0, count); *mismatches = number of results that differ in any bit (must be 0). */
 int olf_debug_sqrtq_sweep(olf_ctx* ctx, int count, uint64_t* mismatches);
+/* debug/test: the growth agent's cheap alignment test (dot / cross products of the region's float sums with a candidate's tabulated direction, decided under a
+ * margin that bounds cv::fastAtan2's error -- csrc/lsd.hip, PF bit 16) against the reference's expression |fastAtan2(sums) * DEG2RAD - angle| <= prec
+ * (OpenCV lsd.cpp isAligned as called by region_grow; LSDDetector_custom.cpp:246,262) on blocks*256*per_thread pseudo-random (sums, candidate) pairs, three
+ * quarters of them within 3 mrad of the tolerance: out3[0] = certain decisions that contradict the reference (must be 0), out3[1] = decisions left to the
+ * reference's expression, out3[2] = all. */
+int olf_debug_align_sweep(olf_ctx* ctx, uint64_t seed, int blocks, int per_thread, uint64_t* out3);
 
 /* ---- Frame::ComputeStereoMatches (src/Frame.cc:702-876) ------------------------------------- */
 /* Stereo point matching for n_pairs pairs whose ORB features (images 2p = left, 2p+1 = right) came from

@@ -164,6 +164,7 @@ def lib():
         L.olf_debug_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         L.olf_debug_fdiv_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.olf_debug_sqrtq_sweep.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.olf_debug_align_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.olf_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.olf_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.olf_voc_load_text.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]

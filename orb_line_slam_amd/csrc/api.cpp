@@ -741,6 +741,19 @@ int olf_debug_sqrtq_sweep(olf_ctx* c, int count, uint64_t* mismatches)
     return OLF_OK;
 }
 
+int olf_debug_align_sweep(olf_ctx* c, uint64_t seed, int blocks, int per_thread, uint64_t* out3)
+{
+    if (!c || !out3 || blocks < 1 || per_thread < 1) { set_error("olf_debug_align_sweep: bad argument"); return OLF_ERR_INVALID; }
+    if (c->line.geom.alignTanLo < 0.f) { set_error("olf_debug_align_sweep: the cheap alignment test is off for lsd_ang_th > 80 degrees"); return OLF_ERR_INVALID; }
+    void* st = nullptr;
+    OLF_TRY(scratch_get(c, 1, 64, &st));
+    OLF_HIP_CHECK(hipMemsetAsync(st, 0, 24, c->stream));
+    OLF_TRY(launch_align_sweep(c->lb, (unsigned long long)seed, blocks, per_thread, (unsigned long long*)st, c->stream));
+    OLF_HIP_CHECK(hipMemcpyAsync(out3, st, 24, hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return OLF_OK;
+}
+
 int olf_orb_debug_candidates(olf_ctx* c, int image, int level, int32_t* xys, int cap, int32_t* count)
 {
     if (!c || !xys || !count || image < 0 || image >= c->max_images || level < 0 || level >= c->orb.geom.nlevels) return OLF_ERR_INVALID;

@@ -141,6 +141,7 @@ int launch_gauss7_img(const uint8_t* src, int srcPitch, size_t srcStride, uint8_
 int launch_lsd_angle_table(LineDeviceBufs& b, int libmFloat, hipStream_t s);
 int launch_fdiv_sweep(unsigned long long seed, int blocks, int per_thread, unsigned long long* d_mismatches, hipStream_t s);
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s);
+int launch_align_sweep(const LineDeviceBufs& b, unsigned long long seed, int blocks, int per_thread, unsigned long long* d_out, hipStream_t s);
 int lsd_sort_max_chunks(int Ps);
 size_t lsd_grow_mg_stride(int maxRegions);   // bytes per image of LineDeviceBufs::mg
 constexpr int kMwMaxImages = 3072;           // images per call up to which the multi-wave growth is chosen (lsd_grow_waves)

@@ -542,6 +542,53 @@ __global__ __launch_bounds__(256) void k_sqrtq_sweep(int count, unsigned long lo
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// debug / test: the growth agent's cheap alignment test (k_lsd_grow, PF bit 16) against the reference's expression.  Every thread takes pseudo-random table
+// entries (the candidate pixel: angle a, direction d) and float sums S -- lengths from 0.6 to 6000, directions concentrated within 3 mrad of a +- prec, where
+// the two tests can disagree, the rest uniform -- and counts: out[0] decisions the cheap test called certain that differ from
+// |fastAtan2(S) * DEG2RAD - a| (wrapped) <= prec, out[1] decisions it left to the reference's expression, out[2] all.
+__global__ __launch_bounds__(256) void k_align_sweep(const LineGeom* __restrict__ gp, const AngEnt* __restrict__ ent, unsigned long long seed, int per_thread,
+                                                     unsigned long long* __restrict__ out)
+{
+    const LineGeom& g = *gp;
+    const float tanLo = g.alignTanLo, tanHi = g.alignTanHi;
+    const double prec = g.prec, precWrap = g.precWrap;
+    unsigned long long x = seed ^ ((unsigned long long)(blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull);
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    next(); next();
+    unsigned long long bad = 0, und = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        const unsigned long long r = next(), r2 = next();
+        // a gradient pair as images have them (|g| <= 510; small gradients are the common ones)
+        const int span = (r & 3) ? 40 : 510;
+        const int gx = (int)((r >> 2) % (2 * span + 1)) - span, gy = (int)((r >> 24) % (2 * span + 1)) - span;
+        const AngEnt e = ent[pack_g(gx, gy)];
+        const double u = (double)(r2 & 0xfffff) / 1048576.0;               // [0, 1)
+        const double len = 0.6 * exp(9.2 * (double)((r2 >> 20) & 0xfffff) / 1048576.0);
+        double th;
+        if ((r2 >> 40) & 3) th = e.ang + (((r2 >> 42) & 1) ? prec : -prec) + (u - 0.5) * 6e-3;
+        else th = u * kM2PI;
+        const float sx = (float)(len * cos(th)), sy = (float)(len * sin(th));
+        // the reference: region angle = fastAtan2 of the float sums, compared in double
+        const double reg_angle = d_mul((double)agent_fastAtan2(sy, sx), kDegToRads);
+        const double nth = fabs(d_sub(reg_angle, e.ang));
+        const bool exact = nth <= prec || nth >= precWrap;
+        const float dot = __fmaf_rn(sy, e.seed.y, __fmul_rn(sx, e.seed.x));
+        const float crs = __fmaf_rn(sx, e.seed.y, -__fmul_rn(sy, e.seed.x));
+        const bool sa = fabsf(crs) <= __fmaf_rn(tanLo, dot, -1e-4f), sn = fabsf(crs) >= __fmaf_rn(tanHi, dot, 1e-4f);
+        if (sa && sn) ++bad;
+        else if (sa || sn) bad += sa != exact;
+        else ++und;
+    }
+    atomicAdd(out, bad); atomicAdd(out + 1, und); atomicAdd(out + 2, (unsigned long long)per_thread);
+}
+
+int launch_align_sweep(const LineDeviceBufs& b, unsigned long long seed, int blocks, int per_thread, unsigned long long* d_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_align_sweep, dim3(blocks), dim3(256), 0, s, b.geom, reinterpret_cast<const AngEnt*>(b.angEnt), seed, per_thread, d_out);
+    OLF_HIP_CHECK(hipGetLastError());
+    return OLF_OK;
+}
+
 int launch_sqrtq_sweep(int count, unsigned long long* d_mismatches, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sqrtq_sweep, dim3((count + 255) / 256), dim3(256), 0, s, count, d_mismatches);
@@ -1070,7 +1117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #define WIN_ALIGNED(TH) ({ const double _n = fabs(d_sub((TH), wang)); wave_vote(_n <= prec) | wave_vote(_n >= precWrap); })
 // CHEAP: the cheap test on the sums (SX, SY); a live pixel it cannot decide sends every lane to the reference's expression under the angle TH (evaluated there only)
 #define WIN_ALIGNED_C(SX, SY, TH) ({ unsigned long long _sa, _sn; ALIGN_CHEAP(SX, SY, wdir, _sa, _sn); \
-                                     if (live & ~(_sa | _sn)) { asm volatile("" : "=v"(wang)); if (wave_bit(live)) wang = ent[ww & 0x3fffffu].ang; _sa = WIN_ALIGNED(TH); } _sa; })
+                                     if (live & ~(_sa | _sn)) { asm volatile("" : "=v"(wang)); uint32_t _wx = ww; asm volatile("" : "+v"(_wx)); if (wave_bit(live)) wang = ent[_wx & 0x3fffffu].ang; _sa = WIN_ALIGNED(TH); } _sa; })
                 unsigned long long alM = CHEAP ? WIN_ALIGNED_C(sumdx, sumdy, reg_angle) : WIN_ALIGNED(reg_angle);
                 // FIFO entries [i, lim) are replayed here: lim = min(n, place of the first pixel on the window's outer ring -- its 3 x 3 looks outside);
                 // a long FIFO is what the general loop's 8 entries per gather are for
@@ -1242,7 +1289,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                             ENSURE_ANGLE();
                             double angx;
                             asm volatile("" : "=v"(angx));
-                            if (wave_bit(cm)) angx = ent[pw & 0x3fffffu].ang;
+                            { uint32_t pwx = pw; asm volatile("" : "+v"(pwx)); if (wave_bit(cm)) angx = ent[pwx & 0x3fffffu].ang; }      // (opaque: the address arithmetic stays on this path)
                             const double nth = fabs(d_sub(reg_angle, angx));
                             wasM = wave_vote(nth <= prec) | wave_vote(nth >= precWrap);
                         }
@@ -1313,7 +1360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                             ENSURE_ANGLE();
                             double angx;
                             asm volatile("" : "=v"(angx));
-                            if (wave_bit(cm)) angx = ent[pw & 0x3fffffu].ang;
+                            { uint32_t pwx = pw; asm volatile("" : "+v"(pwx)); if (wave_bit(cm)) angx = ent[pwx & 0x3fffffu].ang; }
                             const double thg = lane <= c0 ? reg_angle : d_mul((double)agent_fastAtan2(bsy, bsx), kDegToRads);
                             const double n2 = fabs(d_sub(thg, angx));
                             reM = wave_vote(n2 <= prec) | wave_vote(n2 >= precWrap);

@@ -24,3 +24,20 @@ def test_key_kernel_sqrt_is_ieee_exact():
     bad = C.c_uint64(123)
     _lib.check(_lib.lib().olf_debug_sqrtq_sweep(ctx.handle, 1 << 20, C.byref(bad)), "olf_debug_sqrtq_sweep")
     assert bad.value == 0, bad.value
+
+
+@pytest.mark.parametrize("ang_th", [22.5, 10.0, 45.0, 80.0])
+def test_cheap_alignment_test_never_contradicts_the_reference(ang_th):
+    """The growth agent decides `is this pixel aligned with the region` from dot / cross products of the float sums with the pixel's tabulated direction and
+    forms the reference's region angle (cv::fastAtan2 of the sums) only for the decisions inside a margin around the tolerance (lsd.hip, PF bit 16).  Over
+    3 x 2^28 (sums, candidate) pairs, three quarters of them within 3 mrad of the tolerance, no decision it calls certain differs from the reference's
+    |fastAtan2(sums) * DEG2RAD - angle| <= prec, and the margin is not hit by more than the share of the samples that was aimed at it."""
+    p = _lib.default_params()
+    p.line.lsd_ang_th = ang_th
+    ctx = _lib.Context(p, 640, 480, 1)
+    for seed in (3, 0xC0FFEE, 20260929):
+        out = (C.c_uint64 * 3)()
+        _lib.check(_lib.lib().olf_debug_align_sweep(ctx.handle, seed, 4096, 256, out), "olf_debug_align_sweep")
+        assert out[2] == 4096 * 256 * 256
+        assert out[0] == 0, (ang_th, seed, list(out))
+        assert out[1] < out[2] // 2, list(out)
