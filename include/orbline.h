@@ -208,6 +208,12 @@ int olf_debug_seed_sort(olf_ctx* ctx, const uint32_t* keys, int n, int kthr, int
  * drop-in's one-pair-per-call shape), 3 / 4: groups of 4 / 8 images per workgroup whose waves take over each other's ranges (large batches), 5: 2 waves per image,
  * -1: chosen from the batch size.  Results do not depend on it. */
 int olf_debug_seed_sort_mode(olf_ctx* ctx, int mode);
+/* debug / tests: the seed-order kernel of the capacity path (csrc/lsd_wide.hip: lsd_n_bins > 1024 or an LSD working image of 2^22 pixels and more -- free YAML
+ * keys of the reference, src/Config.cpp:268,274) on a caller-supplied array of 64-bit keys (field << 32 | payload).  full = 0: the order libstdc++'s
+ * std::sort(begin, end, field ascending) leaves (convention C.9 variant 1, OpenCV lsd.cpp ll_angle); full = 1: ascending whole words (variant 0).  Keys whose
+ * field is <= kthr are listed: out receives their payloads in order, *out_n their number.  depth_limit: introsort's depth limit (-1: 2 * floor(log2 n)).  The
+ * context must be a wide one. */
+int olf_debug_seed_sort_wide(olf_ctx* ctx, const uint64_t* keys, int n, int64_t kthr, int depth_limit, int full, uint32_t* out, int32_t* out_n);
 /* debug / tests: cap the 32-pixel chunk pool the multi-wave growth may use per image (0: all of it).  An image that exhausts the pool is grown
  * again by the one-wave agent inside the same call -- the result does not change, only the time. */
 int olf_debug_lsd_pool(olf_ctx* ctx, int pool_chunks);

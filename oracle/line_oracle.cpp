@@ -774,6 +774,54 @@ void orc_introsort_keys(const uint32_t* keys, int n, int depth_limit, uint32_t* 
     std::memcpy(out, A.data(), (size_t)n * 4);
 }
 
+// The two sorts above on 64-bit keys (field << 32 | payload) -- the keys of the capacity path (csrc/lsd_wide.hip: lsd_n_bins > 1024 or a working image of 2^22
+// pixels and more).  full = 0: compared by the field alone (convention C.9 variant 1: what std::sort leaves for ll_angle's {point, norm} vector); full = 1: whole
+// words (variant 0: the defined pixels' keys are distinct and ascend with the address inside a field, so any sort gives the stable order).
+void orc_std_sort_keys64(const uint64_t* keys, int n, int full, uint64_t* out)
+{
+    std::vector<uint64_t> v(keys, keys + n);
+    if (full) std::sort(v.begin(), v.end());
+    else std::sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); });
+    std::memcpy(out, v.data(), (size_t)n * 8);
+}
+
+void orc_introsort_keys64(const uint64_t* keys, int n, int depth_limit, int full, uint64_t* out)
+{
+    std::vector<uint64_t> A(keys, keys + n);
+    auto K = [full](uint64_t e) { return full ? e : (e >> 32); };
+    auto lt = [&](uint64_t a, uint64_t b) { return K(a) < K(b); };
+    struct R { int f, l, d; };
+    std::vector<R> stack;
+    if (n > 0) stack.push_back({0, n, depth_limit});
+    while (!stack.empty()) {
+        R r = stack.back(); stack.pop_back();
+        int first = r.f, last = r.l, depth = r.d;
+        while (last - first > 16) {
+            if (depth == 0) { std::partial_sort(A.begin() + first, A.begin() + last, A.begin() + last, lt); break; }
+            --depth;
+            const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+            if (lt(A[a], A[b])) { if (lt(A[b], A[c])) std::swap(A[first], A[b]); else if (lt(A[a], A[c])) std::swap(A[first], A[c]); else std::swap(A[first], A[a]); }
+            else if (lt(A[a], A[c])) std::swap(A[first], A[a]);
+            else if (lt(A[b], A[c])) std::swap(A[first], A[c]);
+            else std::swap(A[first], A[b]);
+            const uint64_t piv = A[first];
+            int i = first + 1, j = last;
+            for (;;) {
+                while (lt(A[i], piv)) ++i;
+                --j;
+                while (lt(piv, A[j])) --j;
+                if (!(i < j)) break;
+                std::swap(A[i], A[j]);
+                ++i;
+            }
+            stack.push_back({i, last, depth});
+            last = i;
+        }
+    }
+    std::stable_sort(A.begin(), A.end(), lt);
+    std::memcpy(out, A.data(), (size_t)n * 8);
+}
+
 int orc_lsd_detect(const uint8_t* img, int w, int h, const olf_line_params* P, float* segs, int cap, int* n, uint8_t* scaled, int* sw, int* sh)
 {
     Image im(w, h);

@@ -165,6 +165,7 @@ def lib():
         L.olf_debug_fdiv_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.olf_debug_sqrtq_sweep.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
         L.olf_debug_align_sweep.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.olf_debug_seed_sort_wide.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
         L.olf_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.olf_voc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.olf_voc_load_text.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]

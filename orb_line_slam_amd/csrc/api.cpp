@@ -310,7 +310,8 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     // batch contexts (> kBatchCtxImages images): the LSD blur and the enlarged working image are dead before the key kernel / the seed sort write the key
     // buffers (one stream, kernels in order): they live there
     const bool batchCtx = n > (size_t)kBatchCtxImages;
-    A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps); A(l.keysB, n * lg.Ps);
+    const size_t keyWords = lg.wide ? 2 : 1;      // (64-bit sort keys: lsd_wide.hip)
+    A(l.grad, n * lg.Ps); A(l.keysA, n * lg.Ps * keyWords); A(l.keysB, n * lg.Ps * keyWords);
     if (batchCtx && lg.Ps * 4 >= lg.pitchW * lg.H && lg.Ps * 4 >= lg.pitchS * lg.Hs) { l.lsdBlur = reinterpret_cast<uint8_t*>(l.keysA); l.scaled = reinterpret_cast<uint8_t*>(l.keysB); c->scaled_aliased = true; }
     else { A(l.lsdBlur, n * lg.pitchW * lg.H); A(l.scaled, n * lg.pitchS * lg.Hs); }
     A(l.topBuf, n * (size_t)lsd_seedsort_top_words()); A(l.keyCount, n * 32); A(l.maxN, n * 32); A(l.chunkCnt, n * ((lg.Ps + 4095) / 4096)); A(l.sortHist, n * (size_t)lsd_sort_max_chunks(lg.Ps) * 32); A(l.sortBase, n * 32);
@@ -320,7 +321,7 @@ int olf_ctx_create(const olf_params* p, int width, int height, int max_images, o
     l.nChunks = lg.regionStride / 32;
     // region: chunk pool of the multi-wave growth / 8-byte (pixel, gradient word) log of the one-wave agent
     // (batch contexts: the one-wave agent only -- no owner words, a log sized by a bound (host_tables.cpp) and a spill arena of full-size logs for the images that outgrow it)
-    A(l.region, n * (size_t)lg.regionStride); l.ownerImages = batchCtx ? 0 : (int)std::min<size_t>(n, kMwMaxImages); A(l.owner, (size_t)l.ownerImages * lg.Ps); A(l.links, n * (size_t)l.nChunks);
+    A(l.region, n * (size_t)lg.regionStride); l.ownerImages = (batchCtx || lg.wide) ? 0 : (int)std::min<size_t>(n, kMwMaxImages); A(l.owner, (size_t)l.ownerImages * lg.Ps); A(l.links, n * (size_t)l.nChunks);
     // (a full-size log never spills: other contexts get an arena only when olf_debug_lsd_log_cap asks for one)
     l.spillBlocks = lg.regionStride / 2 >= lg.Ps ? 0 : (int)std::max<size_t>(4, n / 16);      // (one image in 16 may have more than half of its pixels in logged regions)
     if (l.spillBlocks) A(l.spill, (size_t)l.spillBlocks * 2 * lg.Ps);
@@ -666,6 +667,24 @@ int olf_debug_seed_sort(olf_ctx* c, const uint32_t* keys, int n, int kthr, int d
     if (cnt < 0 || cnt > n) { set_error("olf_debug_seed_sort: count out of range"); return OLF_ERR_HIP; }
     if (cnt) OLF_HIP_CHECK(hipMemcpy(out, c->lb.keysB, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     return OLF_OK;
+}
+
+// debug / tests: the 64-bit seed-order kernel (lsd_wide.hip) on a caller-supplied key array (field << 32 | payload); full = 0: compared by the field alone, the
+// order libstdc++'s std::sort leaves (convention C.9 variant 1); full = 1: compared as whole words (variant 0); kthr: the keys whose field is <= kthr are listed;
+// depth_limit: introsort's depth limit (-1: 2 * floor(log2 n)).  out receives the listed keys' payloads (the pixel addresses) in order.
+int olf_debug_seed_sort_wide(olf_ctx* c, const uint64_t* keys, int n, int64_t kthr, int depth_limit, int full, uint32_t* out, int32_t* out_n)
+{
+    if (!c || !keys || !out || !out_n || n < 0 || n > c->line.geom.Ps || kthr < 0 || kthr > 0xffffffffll || !c->line.geom.wide) {
+        set_error("olf_debug_seed_sort_wide: bad argument (the context must be a wide one: lsd_n_bins > 1024 or 2^22 pixels and more)"); return OLF_ERR_INVALID; }
+    OLF_HIP_CHECK(hipMemcpyAsync(c->lb.keysA, keys, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    OLF_TRY(launch_lsd_sort_wide(c->line.geom, c->lb, 1, c->stream, n, (long long)kthr, depth_limit, full ? 1 : 0));
+    int cnt = 0;
+    OLF_HIP_CHECK(hipMemcpyAsync(&cnt, c->lb.keyCount, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    OLF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *out_n = cnt;
+    if (cnt < 0 || cnt > n) { set_error("olf_debug_seed_sort_wide: count out of range"); return OLF_ERR_HIP; }
+    if (cnt) OLF_HIP_CHECK(hipMemcpy(out, c->lb.keysB, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    return check_status(c);
 }
 
 // debug / tests: which seed-sort kernel runs (-1: chosen from the batch size; 0: one wave per image; 1 / 2: 4 / 8 waves per image)

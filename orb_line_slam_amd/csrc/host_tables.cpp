@@ -207,7 +207,7 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
     if (p.lsd_refine < 0 || p.lsd_refine > 2) return OLF_ERR_INVALID;        // LSD_REFINE_NONE / STD / ADV
     if (p.conv_seed_order != 0 && p.conv_seed_order != 1) return OLF_ERR_INVALID;
     if (p.conv_libm_float != 0 && p.conv_libm_float != 1) return OLF_ERR_INVALID;
-    if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > 1024 || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
+    if (!(p.lsd_scale > 0) || p.lsd_n_bins < 2 || p.lsd_n_bins > (1 << 24) || !(p.lsd_ang_th > 0 && p.lsd_ang_th < 180)) return OLF_ERR_INVALID;
     const double kPI = 3.1415926535897932384626433832795;
     g.W = W; g.H = H; g.pitchW = (W + 63) & ~63; g.pitchD = (W + 3) & ~3;
     g.scale = p.lsd_scale;
@@ -230,7 +230,9 @@ int LineHostTables::build(const olf_line_params& p, int W, int H, int max_images
     // bench scene logs 105 k of 670 k, its long-line scene 231 k -- and an image that needs more is grown again on a full-size block of the spill arena by a
     // second launch (k_lsd_grow `retry`).  The seed sort's grid-wide top levels keep their 2 * (Ps / 64 + 2 * SS_TOP_JOBS + 4) words of scratch.
     if (max_images > kBatchCtxImages) g.regionStride = ((std::max(g.Ps, 8192) + 31) / 32) * 32;
-    if ((long)g.Ws * g.Hs >= (1L << 22) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
+    // (more than 1024 bins or 2^22 pixels and more: the 64-bit keys of lsd_wide.hip -- the capacity path; 2^27 pixels bound the 32-bit index arithmetic)
+    if ((long)g.Ws * g.Hs >= (1L << 27) || g.Ws < 8 || g.Hs < 8 || g.Ws > 32767 || g.Hs > 32767) return OLF_ERR_INVALID;
+    g.wide = (p.lsd_n_bins > 1024 || (long)g.Ws * g.Hs >= (1L << 22)) ? 1 : 0;
     g.prec = kPI * p.lsd_ang_th / 180;
     {   // 2*pi - prec in 64-bit-mantissa arithmetic is exact (two doubles three binades apart), then rounded up to a double
         const long double w = (long double)(2 * kPI) - (long double)g.prec;

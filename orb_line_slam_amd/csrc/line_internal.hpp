@@ -23,6 +23,7 @@ struct LineGeom {
     int Ws, Hs, pitchS, Ps;    // LSD working size, Ps = Ws*Hs
     int nThr;                  // smallest gx^2+gy^2 whose norm sqrt(n/4.0) exceeds rho
     int nBins;
+    int wide;                  // lsd_n_bins > 1024 or Ps >= 2^22: the seed order takes the 64-bit keys of lsd_wide.hip (keysA / keysB hold 8 bytes per pixel), the growth the one-wave agent
     int minRegSize;
     double prec;               // pi * ang_th / 180
     double precWrap;           // smallest double >= 2*pi - prec (exact): n >= precWrap <=> |n - 2*pi| <= prec for n in (3*pi/2, 2*pi + prec]
@@ -148,6 +149,7 @@ constexpr int kMwMaxImages = 3072;           // images per call up to which the 
 constexpr int kMgMaxImages = 64;             // images grown by several workgroups each in one call, at most
 int lsd_seedsort_top_words();      // ints per image of LineDeviceBufs::topBuf
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
+int launch_lsd_sort_wide(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, long long kthrOverride, int depthOverride, int fullOverride);
 
 size_t stereo_lines_prep_bytes(int n_images, int cap);
 int launch_stereo_lines(int W, int H, const olf_stereo_params& P, int n_pairs, const olf_keyline* d_kls, const uint8_t* d_desc,

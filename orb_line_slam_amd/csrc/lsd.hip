@@ -286,7 +286,10 @@ __device__ __forceinline__ int lsd_bin(int n, double bin_coef, float bin_coef_ha
 
 // CH: pixels per block (CH for the compacted emission, whose chunk counts come from k_lsd_grad; ALLKEYS may take larger chunks: the two halo rows a
 // block evaluates on top of its chunk are 73 % extra at 4096 pixels and a 1490-pixel row, 36 % at 8192)
-template <bool OWNER, bool ALLKEYS, int CH>
+// WIDE (lsd_wide.hip): lsd_n_bins > 1024 or a working image of 2^22 pixels and more -- the key is the 64-bit word (n_bins - 1 - bin) << 32 | address (the key
+// buffers hold 8 bytes per pixel then), the bin is the reference's double expression throughout (the float shortcut's error bound assumes bins below 1024) and
+// the row of a pixel comes from a real division (the multiply-shift pair is exact below 2^22 only)
+template <bool OWNER, bool ALLKEYS, int CH, bool WIDE = false>
 __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict__ gradAll, const LineGeom* __restrict__ gp,
                                                   const int* __restrict__ maxN, const int* __restrict__ chunkCnt, uint32_t* __restrict__ keys,
                                                   int* __restrict__ keyCount, uint32_t* __restrict__ owner, const float* __restrict__ angDeg,
@@ -330,15 +333,21 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
             // the std::sort key of every pixel of the chunk itself (not of the halo rows), while its gradient word is in a register: a second pass over
             // the chunk would load every word again, one dependent L2 round trip per pixel and thread (16.5 -> 12 ms per 6144 images)
             uint32_t* kall = keys + (size_t)img * Ps;
+            unsigned long long* kallW = reinterpret_cast<unsigned long long*>(keys) + (size_t)img * Ps;
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 const int idx = i0 + u * KEYS_THREADS;
                 if (idx >= c0 && idx < min(Ps, c0 + CH)) {
-                    const int y = (int)(__umulhi((uint32_t)idx, divM) >> divS), x = idx - y * Ws;
+                    const int y = WIDE ? idx / Ws : (int)(__umulhi((uint32_t)idx, divM) >> divS), x = idx - y * Ws;
                     if (x < Ws - 1 && y < Hs - 1) {
                         const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
+                        if (WIDE) {
+                            const int bin = (int)(sqrt_quarter(gx * gx + gy * gy) * bin_coef);
+                            kallW[(size_t)y * (Ws - 1) + x] = ((unsigned long long)(uint32_t)(nBins1 - bin) << 32) | (unsigned long long)(uint32_t)idx;
+                        } else {
                         const int bin = lsd_bin(gx * gx + gy * gy, bin_coef, bin_coef_half_f);
                         kall[y * (Ws - 1) + x] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx;
+                        }
                     }
                 }
             }
@@ -376,6 +385,7 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     }
     __syncthreads();
     uint32_t* kout = keys + (size_t)img * Ps + s_base;
+    unsigned long long* koutW = reinterpret_cast<unsigned long long*>(keys) + (size_t)img * Ps + s_base;
     // (ALLKEYS: a per-block table of the undefined pixels' bins -- gx^2 + gy^2 < nThr -- with the defined ones keyed by the dense loop below was
     // slower, 22.8 against 16.9 ms per 6144 images: the dense loop's stores then scatter and nearly every wave still holds a defined pixel)
     // dense over the defined pixels: bin -> key, and the isolated-seed test against the neighbours' angles in LDS
@@ -420,7 +430,8 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
         }
         if (iso) grad[idx] = (ALLKEYS ? grad[idx] : p) | kIso;       // other blocks only read the NOTDEF bit and the gradient pair of this word
         if (OWNER) owner[(size_t)img * Ps + idx] = 0xffffffffu;       // nobody has claimed the pixel (multi-wave growth, lsd_grow.hip)
-        if (!ALLKEYS) kout[t] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx;
+        if (!ALLKEYS) { if (WIDE) koutW[t] = ((unsigned long long)(uint32_t)(nBins1 - bin) << 32) | (unsigned long long)(uint32_t)idx;
+                        else kout[t] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx; }
     }
     if (!ALLKEYS && chunk == nChunks - 1 && threadIdx.x == 0) keyCount[img * 32] = s_base + n3;
 }
@@ -901,6 +912,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                                  SegCand* __restrict__ candAll, int retry)
 {
     OLF_SET_AGENT_PRIO();
+    // PF bit 32 = WIDE (lsd_wide.hip: lsd_n_bins > 1024 or a working image of 2^22 pixels and more): the seed list holds plain 32-bit addresses, 2 Ps words per image
+    constexpr bool WIDE = (PF & 32) != 0;
+    constexpr uint32_t kAddrMask = WIDE ? 0xffffffffu : 0x3fffffu;
     __shared__ uint32_t s_ring[RING];
     __shared__ __attribute__((aligned(16))) int s_pend[PEND];
     const LineGeom& g = *gp;
@@ -910,7 +924,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     if (growFmt && growFmt[img] != -1) return;
     const int Ws = g.Ws, Hs = g.Hs;
     uint32_t* grad = gradAll + (size_t)img * g.Ps;
-    const uint32_t* keys = keysAll + (size_t)img * g.Ps;
+    const uint32_t* keys = keysAll + (size_t)img * g.Ps * (WIDE ? 2 : 1);
     // the pixel log: (x | y << 16, gradient word) per pixel -- k_lsd_rect needs the gradient norm of every region pixel and reads it from here
     // instead of gathering the word again
     // The log: the image's own (g.logCap entries -- every pixel, or half of them in a batch context) or, in the RETRY launch, a full-size block of the spill
@@ -976,6 +990,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
 #define ST_FLUSH
 #endif
     constexpr bool PIPE = !REFINE && (PF & 1), PFSEED = !REFINE && (PF & 2), PFCAND = !REFINE && (PF & 4), WIN = !REFINE && (PF & 8), CHEAP = !REFINE && (PF & 16);
+
     const float tanLo = g.alignTanLo, tanHi = g.alignTanHi;      // (a tolerance too wide for the folded test -- alignTanLo < 0 -- takes the kernel without the bit: launch_lsd_grow)
     constexpr float kAlDelta = 1e-4f;      // sums shorter than this decide nothing (fastAtan2 of a vanishing vector is dominated by its epsilon)
 // the lanes whose direction DIR is aligned / not aligned with the sums (SX, SY) for certain (garbage in the lanes that hold no table entry)
@@ -1011,7 +1026,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
     uint32_t wN = kUsed;
     unsigned long long deadN = 0;
     if (PIPE) {
-        addrN = lane < nkeys ? (int)(keyNext & 0x3fffffu) : 0;
+        addrN = lane < nkeys ? (int)(keyNext & kAddrMask) : 0;
         wN = lane < nkeys ? grad[addrN] : kUsed;
         keyNext = 64 + lane < nkeys ? keys[64 + lane] : 0u;
     }
@@ -1023,7 +1038,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
         if (PIPE) {
             addr = addrN; wseed = wN; dead = deadN;
             const bool validN = base + 64 + lane < nkeys;
-            addrN = validN ? (int)(keyNext & 0x3fffffu) : 0;
+            addrN = validN ? (int)(keyNext & kAddrMask) : 0;
             // (the new requests go out BEHIND the wait for the old ones: tied to the arrival of this window's words, or the compiler hoists the key
             // load above that wait and every window waits for a request it has just made)
             int kidx = base + 128 + lane;
@@ -1032,7 +1047,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             keyNext = kidx < nkeys ? keys[kidx] : 0u;
             deadN = 0;
         } else {
-            addr = valid ? (int)(keyNext & 0x3fffffu) : 0;
+            addr = valid ? (int)(keyNext & kAddrMask) : 0;
             keyNext = base + 64 + lane < nkeys ? keys[base + 64 + lane] : 0u;
             wseed = valid ? grad[addr] : kUsed;
         }
@@ -1093,7 +1108,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
             reg_angle = rlane_d(seedAng, l);
             float sumdx = __int_as_float(rlane(__float_as_int(seedSum.x), l)), sumdy = __int_as_float(rlane(__float_as_int(seedSum.y), l));
             // (seed / Ws through the host's exact multiply-shift pair: 4 scalar instructions where the compiler's division by a run-time value takes 20)
-            const uint32_t sy0 = __umulhi((uint32_t)seed, divM) >> divS, sx0 = (uint32_t)seed - sy0 * (uint32_t)Ws;
+            const uint32_t sy0 = WIDE ? (uint32_t)seed / (uint32_t)Ws : __umulhi((uint32_t)seed, divM) >> divS, sx0 = (uint32_t)seed - sy0 * (uint32_t)Ws;
             int i = 0;
             if (WIN) {
                 // ---- window phase: gather the 7 x 7 around the seed, one lane per pixel
@@ -1176,7 +1191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REFINE == 2 
                                 if (!CHEAP) reg_angle = rlane_d(thOwn, mLane);
                             }
                             live &= ~acc1; accM |= acc1;
-                            if (const unsigned long long rm = acc1 & ~kD2) ringAt = min(ringAt, n0 + __popcll(acc1 & ((1ull << __builtin_ctzll(rm)) - 1ull)));
+                            if (const unsigned long long rm = acc1 & ~kD2) ringAt = min(ringAt, n0 + (int)__popcll(acc1 & ((1ull << __builtin_ctzll(rm)) - 1ull)));      // ((int): min(int, unsigned) resolves to the double overload)
                             alM = CHEAP ? WIN_ALIGNED_C(sumdx, sumdy, ({ ENSURE_ANGLE(); reg_angle; })) : WIN_ALIGNED(reg_angle);
                             cand &= after;                                   // the entry's later neighbours, under the new angle
                             al = cand & alM;
@@ -1798,12 +1813,13 @@ __global__ __launch_bounds__(256) void k_lsd_emit(const LineGeom* __restrict__ g
 // ---------------------------------------------------------------------------------------------
 int launch_lsd_sort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s);
 int launch_lsd_seedsort(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, int kthrOverride, int depthOverride);
+int launch_lsd_sort_wide(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStream_t s, int nOverride, long long kthrOverride, int depthOverride, int fullOverride);
 
 int lsd_grow_waves(int n_images);
 // the growth kernel a batch of n_images takes: 0 the one-wave agent, > 0 waves per image of the multi-wave kernel
 // (lsd_refine = STD runs in the one-wave agent only)
 // (a call of more images than the owner words are allocated for -- kMwMaxImages -- takes the one-wave agent whatever is forced)
-static int lsd_grow_path(const LineGeom& g, const LineDeviceBufs& b, int n_images) { return (g.refine || n_images > b.ownerImages) ? 0 : b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
+static int lsd_grow_path(const LineGeom& g, const LineDeviceBufs& b, int n_images) { return (g.refine || g.wide || n_images > b.ownerImages) ? 0 : b.forceNW >= 0 ? b.forceNW : lsd_grow_waves(n_images); }
 
 int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, int in_pitch, int n_images, hipStream_t s)
 {
@@ -1837,6 +1853,13 @@ int launch_lsd_front(const LineGeom& g, LineDeviceBufs& b, const uint8_t* d_in, 
         const size_t lds = (size_t)(CHK + 2 * g.Ws + 2) * sizeof(float);
         if (lds > 60 * 1024) { set_error("LSD image wider than the key kernel's LDS window"); return OLF_ERR_CAPACITY; }
         const bool ow = lsd_grow_path(g, b, n_images) != 0;
+        if (g.wide) {      // 64-bit keys, both conventions into keysA (lsd_wide.hip sorts them in place and lists the addresses in keysB)
+            if (g.seedOrder == 1) hipLaunchKernelGGL((k_lsd_keys<false, true, LG_CHUNK, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            else hipLaunchKernelGGL((k_lsd_keys<false, false, LG_CHUNK, true>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, b.keysA, b.keyCount, b.owner, b.angDeg, nChunks, total);
+            OLF_HIP_CHECK(hipGetLastError());
+            if (b.sortEvent) OLF_HIP_CHECK(hipEventRecord(b.sortEvent, s));
+            return launch_lsd_sort_wide(g, b, n_images, s, -1, -1, -1, -1);
+        }
 #define KEYS_LAUNCH(OW, AK, C, KBUF) hipLaunchKernelGGL((k_lsd_keys<OW, AK, C>), dim3(total), dim3(KEYS_THREADS), lds, s, b.grad, b.geom, b.maxN, b.chunkCnt, KBUF, b.keyCount, b.owner, b.angDeg, nChunks, total)
         if (g.seedOrder == 1) {
             if (big) { if (ow) KEYS_LAUNCH(true, true, 8192, b.keysA); else KEYS_LAUNCH(false, true, 8192, b.keysA); }
@@ -1910,7 +1933,14 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     // arena; every other workgroup of it exits at once
     for (int RETRY = 0; RETRY < (g.logCap < g.Ps ? 2 : 1); ++RETRY) {
     // (lsd_refine: the candidates go to keysA -- keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
-    if (g.refine >= 2)
+    if (g.wide) {
+        // (64-bit sort keys: the plain agent -- no seed pipeline, no window phase -- reading 32-bit addresses; the capacity path, lsd_wide.hip)
+#define GROWW(RF) hipLaunchKernelGGL((k_lsd_grow<RF, 32>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
+                           RF ? (RegionRec*)nullptr : reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, \
+                           RF ? reinterpret_cast<SegCand*>(b.keysA) : (SegCand*)nullptr, RETRY)
+        if (g.refine >= 2) GROWW(2); else if (g.refine) GROWW(1); else GROWW(0);
+#undef GROWW
+    } else if (g.refine >= 2)
         hipLaunchKernelGGL((k_lsd_grow<2, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
                            (RegionRec*)nullptr, b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, reinterpret_cast<SegCand*>(b.keysA), RETRY);
     else if (g.refine)

@@ -170,6 +170,22 @@ def introsort_keys(keys, depth_limit):
     return out
 
 
+def std_sort_keys64(keys, full=False):
+    """std::sort on 64-bit keys (field << 32 | payload): by the field alone, or (full) as whole words -- the real library call"""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    out = np.empty_like(keys)
+    _L.orc_std_sort_keys64(_p(keys), len(keys), int(bool(full)), _p(out))
+    return out
+
+
+def introsort_keys64(keys, depth_limit, full=False):
+    """libstdc++'s introsort restated with an explicit depth limit, 64-bit keys"""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    out = np.empty_like(keys)
+    _L.orc_introsort_keys64(_p(keys), len(keys), int(depth_limit), int(bool(full)), _p(out))
+    return out
+
+
 def line_extract(img, lp, use_std_sort=False, cap=None, all_cap=20000):
     img = np.ascontiguousarray(img)
     h, w = img.shape

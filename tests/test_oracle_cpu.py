@@ -263,6 +263,22 @@ def test_introsort_restatement_equals_std_sort(oracle):
     assert not np.array_equal(oracle.std_sort_keys(keys), keys[np.argsort(k, kind="stable")])
 
 
+def test_introsort_restatement_equals_std_sort_64bit_keys(oracle):
+    """the same pin for the 64-bit keys of the capacity path (csrc/lsd_wide.hip; orc_introsort_keys64 / orc_std_sort_keys64): by the field alone and as whole
+    words, more than 1024 distinct fields"""
+    rng = np.random.default_rng(12)
+    for n in (0, 1, 16, 17, 100, 1000, 70001):
+        for nk in (1, 3, 70000):
+            k = rng.integers(0, nk, n).astype(np.uint64)
+            keys = (k << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+            lim = 2 * (int(n).bit_length() - 1) if n > 0 else 0
+            want = oracle.std_sort_keys64(keys)
+            assert np.array_equal(oracle.introsort_keys64(keys, lim), want), (n, nk)
+            assert np.array_equal(np.sort(want >> np.uint64(32), kind="stable"), want >> np.uint64(32))
+            perm = keys[rng.permutation(n)]
+            assert np.array_equal(oracle.std_sort_keys64(perm, full=True), np.sort(keys)) and np.array_equal(oracle.introsort_keys64(perm, lim, full=True), np.sort(keys))
+
+
 def test_lsd_refine_restatement_consistency(oracle):
     """lsd_refine (convention C.14, restated from memory): properties that hold whatever the details -- a density threshold of 0 never
     refines (STD = NONE), a log_eps below every number of false alarms never rejects and never improves (ADV = STD), STD changes segments on
