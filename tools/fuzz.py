@@ -52,8 +52,8 @@ for it in range(N):
     p.line.lsd_scale = float(rng.choice([0.5, 0.8, 0.8, 1.0, 1.2, 1.2, 1.5, 2.0]))
     p.line.lsd_sigma_scale = float(rng.choice([0.6, 0.75]))
     p.line.lsd_quant = float(rng.choice([1.0, 2.0, 3.0]))
-    p.line.lsd_ang_th = float(rng.choice([15.0, 22.5, 30.0]))
-    p.line.lsd_n_bins = int(rng.choice([256, 512, 1024]))
+    p.line.lsd_ang_th = float(rng.choice([15.0, 22.5, 30.0, 22.5, 5.0, 45.0, 70.0, 85.0]))      # (85: beyond the cheap alignment test's range -- the reference-expression kernel)
+    p.line.lsd_n_bins = int(rng.choice([256, 512, 1024, 1024, 1024, 2048, 5000]))      # (> 1024: the 64-bit-key capacity path, lsd_wide.hip)
     p.line.conv_seed_order = int(rng.random() < 0.7)       # convention C.9: mostly the std::sort order (the default), sometimes the raster order
     p.line.lsd_refine = int(rng.choice([0, 0, 0, 0, 1, 1, 2]))   # LSD_REFINE_STD / ADV on some of the draws
     p.line.lsd_log_eps = float(rng.choice([0.0, 0.0, 1.0, -1.0]))
