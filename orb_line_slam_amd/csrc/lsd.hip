@@ -1934,11 +1934,12 @@ int launch_lsd_grow(const LineGeom& g, LineDeviceBufs& b, int n_images, hipStrea
     for (int RETRY = 0; RETRY < (g.logCap < g.Ps ? 2 : 1); ++RETRY) {
     // (lsd_refine: the candidates go to keysA -- keysB still holds the seed list the agent is reading; launch_lsd_rect emits from there)
     if (g.wide) {
-        // (64-bit sort keys: the plain agent -- no seed pipeline, no window phase -- reading 32-bit addresses; the capacity path, lsd_wide.hip)
-#define GROWW(RF) hipLaunchKernelGGL((k_lsd_grow<RF, 32>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
+        // (64-bit sort keys: the agent reading 32-bit addresses, the capacity path of lsd_wide.hip; lsd_ang_th > 80 degrees takes it without the cheap alignment test)
+#define GROWW(RF) hipLaunchKernelGGL((k_lsd_grow<RF, (RF ? 32 : 32 | 27)>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region, \
                            RF ? (RegionRec*)nullptr : reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, \
                            RF ? reinterpret_cast<SegCand*>(b.keysA) : (SegCand*)nullptr, RETRY)
-        if (g.refine >= 2) GROWW(2); else if (g.refine) GROWW(1); else GROWW(0);
+        if (g.refine >= 2) GROWW(2); else if (g.refine) GROWW(1); else if (g.alignTanLo < 0.f) hipLaunchKernelGGL((k_lsd_grow<0, 32 | 11>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
+                           reinterpret_cast<RegionRec*>(b.keysA), b.regCount, b.status, reinterpret_cast<const AngEnt*>(b.angEnt), (int*)nullptr, (SegCand*)nullptr, RETRY); else GROWW(0);
 #undef GROWW
     } else if (g.refine >= 2)
         hipLaunchKernelGGL((k_lsd_grow<2, 0>), dim3(n_images), dim3(64), 0, s, b.geom, b.grad, b.keysB, b.keyCount, b.region,
