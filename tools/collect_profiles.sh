@@ -41,4 +41,5 @@ OLF_AB_SETTINGS="1:512,2:512,4:512" timeout 300 python $R/tools/ab_groups.py 1 8
 timeout 300 bash $R/tools/pair_timeline_full.sh > $O/${T}_pair_timeline.txt 2>&1
 timeout 300 python $R/tools/stress_mg.py 60 2>&1 | grep -v amdgpu.ids > $O/${T}_stress_uneven_load.txt
 timeout 300 python $R/tools/search_latency.py 2>/dev/null | tail -1 > $O/${T}_search_latency.txt
+timeout 300 python $R/tools/wide_latency.py 2>&1 | grep -v amdgpu.ids > $O/${T}_wide_latency.txt
 ls -la $O
