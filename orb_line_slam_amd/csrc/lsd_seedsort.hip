@@ -65,6 +65,24 @@ __device__ __forceinline__ void ss_async_ld(const uint32_t* g, unsigned lds_byte
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
 }
+// NE tiles of one block whose positions are all inside the range: ONE address and one LDS base, the tiles through the instruction's offset field (it advances
+// the memory address and the LDS address together) -- 2 + NE instructions where NE single loads take 6 NE (clamp, 64-bit address, m0, wait state, load)
+template <int NE>
+__device__ __forceinline__ void ss_async_ld_block(const uint32_t* g, unsigned lds_byte_off)
+{
+    static_assert(NE == 1 || NE == 2 || NE == 4 || NE == 8, "tiles per block");
+    if (NE == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
+    else if (NE == 2)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
+    else if (NE == 4)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256\n\tglobal_load_lds_dword %0, off offset:512\n\t"
+                     "global_load_lds_dword %0, off offset:768" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256\n\tglobal_load_lds_dword %0, off offset:512\n\t"
+                     "global_load_lds_dword %0, off offset:768\n\tglobal_load_lds_dword %0, off offset:1024\n\tglobal_load_lds_dword %0, off offset:1280\n\t"
+                     "global_load_lds_dword %0, off offset:1536\n\tglobal_load_lds_dword %0, off offset:1792" :: "v"(g), "s"(lds_byte_off) : "memory", "m0");
+}
 __device__ __forceinline__ unsigned ss_lds_off(const void* p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)reinterpret_cast<uintptr_t>(p)); }
 __device__ __forceinline__ int ss_rank_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
 
@@ -165,15 +183,17 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
                 if (lc + n < rc) {
                     pfL = lc + n;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) ss_async_ld(c.A + min(pfL + 64 * u + lane, hi - 1), ss_lds_off(SL) + 256u * u);
+                    for (int u = 0; u < NE; ++u) { if (pfL + 64 * NE <= hi) { if (u == 0) ss_async_ld_block<NE>(c.A + pfL + lane, ss_lds_off(SL)); }
+                                                   else ss_async_ld(c.A + min(pfL + 64 * u + lane, hi - 1), ss_lds_off(SL) + 256u * u); }
                 }
             }
             int run = 0;
 #pragma unroll
             for (int u = 0; u < NE; ++u) {
                 const int pos = lc + 64 * u + lane;
-                const bool st = pos < L.lim && ssK(L.v[u]) >= Kp;
-                const unsigned long long m = wave_vote(st);
+                // (votes per comparison, combined as lane masks: a vote on the combined predicate materialises the bool -- a v_cndmask + v_cmp pair per tile)
+                const unsigned long long m = wave_vote(pos < L.lim) & wave_vote(ssK(L.v[u]) >= Kp);
+                const bool st = wave_bit(m);
                 L.rk[u] = st ? run + ss_rank_below(m) : -1;
                 if (st) QL[L.rk[u]] = make_uint2((uint32_t)pos, L.v[u]);
                 run += (int)__popcll(m);
@@ -199,15 +219,16 @@ __device__ __forceinline__ int ss_partition(const SsCtx& c, uint2* QL, uint2* QR
                 if (lc < rc - n) {
                     pfR = rc - n - 64 * NE;
 #pragma unroll
-                    for (int u = 0; u < NE; ++u) ss_async_ld(c.A + max(pfR + 64 * u + lane, lo), ss_lds_off(SR) + 256u * u);
+                    for (int u = 0; u < NE; ++u) { if (pfR >= lo) { if (u == 0) ss_async_ld_block<NE>(c.A + pfR + lane, ss_lds_off(SR)); }
+                                                   else ss_async_ld(c.A + max(pfR + 64 * u + lane, lo), ss_lds_off(SR) + 256u * u); }
                 }
             }
             int run = 0;
 #pragma unroll
             for (int u = NE - 1; u >= 0; --u) {
                 const int pos = R.base + 64 * u + lane;
-                const bool st = pos >= R.lim && ssK(R.v[u]) <= Kp;
-                const unsigned long long m = wave_vote(st);
+                const unsigned long long m = wave_vote(pos >= R.lim) & wave_vote(ssK(R.v[u]) <= Kp);
+                const bool st = wave_bit(m);
                 const int cnt = (int)__popcll(m);
                 R.rk[u] = st ? run + cnt - 1 - ss_rank_below(m) : -1;
                 if (st) QR[R.rk[u]] = make_uint2((uint32_t)pos, R.v[u]);
