@@ -128,3 +128,19 @@ def test_line_extract_1080p_at_lsd_scale_2(oracle, seed_order):
     gk, gd = ex(img)
     o = oracle.line_extract(img, p.line)
     assert len(gk) > 100 and np.array_equal(gk, o["kls"]) and np.array_equal(gd, o["desc"]), seed_order
+
+
+def test_wide_keys_in_a_batch_context(oracle):
+    """more than 2048 images per call (a batch context: the LSD work images live inside the key buffers, the pixel log is sized by a bound with a spill arena
+    behind it) with 64-bit keys: 2080 small images at 4096 bins in one call, a sample of them against the oracle"""
+    w, h, n = 208, 160, 2080
+    p = oracle.full_params(300, 60)
+    p.line.lsd_n_bins = 4096
+    ex = ola.Lineextractor(60, 0.025, lsd_n_bins=4096, max_images=n)
+    base = np.stack([synth.stereo_pair(40 + i, w, h)[i & 1] for i in range(16)])
+    imgs = np.tile(base, (n // 16, 1, 1))[:n].copy()
+    kls, desc, counts = ex.extract_batch(imgs)
+    for i in (0, 1, 7, 15, 16, 1033, 2079):
+        o = oracle.line_extract(imgs[i], p.line)
+        c = int(counts[i])
+        assert c > 5 and np.array_equal(kls[i, :c], o["kls"]) and np.array_equal(desc[i, :c], o["desc"]), i
