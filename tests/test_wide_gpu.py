@@ -133,7 +133,7 @@ def test_line_extract_1080p_at_lsd_scale_2(oracle, seed_order):
 def test_wide_keys_in_a_batch_context(oracle):
     """more than 2048 images per call (a batch context: the LSD work images live inside the key buffers, the pixel log is sized by a bound with a spill arena
     behind it) with 64-bit keys: 2080 small images at 4096 bins in one call, a sample of them against the oracle"""
-    w, h, n = 208, 160, 2080
+    w, h, n = 320, 240, 2080
     p = oracle.full_params(300, 60)
     p.line.lsd_n_bins = 4096
     ex = ola.Lineextractor(60, 0.025, lsd_n_bins=4096, max_images=n)
