@@ -69,10 +69,11 @@ typedef struct olf_line_params {
     double  lsd_scale;
     double  lsd_sigma_scale;
     double  lsd_quant;
-    double  lsd_ang_th;
+    double  lsd_ang_th;         /* degrees, (0, 180).  Up to 80 the growth agent decides alignment by dot / cross products under a proven margin */
     double  lsd_log_eps;
     double  lsd_density_th;
-    int32_t lsd_n_bins;
+    int32_t lsd_n_bins;         /* 2 .. 2^24.  Up to 1024 bins and LSD working images below 2^22 pixels (round(lsd_scale w) x round(lsd_scale h)) take the
+                                 * fast path; beyond either the 64-bit-key capacity path (csrc/lsd_wide.hip): same results, about 6 x the time */
     /* conventions where the un-vendored OpenCV decides the result and its version is not pinned by the reference:
      * C.11 conv_gauss_sum256: as in olf_orb_params, for LSD's sigma-0.6 blur and LBD's 5x5 sigma-1 blur.
      * C.10 conv_resize_exact: LSD's x1.2 upsampling, 0: cv::resize INTER_LINEAR (11-bit coefficients); 1: INTER_LINEAR_EXACT (8-bit
