@@ -320,6 +320,54 @@ __global__ __launch_bounds__(KEYS_THREADS) void k_lsd_keys(uint32_t* __restrict_
     const float bin_coef_half_f = 0.5f * (float)bin_coef;
     // (NB independent loads in flight per thread, then their table lookups: the pass is latency bound otherwise)
     constexpr int NB = 8;
+    // ALLKEYS with a chunk of exactly NB x KEYS_THREADS pixels (the batch's form): the chunk's own pixels -- thread t takes c0 + t + 512 u, no position tests but the
+    // image's end -- with their keys, then the two halo rows (angles only).  One predicate per key (inside the image's key area and not in the last column), one
+    // branch for the rare double-precision bin: 25 % fewer instructions than the general loop below, which tests every element against the chunk and the area
+    // with nested branches (1.30 M -> instructions per image in profiles/r6z_*; the kernel is issue bound)
+    constexpr bool SPLIT = ALLKEYS && !WIDE && CH == NB * KEYS_THREADS;
+    if (SPLIT) {
+        uint32_t* kall = keys + (size_t)img * Ps;
+        const int keyEnd = min(Ps, (Hs - 1) * Ws);          // y < Hs - 1  <=>  idx < (Hs - 1) Ws
+        {
+            uint32_t p[NB];
+            float d[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { const int idx = c0 + (int)threadIdx.x + u * KEYS_THREADS; p[u] = idx < Ps ? grad[idx] : kNotDef; }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) d[u] = (p[u] & kNotDef) ? kNaN : angDeg[p[u] & 0x3fffffu];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) s_deg[Ws + 1 + (int)threadIdx.x + u * KEYS_THREADS] = d[u];      // (position idx - lo)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int idx = c0 + (int)threadIdx.x + u * KEYS_THREADS;
+                const int y = (int)(__umulhi((uint32_t)idx, divM) >> divS), x = idx - y * Ws;
+                const int gx = unpack_gx(p[u]), gy = unpack_gy(p[u]);
+                const int n = gx * gx + gy * gy;
+                const float tf = __builtin_amdgcn_sqrtf((float)n) * bin_coef_half_f;
+                int bin = (int)tf;
+                const float fr = tf - (float)bin;
+                const bool valid = (idx < keyEnd) & (x < Ws - 1);
+                if (valid & (n != 0) & ((fr < 1e-3f) | (fr > 0.999f))) bin = (int)(sqrt_quarter(n) * bin_coef);      // (lsd_bin: the reference's double expression near an integer)
+                if (valid) kall[(uint32_t)(idx - y)] = ((uint32_t)(nBins1 - bin) << 22) | (uint32_t)idx;             // (y (Ws - 1) + x = idx - y)
+            }
+        }
+        // the row (+ 1 pixel) above the chunk, then the one below: s_deg positions h and CH + Ws + 1 + h
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int first = side ? c0 + CH : lo, qBase = side ? CH + Ws + 1 : 0;
+            constexpr int NH = 4;
+            for (int h0 = (int)threadIdx.x; h0 < Ws + 1; h0 += NH * KEYS_THREADS) {
+                uint32_t p[NH];
+                float d[NH];
+#pragma unroll
+                for (int u = 0; u < NH; ++u) { const int h = h0 + u * KEYS_THREADS, idx = first + h; p[u] = (h < Ws + 1) & ((unsigned)idx < (unsigned)Ps) ? grad[idx] : kNotDef; }
+#pragma unroll
+                for (int u = 0; u < NH; ++u) d[u] = (p[u] & kNotDef) ? kNaN : angDeg[p[u] & 0x3fffffu];
+#pragma unroll
+                for (int u = 0; u < NH; ++u) if (h0 + u * KEYS_THREADS < Ws + 1) s_deg[qBase + h0 + u * KEYS_THREADS] = d[u];
+            }
+        }
+    } else
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += NB * KEYS_THREADS) {
         uint32_t p[NB];
         float d[NB];
