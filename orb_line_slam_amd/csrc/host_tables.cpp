@@ -147,6 +147,9 @@ int OrbHostTables::build(const olf_orb_params& p, int W, int H)
         const float width = (float)(L.maxBorderX - kMinBorder), height = (float)(L.maxBorderY - kMinBorder);
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
         L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+        // (M = ceil(2^20 / d): e = M d - 2^20 < d, and floor(v M / 2^20) == v / d as long as v e < 2^20 -- v < 2^20 / d; levels are at most 2^14 wide, cells at most 64)
+        L.wCellM = (uint32_t)(((1u << 20) + L.wCell - 1) / L.wCell); L.hCellM = (uint32_t)(((1u << 20) + L.hCell - 1) / L.hCell);
+        if (L.w >= (1 << 14) || L.h >= (1 << 14) || L.wCell > 64 || L.hCell > 64) { L.wCellM = 0; L.hCellM = 0; }      // (0: the kernel divides)
         L.cellBase = cells;
         cells += L.nCols * L.nRows;
         cellCap = std::max(cellCap, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));

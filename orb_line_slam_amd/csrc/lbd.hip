@@ -156,6 +156,7 @@ __global__ __launch_bounds__(64) void k_lbd_prep(const LineGeom* __restrict__ gp
 // row's 16 pixel offsets to LDS, the wave loads them as (4 rows x 16 consecutive samples) per instruction -- 4 to 8 cache lines -- and hands the values back
 // through the same LDS words.  Steep lines keep the direct form (their rows are horizontal: 63 neighbouring pixels per instruction as it is).
 constexpr int LR_U = 16, LR_P = LR_U + 1;      // samples per step; row pitch of the LDS tile in words (17: lanes = rows and lanes = samples both hit distinct banks)
+template <bool LEAN>      // LEAN: the image is smaller than 32768 - 256 pixels a side (chosen at the launch): the lean form of the sample coordinates below
 __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ gp, const uint32_t* __restrict__ dxdyAll,
                                                   const olf_keyline* __restrict__ kls, const int* __restrict__ counts,
                                                   const float2* __restrict__ starts, float4* __restrict__ rowSums, int transposeFlat)
@@ -187,10 +188,21 @@ __global__ __launch_bounds__(256) void k_lbd_rows(const LineGeom* __restrict__ g
         int off[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            int xCor, yCor;
+            if (LEAN) {
+                // round() = half away from zero, (short), clamp to [0, size - 1] -- with coordinates that stay within 256 pixels of the image (a support region is
+                // 63 rows around a line inside the image) the cast is the identity, every negative value clamps to 0 whichever way its tie went, and a positive
+                // tie is round-to-nearest-even bumped when it went down: v_rndne, the exact remainder, one compare, one select, v_med3 -- 7 instructions per
+                // coordinate where the general form takes 12 (k_lbd_rows runs alone at the end of the step: its instructions are the step's time)
+                const float rx = __builtin_rintf(sCorX), ry = __builtin_rintf(sCorY);
+                const float bx = f_sub(sCorX, rx) == 0.5f ? f_add(rx, 1.0f) : rx, by = f_sub(sCorY, ry) == 0.5f ? f_add(ry, 1.0f) : ry;
+                xCor = min(max((int)bx, 0), (int)imageWidth); yCor = min(max((int)by, 0), (int)imageHeight);
+            } else {
             int tc = (int)(short)roundf(sCorX);
-            const int xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
+            xCor = tc < 0 ? 0 : (tc > imageWidth ? imageWidth : tc);
             tc = (int)(short)roundf(sCorY);
-            const int yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+            yCor = tc < 0 ? 0 : (tc > imageHeight ? imageHeight : tc);
+            }
             off[u] = yCor * realWidth + xCor;           // (coordinates past the row end are clamped into the image, the value is unused)
             sCorX = f_add(sCorX, dL0);
             sCorY = f_add(sCorY, dL1);
@@ -356,8 +368,12 @@ int launch_line_select_lbd(const LineGeom& g, const LineDeviceBufs& b, const uin
                        d_counts, reinterpret_cast<unsigned long long*>(b.keysA), (size_t)g.Ps / 2);
     if (!denseDone) OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
     hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
-    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
+    if (g.W + 256 < 32768 && g.H + 256 < 32768)
+        hipLaunchKernelGGL(k_lbd_rows<true>, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                           reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
+    else
+        hipLaunchKernelGGL(k_lbd_rows<false>, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                           reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());
@@ -370,8 +386,12 @@ int launch_lbd_only(const LineGeom& g, const LineDeviceBufs& b, const uint8_t* d
 {
     OLF_TRY_RC(launch_lbd_dense(g, b, d_in, in_pitch, n_images, s));
     hipLaunchKernelGGL(k_lbd_prep, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, d_kls, d_counts, reinterpret_cast<float2*>(b.lbdStarts));
-    hipLaunchKernelGGL(k_lbd_rows, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
-                       reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
+    if (g.W + 256 < 32768 && g.H + 256 < 32768)
+        hipLaunchKernelGGL(k_lbd_rows<true>, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                           reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
+    else
+        hipLaunchKernelGGL(k_lbd_rows<false>, dim3((g.outCap + 3) / 4, n_images), dim3(256), 0, s, b.geom, b.dxdy, d_kls, d_counts,
+                           reinterpret_cast<const float2*>(b.lbdStarts), reinterpret_cast<float4*>(b.rowSums), lbd_rows_transpose());
     hipLaunchKernelGGL(k_lbd_desc, dim3((g.outCap + 63) / 64, n_images), dim3(64), 0, s, b.geom, reinterpret_cast<const float4*>(b.rowSums),
                        d_counts, d_desc);
     OLF_HIP_CHECK(hipGetLastError());

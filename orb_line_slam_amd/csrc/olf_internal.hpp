@@ -81,6 +81,7 @@ struct LevelGeom {
     int offset;             // byte offset of the level inside a per-image pyramid block
     int maxBorderX, maxBorderY;
     int nCols, nRows, wCell, hCell;   // FAST cell grid, src/ORBextractor.cc:783-789
+    uint32_t wCellM, hCellM;          // ceil(2^20 / wCell), ceil(2^20 / hCell): v / cell == (v * M) >> 20 for 0 <= v < 2^14 (k_fast_score's cell of a corner without a division)
     int cellBase;           // index of this level's first cell in the per-image cell arrays
     int quota;              // mnFeaturesPerLevel[level]
     int nIni;               // DistributeOctTree root count

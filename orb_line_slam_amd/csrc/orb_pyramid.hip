@@ -248,7 +248,9 @@ void k_fast_score(const uint8_t* __restrict__ pyr, int pyrBytes, LevelGeom L, in
         const int cur = s_score[id];
         if (cur == 0) continue;
         const int gx = x0 + tx, gy = y0 + ty;
-        const int cj = (gx - xBeg) / L.wCell, ci = (gy - yBeg) / L.hCell;
+        // (the cell of the corner through the host's multiply-shift pair: two 30-instruction divisions per corner otherwise)
+        const int cj = L.wCellM ? (int)(((uint32_t)(gx - xBeg) * L.wCellM) >> 20) : (gx - xBeg) / L.wCell;
+        const int ci = L.hCellM ? (int)(((uint32_t)(gy - yBeg) * L.hCellM) >> 20) : (gy - yBeg) / L.hCell;
         const int lx = (gx - xBeg) - cj * L.wCell, ly = (gy - yBeg) - ci * L.hCell;
         // neighbours outside the cell interior (or outside the scored area, where the tile holds 0) do not count
         const bool xl = lx > 0, xr = lx < L.wCell - 1 && gx + 1 < xEnd, yu = ly > 0, yd = ly < L.hCell - 1 && gy + 1 < yEnd;
