@@ -61,11 +61,19 @@ __global__ __launch_bounds__(256) void k_describe(const OrbGeom* __restrict__ gp
     }
     // (the per-lane constants -- 16 pattern floats, 8 disc weight words -- are read from LDS where they are used: held in registers across the key point they
     // cost 24 VGPRs, i.e. two of the eight waves a SIMD can hold, and the kernel lives on its occupancy)
+    // XCD-aware numbering: workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own), so the blocks x, x + 8, x + 16, ... of an image share
+    // one; they take CONSECUTIVE groups of key point slots -- neighbours in the octree's output order, whose 37 x 37 patches overlap -- instead of every eighth
+    // (OLF_DESC_XCD=0 in the environment of the build's A/B: -DOLF_DESC_XCD=0)
+#ifndef OLF_DESC_XCD
+#define OLF_DESC_XCD 1
+#endif
+    const int nbx = (int)gridDim.x, per = nbx >> 3;
+    const int vblock = (OLF_DESC_XCD && (int)blockIdx.x < per * 8) ? ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int r6 = lane / PDW, c10 = lane - r6 * PDW;      // staging: lanes 0 .. 59 take six rows of ten dwords per step
     uint32_t* patch = s_patch[wv];
 #pragma unroll 1
     for (int q = 0; q < DESC_KPW; ++q) {
-        const int slot = (blockIdx.x * 4 + wv) * DESC_KPW + q;
+        const int slot = (vblock * 4 + wv) * DESC_KPW + q;
         if (slot >= kpTotal) break;
         // which level the slot belongs to, its rank there and its place in the output: lane l holds level l's first slot and count (ONE round trip of two vector
         // loads beside the key point word -- as loops over scalar loads, "while (slot >= lv[level + 1].kpBase)" and "outIdx += lc[l]", these were up to fourteen
